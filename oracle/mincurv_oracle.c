@@ -1,0 +1,529 @@
+/*
+ * oracle/mincurv_oracle.c -- plain-C restatement of the reference's min-curvature hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see mincurv_oracle.h).  Scalar, single-pass, written for clarity:
+ * every update re-samples the whole curve and re-intersects every normal with every ring edge,
+ * exactly as the reference's Python does.  The product (HIP) path shares no code with this file.
+ *
+ * Third-party arithmetic restated here (absent from the reference tree; versions of this image):
+ *   scipy 1.15.3  BSpline.__call__/derivative/basis_element (de Boor's recurrences, the FITPACK
+ *                 splder formula), scipy.integrate.quad -> QUADPACK qk21 nodes and weights.
+ *   qpOASES (via casadi.conic) and GEOS (via shapely): not restated as algorithms; replaced by the
+ *                 exact solution / exact geometry of the same problem (header: "parity unpinned").
+ */
+#define _GNU_SOURCE
+#include "mincurv_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MAXK 7
+
+/* ---------------------------------------------------------------- B-spline kernels */
+
+/* scipy find_interval: largest l in [k, n-1] with t[l] <= x, clamped (extrapolate=True). */
+static int find_interval(const double* t, int nt, int k, double x) {
+  int n = nt - k - 1;
+  int l = k;
+  if (x != x) return -1;
+  while (l + 1 < n && x >= t[l + 1]) ++l;
+  return l;
+}
+
+/* de Boor: the k+1 non-zero basis functions B_{l-k..l} (m-th derivative) at x.
+ * work has 2k+2 entries; result in work[0..k].  Same recurrences scipy's _deBoor_D uses:
+ * k-m value steps  h[n-1] += w (xb-x), h[n] = w (x-xa), w = hh[n-1]/(xb-xa);
+ * then m derivative steps  h[n-1] -= w, h[n] = w, w = j hh[n-1]/(xb-xa). */
+static void deboor_d(const double* t, double x, int k, int l, int m, double* work) {
+  double* h = work;
+  double* hh = work + k + 1;
+  int j, n;
+  h[0] = 1.0;
+  for (j = 1; j <= k - m; ++j) {
+    memcpy(hh, h, (size_t)j * sizeof(double));
+    h[0] = 0.0;
+    for (n = 1; n <= j; ++n) {
+      double xb = t[l + n], xa = t[l + n - j];
+      if (xb == xa) { h[n] = 0.0; continue; }
+      double w = hh[n - 1] / (xb - xa);
+      h[n - 1] += w * (xb - x);
+      h[n] = w * (x - xa);
+    }
+  }
+  for (j = k - m + 1; j <= k; ++j) {
+    memcpy(hh, h, (size_t)j * sizeof(double));
+    h[0] = 0.0;
+    for (n = 1; n <= j; ++n) {
+      double xb = t[l + n], xa = t[l + n - j];
+      if (xb == xa) { h[m] = 0.0; continue; }
+      double w = (double)j * hh[n - 1] / (xb - xa);
+      h[n - 1] -= w;
+      h[n] = w;
+    }
+  }
+}
+
+void orc_bspline_eval(const double* t, int nt, const double* c, int k,
+                      const double* x, int nx, int der, double* out) {
+  double work[2 * ORC_MAXK + 2];
+  for (int i = 0; i < nx; ++i) {
+    int l = find_interval(t, nt, k, x[i]);
+    if (l < 0) { out[i] = NAN; continue; }
+    if (der > k) { out[i] = 0.0; continue; }
+    deboor_d(t, x[i], k, l, der, work);
+    double s = 0.0;
+    for (int a = 0; a <= k; ++a) s += c[l + a - k] * work[a];
+    out[i] = s;
+  }
+}
+
+int orc_bspline_derivative(const double* t, int nt, const double* c, int nc, int k, int nu,
+                           double* t_out, double* c_out) {
+  /* scipy BSpline.derivative: pad c to len(t), then nu times
+   *   c <- (c[1:-1-k] - c[:-2-k]) * k / (t[k+1:-1] - t[1:-k-1]);  c <- r_[c, zeros(k)];
+   *   t <- t[1:-1]; k <- k-1                                                          */
+  int len = nt;
+  double* tc = (double*)malloc((size_t)nt * sizeof(double));
+  double* cc = (double*)calloc((size_t)nt, sizeof(double));
+  memcpy(tc, t, (size_t)nt * sizeof(double));
+  memcpy(cc, c, (size_t)(nc < nt ? nc : nt) * sizeof(double));
+  for (int it = 0; it < nu; ++it) {
+    int m = len - k - 2; /* number of new coefficients */
+    for (int j = 0; j < m; ++j) {
+      double dt = tc[j + k + 1] - tc[j + 1];
+      cc[j] = (cc[j + 1] - cc[j]) * (double)k / dt;
+    }
+    for (int j = m; j < m + k; ++j) cc[j] = 0.0;
+    memmove(tc, tc + 1, (size_t)(len - 2) * sizeof(double));
+    len -= 2;
+    k -= 1;
+  }
+  memcpy(t_out, tc, (size_t)len * sizeof(double));
+  memcpy(c_out, cc, (size_t)len * sizeof(double));
+  free(tc);
+  free(cc);
+  return k;
+}
+
+void orc_basis_element(const double* tk, int k, const double* x, int nx, int der, double* out) {
+  /* scipy: t = r_[(tk[0]-1,)*k, tk, (tk[-1]+1,)*k]; c = zeros_like(t); c[k] = 1 */
+  double tp[3 * ORC_MAXK + 2];
+  double cp[3 * ORC_MAXK + 2];
+  int ntp = 3 * k + 2;
+  for (int i = 0; i < k; ++i) tp[i] = tk[0] - 1.0;
+  for (int i = 0; i < k + 2; ++i) tp[k + i] = tk[i];
+  for (int i = 0; i < k; ++i) tp[2 * k + 2 + i] = tk[k + 1] + 1.0;
+  for (int i = 0; i < ntp; ++i) cp[i] = 0.0;
+  cp[k] = 1.0;
+  orc_bspline_eval(tp, ntp, cp, k, x, nx, der, out);
+}
+
+/* ---------------------------------------------------------------- arc length (QUADPACK qk21) */
+
+static const double XGK[11] = {
+    0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+    0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+    0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+    0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+    0.294392862701460198131126603103866, 0.148874338981631210884826001129720,
+    0.000000000000000000000000000000000};
+static const double WGK[11] = {
+    0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+    0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
+    0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+    0.123491976262065851077958109585166, 0.134709217311473325928054001771707,
+    0.142775938577060080797094273138717, 0.147739104901338491374841515972068,
+    0.149445554002916905664936468389821};
+
+static double speed_at(const double* t, int nt, const double* cx, const double* cy, int k,
+                       double u) {
+  /* models/trajectory.py:225-226 */
+  double dx, dy;
+  orc_bspline_eval(t, nt, cx, k, &u, 1, 1, &dx);
+  orc_bspline_eval(t, nt, cy, k, &u, 1, 1, &dy);
+  return sqrt(dx * dx + dy * dy);
+}
+
+double orc_arc_gk21(const double* t, int nt, const double* cx, const double* cy, int k,
+                    double a, double b) {
+  /* QUADPACK dqk21 summation order: centre, the 5 Gauss nodes (odd), the 5 Kronrod-only nodes */
+  double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a);
+  double resk = WGK[10] * speed_at(t, nt, cx, cy, k, centr);
+  for (int j = 0; j < 5; ++j) {
+    int jtw = 2 * j + 1;
+    double absc = hlgth * XGK[jtw];
+    double f1 = speed_at(t, nt, cx, cy, k, centr - absc);
+    double f2 = speed_at(t, nt, cx, cy, k, centr + absc);
+    resk += WGK[jtw] * (f1 + f2);
+  }
+  for (int j = 0; j < 5; ++j) {
+    int jtwm1 = 2 * j;
+    double absc = hlgth * XGK[jtwm1];
+    double f1 = speed_at(t, nt, cx, cy, k, centr - absc);
+    double f2 = speed_at(t, nt, cx, cy, k, centr + absc);
+    resk += WGK[jtwm1] * (f1 + f2);
+  }
+  return resk * hlgth;
+}
+
+/* ---------------------------------------------------------------- Trajectory / sampling */
+
+void orc_trajectory_init(double* points, int N) {
+  memset(points, 0, (size_t)N * ORC_NCOL * sizeof(double));
+  for (int i = 0; i < N; ++i) {
+    points[i * ORC_NCOL + ORC_IDX] = (double)i;
+    points[i * ORC_NCOL + ORC_ITER_FLAG] = -1.0;
+  }
+}
+
+/* geometry-only part of sample_along (columns X, Y, YAW, CURVATURE): trajectory.py:278-281 */
+static void sample_geometry(const double* t, int nt, const double* cx, const double* cy, int k,
+                            const double* u, int N, double* points) {
+  double* buf = (double*)malloc((size_t)N * 6 * sizeof(double));
+  double *x = buf, *y = buf + N, *dx = buf + 2 * N, *dy = buf + 3 * N, *d2x = buf + 4 * N,
+         *d2y = buf + 5 * N;
+  orc_bspline_eval(t, nt, cx, k, u, N, 0, x);
+  orc_bspline_eval(t, nt, cy, k, u, N, 0, y);
+  orc_bspline_eval(t, nt, cx, k, u, N, 1, dx);
+  orc_bspline_eval(t, nt, cy, k, u, N, 1, dy);
+  orc_bspline_eval(t, nt, cx, k, u, N, 2, d2x);
+  orc_bspline_eval(t, nt, cy, k, u, N, 2, d2y);
+  for (int i = 0; i < N; ++i) {
+    double* p = points + (size_t)i * ORC_NCOL;
+    p[ORC_X] = x[i];
+    p[ORC_Y] = y[i];
+    p[ORC_YAW] = atan2(dy[i], dx[i]);
+    /* __get_turn_radius, trajectory.py:253-260 */
+    double s2 = dx[i] * dx[i] + dy[i] * dy[i];
+    double curvature = fabs(dx[i] * d2y[i] - dy[i] * d2x[i]) / sqrt(s2 * s2 * s2);
+    p[ORC_CURVATURE] = 1.0 / fabs(curvature);
+  }
+  free(buf);
+}
+
+void orc_sample_along(const double* t, int nt, const double* cx, const double* cy, int k,
+                      double length, const double* u, int N, double* points) {
+  orc_trajectory_init(points, N);
+  sample_geometry(t, nt, cx, cy, k, u, N, points);
+  /* trajectory.py:283-289 */
+  for (int i = 1; i < N; ++i) {
+    points[(size_t)i * ORC_NCOL + ORC_DIST_BWD] =
+        points[(size_t)(i - 1) * ORC_NCOL + ORC_DIST_BWD] +
+        orc_arc_gk21(t, nt, cx, cy, k, u[i - 1], u[i]);
+  }
+  for (int i = 0; i < N; ++i)
+    points[(size_t)i * ORC_NCOL + ORC_DIST_FWD] = length - points[(size_t)i * ORC_NCOL + ORC_DIST_BWD];
+}
+
+/* ---------------------------------------------------------------- fill_bounds */
+
+/* Closest intersection of the normal segment  p + s*d, s in [-1,1]  (d = max_dist*(cos,sin)(yaw+norm))
+ * with the closed polyline `ring`.  trajectory.py:84-129: LineString((min_norm,max_norm)) ∩ ring,
+ * keep the Point closest to the waypoint; no intersection -> the waypoint itself (:127).
+ * The hit is expressed as  p + s*d  with  s = cross(P-p, Q-P) / cross(d, Q-P)  for the ring edge
+ * (P,Q) the line crosses (cross(P-p,d) and cross(Q-p,d) of opposite sign); distance = |s|*max_dist.
+ * Ties keep the lowest edge index. */
+static void closest_hit(double px, double py, double yaw_norm, double max_dist,
+                        const double* ring, int nr, double* bx, double* by) {
+  double dx = max_dist * cos(yaw_norm), dy = max_dist * sin(yaw_norm);
+  double best = INFINITY, best_s = 0.0;
+  int found = 0;
+  for (int j = 0; j < nr; ++j) {
+    int j1 = (j + 1 == nr) ? 0 : j + 1;
+    double ax = ring[2 * j] - px, ay = ring[2 * j + 1] - py;
+    double bxx = ring[2 * j1] - px, byy = ring[2 * j1 + 1] - py;
+    double ea = ax * dy - ay * dx;
+    double eb = bxx * dy - byy * dx;
+    if ((ea > 0.0 && eb > 0.0) || (ea < 0.0 && eb < 0.0)) continue; /* edge on one side of the line */
+    double sx = bxx - ax, sy = byy - ay;
+    double den = dx * sy - dy * sx;
+    if (den == 0.0) continue; /* parallel / collinear: not a Point intersection (:104-106) */
+    double s = (ax * sy - ay * sx) / den;
+    double as = fabs(s);
+    if (as > 1.0) continue; /* beyond +-max_dist */
+    if (as < best) { best = as; best_s = s; found = 1; }
+  }
+  if (found) { *bx = px + best_s * dx; *by = py + best_s * dy; }
+  else { *bx = px; *by = py; }
+}
+
+void orc_fill_bounds(double* points, int N, const double* ringL, int nL,
+                     const double* ringR, int nR, double max_dist) {
+  /* trajectory.py:131-141 */
+  for (int i = 0; i < N; ++i) {
+    double* p = points + (size_t)i * ORC_NCOL;
+    closest_hit(p[ORC_X], p[ORC_Y], p[ORC_YAW] + M_PI / 2.0, max_dist, ringL, nL,
+                &p[ORC_LBX], &p[ORC_LBY]);
+    closest_hit(p[ORC_X], p[ORC_Y], p[ORC_YAW] + (-M_PI / 2.0), max_dist, ringR, nR,
+                &p[ORC_RBX], &p[ORC_RBY]);
+  }
+}
+
+/* ---------------------------------------------------------------- cost / constraint / QP */
+
+/* support mask of control point idx on the uniform grid u_i = i/N: optimizer.py:25-31, 223-229.
+ * ts = linspace(0,1,N,endpoint=False) computes i*(1/N) in numpy: step = 1/N, u_i = i*step. */
+static double grid_u(int i, int N) { return (double)i * (1.0 / (double)N); }
+
+static void support_range(const double* t, int k, int idx, int N, int* i0, int* i1) {
+  /* samples are sorted, so the mask (u >= t[idx]) & (u < t[idx+k+1]) is one contiguous run */
+  double ts = t[idx], te = t[idx + k + 1];
+  int a = 0;
+  while (a < N && !(grid_u(a, N) >= ts)) ++a;
+  int b = a;
+  while (b < N && grid_u(b, N) < te) ++b;
+  *i0 = a;
+  *i1 = b;
+}
+
+int orc_min_curvature_cost(const double z[2], int idx, const double* t, int nt,
+                           const double* cx, const double* cy, int k, int N,
+                           double H[4], double g[2]) {
+  int i0, i1;
+  support_range(t, k, idx, N, &i0, &i1);
+  int M = i1 - i0;
+  H[0] = H[1] = H[2] = H[3] = 0.0;
+  g[0] = g[1] = 0.0;
+  if (M <= 0) return 0;
+  double* buf = (double*)malloc((size_t)M * 6 * sizeof(double));
+  double *ti = buf, *dTx = buf + M, *dTy = buf + 2 * M, *d2Tx = buf + 3 * M, *d2Ty = buf + 4 * M,
+         *B = buf + 5 * M;
+  for (int i = 0; i < M; ++i) ti[i] = grid_u(i0 + i, N);
+  /* optimizer.py:33-36: the derivative splines are built (splder) and then evaluated */
+  double* td = (double*)malloc((size_t)nt * 2 * sizeof(double));
+  double* cd = td + nt;
+  int k1 = orc_bspline_derivative(t, nt, cx, nt - k - 1, k, 1, td, cd);
+  orc_bspline_eval(td, nt - 2, cd, k1, ti, M, 0, dTx);
+  k1 = orc_bspline_derivative(t, nt, cy, nt - k - 1, k, 1, td, cd);
+  orc_bspline_eval(td, nt - 2, cd, k1, ti, M, 0, dTy);
+  int k2 = orc_bspline_derivative(t, nt, cx, nt - k - 1, k, 2, td, cd);
+  orc_bspline_eval(td, nt - 4, cd, k2, ti, M, 0, d2Tx);
+  k2 = orc_bspline_derivative(t, nt, cy, nt - k - 1, k, 2, td, cd);
+  orc_bspline_eval(td, nt - 4, cd, k2, ti, M, 0, d2Ty);
+  /* optimizer.py:64 */
+  orc_basis_element(t + idx, k, ti, M, 2, B);
+  double hxx = 0, hyy = 0, s_fx_pxx_b = 0, s_fy_pxy_b = 0, s_fy_pyy_b = 0, s_b_pxy_fx = 0;
+  for (int i = 0; i < M; ++i) {
+    /* optimizer.py:66-76 (v = 1) */
+    double Fx = d2Tx[i] - B[i] * z[0];
+    double Fy = d2Ty[i] - B[i] * z[1];
+    double s2 = dTx[i] * dTx[i] + dTy[i] * dTy[i];
+    double denom = s2 * s2 * s2;
+    double Pxx = (dTy[i] * dTy[i]) / denom;
+    double Pxy = (-2.0 * dTx[i] * dTy[i]) / denom;
+    double Pyy = (dTx[i] * dTx[i]) / denom;
+    hxx += B[i] * Pxx * B[i];
+    hyy += B[i] * Pyy * B[i];
+    s_fx_pxx_b += Fx * Pxx * B[i];
+    s_fy_pxy_b += Fy * Pxy * B[i];
+    s_fy_pyy_b += Fy * Pyy * B[i];
+    s_b_pxy_fx += B[i] * Pxy * Fx;
+  }
+  /* optimizer.py:83: H = 2 (Bx' Pxx Bx + By' Pyy By) -- the Pxy cross term is commented out (:82) */
+  H[0] = 2.0 * hxx;
+  H[3] = 2.0 * hyy;
+  /* optimizer.py:85: g = (Fx'PxxBx + Fy'PxyBy + Fy'PyyBy) + (Bx'PxxFx + By'PxyFx + By'PyyFy)' */
+  g[0] = s_fx_pxx_b + s_fx_pxx_b;
+  g[1] = (s_fy_pxy_b + s_fy_pyy_b) + (s_b_pxy_fx + s_fy_pyy_b);
+  free(td);
+  free(buf);
+  return M;
+}
+
+int orc_track_constraint(int idx, const double* t, int nt, const double* cx, const double* cy,
+                         int k, const double* points, int N,
+                         double* A, double* lba, double* uba) {
+  (void)nt;
+  int i0, i1;
+  support_range(t, k, idx, N, &i0, &i1);
+  int M = i1 - i0;
+  if (M <= 0) return 0;
+  double* ti = (double*)malloc((size_t)M * 2 * sizeof(double));
+  double* b = ti + M;
+  for (int i = 0; i < M; ++i) ti[i] = grid_u(i0 + i, N);
+  orc_basis_element(t + idx, k, ti, M, 0, b); /* optimizer.py:231-233 (b_x == b_y: same knots) */
+  double zx = cx[idx], zy = cy[idx];         /* :235 */
+  for (int i = 0; i < M; ++i) {
+    const double* p = points + (size_t)(i0 + i) * ORC_NCOL;
+    double nzx = p[ORC_X] - b[i] * zx;       /* :236 */
+    double nzy = p[ORC_Y] - b[i] * zy;
+    lba[2 * i] = fmin(p[ORC_LBX], p[ORC_RBX]) - nzx;     /* :243-248 */
+    lba[2 * i + 1] = fmin(p[ORC_LBY], p[ORC_RBY]) - nzy;
+    uba[2 * i] = fmax(p[ORC_LBX], p[ORC_RBX]) - nzx;
+    uba[2 * i + 1] = fmax(p[ORC_LBY], p[ORC_RBY]) - nzy;
+    A[4 * i + 0] = b[i]; A[4 * i + 1] = 0.0;             /* :251-253 */
+    A[4 * i + 2] = 0.0;  A[4 * i + 3] = b[i];
+  }
+  free(ti);
+  return M;
+}
+
+int orc_qp_solve_separable(const double H[4], const double g[2], const double* A,
+                           const double* lba, const double* uba, int M, double x[2]) {
+  /* per coordinate c: minimise 1/2 H_cc z^2 + g_c z over the interval cut out by the rows
+   * a_i z in [lba_i, uba_i]; rows with a_i == 0 only decide feasibility. */
+  for (int c = 0; c < 2; ++c) {
+    double h = H[3 * c], gc = g[c];
+    if (!(h > 0.0) || !isfinite(h) || !isfinite(gc)) return 3;
+    double lo = -INFINITY, hi = INFINITY;
+    for (int i = 0; i < M; ++i) {
+      int r = 2 * i + c;
+      double a = A[2 * r + c];
+      double l = lba[r], u = uba[r];
+      if (!isfinite(a) || l != l || u != u) return 3;
+      if (a > 0.0) {
+        double ql = l / a, qu = u / a;
+        if (ql > lo) lo = ql;
+        if (qu < hi) hi = qu;
+      } else if (a < 0.0) {
+        double ql = u / a, qu = l / a;
+        if (ql > lo) lo = ql;
+        if (qu < hi) hi = qu;
+      } else {
+        if (l > 0.0 || u < 0.0) return 2;
+      }
+    }
+    if (lo > hi) return 2;
+    double z = -gc / h;
+    if (z < lo) z = lo;
+    if (z > hi) z = hi;
+    x[c] = z;
+  }
+  return 0;
+}
+
+/* ---------------------------------------------------------------- the sweep driver */
+
+typedef struct {
+  const double* t; int nt; double* cx; double* cy; int k; int n;
+  double* points; int N; double* u;
+  const double* ringL; int nL; const double* ringR; int nR;
+  double *A, *lba, *uba;
+} sweep_state;
+
+/* optimize(i, ts, td): optimizer.py:263-293.  Returns 1 on success, 0 when the QP "raised". */
+static int optimize_one(sweep_state* s, int i) {
+  double z0[2] = {s->cx[i], s->cy[i]};
+  double H[4], g[2], x[2];
+  orc_min_curvature_cost(z0, i, s->t, s->nt, s->cx, s->cy, s->k, s->N, H, g);
+  int M = orc_track_constraint(i, s->t, s->nt, s->cx, s->cy, s->k, s->points, s->N,
+                               s->A, s->lba, s->uba);
+  if (orc_qp_solve_separable(H, g, s->A, s->lba, s->uba, M, x) != 0) return 0;
+  int n = s->n;
+  /* :280-285 (periodic wrap, hard-coded for k = 5 in the reference) */
+  s->cx[i] = x[0];           s->cy[i] = x[1];
+  s->cx[0] = s->cx[n - 5];   s->cy[0] = s->cy[n - 5];
+  s->cx[1] = s->cx[n - 4];   s->cy[1] = s->cy[n - 4];
+  s->cx[n - 3] = s->cx[2];   s->cy[n - 3] = s->cy[2];
+  s->cx[n - 2] = s->cx[3];   s->cy[n - 2] = s->cy[3];
+  s->cx[n - 1] = s->cx[4];   s->cy[n - 1] = s->cy[4];
+  /* :286-288: new_td = ts.sample_along(ts=td.ts()); SPEED carried over; bounds refilled.
+   * Only X, Y, YAW (and the bound columns) of new_td are ever read again inside the sweep, so the
+   * arc-length columns (N quad calls per update in the reference) are filled once at the end. */
+  sample_geometry(s->t, s->nt, s->cx, s->cy, s->k, s->u, s->N, s->points);
+  orc_fill_bounds(s->points, s->N, s->ringL, s->nL, s->ringR, s->nR, 100.0); /* race_track.py:104 */
+  return 1;
+}
+
+void orc_run_min_curvature_qp(const double* t, int nt, double* cx, double* cy, int k,
+                              double length, double* points, int N,
+                              const double* ringL, int nL, const double* ringR, int nR,
+                              const int* i_start, int max_iter, int* n_success) {
+  sweep_state s;
+  s.t = t; s.nt = nt; s.cx = cx; s.cy = cy; s.k = k; s.n = nt - k - 1;
+  s.points = points; s.N = N;
+  s.ringL = ringL; s.nL = nL; s.ringR = ringR; s.nR = nR;
+  s.u = (double*)malloc((size_t)N * sizeof(double));
+  for (int i = 0; i < N; ++i) s.u[i] = grid_u(i, N);
+  s.A = (double*)malloc((size_t)N * 8 * sizeof(double));
+  s.lba = s.A + (size_t)N * 4;
+  s.uba = s.A + (size_t)N * 6;
+  /* :257-259 -- traj_in_d comes from sample_along of the same spline (tests/test_optimizer.py:18);
+   * the caller passes that table, we (re)derive the geometry columns so that `points` may also be
+   * handed in uninitialised. */
+  sample_geometry(t, nt, cx, cy, k, s.u, N, points);
+  orc_fill_bounds(points, N, ringL, nL, ringR, nR, 100.0);
+  int n = s.n;
+  for (int j = 0; j < max_iter; ++j) {
+    /* :296-303 */
+    int ignore_front = k / 2, ignore_rear = k - ignore_front;
+    int i_max = n - ignore_rear, i_min = ignore_front;
+    int st = i_start[j];
+    int ok = 0;
+    for (int i = 0; i < i_max - i_min; ++i) { /* :305-313 */
+      int kk = i + st;
+      if (kk >= i_max) kk = kk - i_max + i_min;
+      ok += optimize_one(&s, kk);
+    }
+    n_success[2 * j] = ok;
+    ok = 0;
+    for (int i = i_max - i_min; i > 0; --i) { /* :316-324 */
+      int kk = i + st;
+      if (kk >= i_max) kk = kk - i_max + i_min;
+      ok += optimize_one(&s, kk);
+    }
+    n_success[2 * j + 1] = ok;
+  }
+  /* final table: arc-length columns of the last sample_along (trajectory.py:283-289) */
+  for (int i = 1; i < N; ++i)
+    points[(size_t)i * ORC_NCOL + ORC_DIST_BWD] =
+        points[(size_t)(i - 1) * ORC_NCOL + ORC_DIST_BWD] + orc_arc_gk21(t, nt, cx, cy, k, s.u[i - 1], s.u[i]);
+  for (int i = 0; i < N; ++i)
+    points[(size_t)i * ORC_NCOL + ORC_DIST_FWD] = length - points[(size_t)i * ORC_NCOL + ORC_DIST_BWD];
+  free(s.A);
+  free(s.u);
+}
+
+void orc_solve_width_batch(const double* t, int nt, const double* cx0, const double* cy0, int k,
+                           double length, int N, const double* widths, int B,
+                           const int* i_start, int max_iter,
+                           double* out_ctrl, double* out_xy, int* n_success, int nthreads) {
+  int n = nt - k - 1;
+  /* shared initial line: p0_i, yaw0_i */
+  double* base = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
+  double* u = (double*)malloc((size_t)N * sizeof(double));
+  for (int i = 0; i < N; ++i) u[i] = grid_u(i, N);
+  orc_trajectory_init(base, N);
+  sample_geometry(t, nt, cx0, cy0, k, u, N, base);
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    double* cx = (double*)malloc((size_t)n * 2 * sizeof(double));
+    double* cy = cx + n;
+    memcpy(cx, cx0, (size_t)n * sizeof(double));
+    memcpy(cy, cy0, (size_t)n * sizeof(double));
+    double* ring = (double*)malloc((size_t)N * 4 * sizeof(double));
+    double *ringL = ring, *ringR = ring + (size_t)2 * N;
+    for (int i = 0; i < N; ++i) {
+      const double* p = base + (size_t)i * ORC_NCOL;
+      double wl = widths[((size_t)b * N + i) * 2], wr = widths[((size_t)b * N + i) * 2 + 1];
+      ringL[2 * i] = p[ORC_X] + wl * cos(p[ORC_YAW] + M_PI / 2.0);
+      ringL[2 * i + 1] = p[ORC_Y] + wl * sin(p[ORC_YAW] + M_PI / 2.0);
+      ringR[2 * i] = p[ORC_X] + wr * cos(p[ORC_YAW] + (-M_PI / 2.0));
+      ringR[2 * i + 1] = p[ORC_Y] + wr * sin(p[ORC_YAW] + (-M_PI / 2.0));
+    }
+    double* pts = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
+    orc_trajectory_init(pts, N);
+    orc_run_min_curvature_qp(t, nt, cx, cy, k, length, pts, N, ringL, N, ringR, N, i_start,
+                             max_iter, n_success + (size_t)b * 2 * max_iter);
+    for (int j = 0; j < n; ++j) {
+      out_ctrl[((size_t)b * n + j) * 2] = cx[j];
+      out_ctrl[((size_t)b * n + j) * 2 + 1] = cy[j];
+    }
+    for (int i = 0; i < N; ++i) {
+      out_xy[((size_t)b * N + i) * 2] = pts[(size_t)i * ORC_NCOL + ORC_X];
+      out_xy[((size_t)b * N + i) * 2 + 1] = pts[(size_t)i * ORC_NCOL + ORC_Y];
+    }
+    free(pts);
+    free(ring);
+    free(cx);
+  }
+  free(u);
+  free(base);
+}

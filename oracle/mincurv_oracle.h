@@ -1,0 +1,108 @@
+/*
+ * oracle/mincurv_oracle.h -- CPU restatement of the reference's min-curvature hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under spline_trajectory_optimization_amd/ (the product)
+ * may include, link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * Every function cites the reference file:line (relative to the reference repo root,
+ * HaoruXue/spline-trajectory-optimization @ v1) whose arithmetic it restates.
+ *
+ * Pinning status (see DESIGN.md section "Oracle"):
+ *   - spline evaluation, sample_along, min_curvature_cost, track_constraint and the whole
+ *     run_min_curvature_qp driver are pinned against fixtures produced by importing the
+ *     reference's own Python functions (tests/golden/make_golden.py, fixtures G1..G7).
+ *   - the QP solve (casadi.conic -> qpOASES 3.2, a third-party dependency that is absent from
+ *     the reference tree and from this image) is restated as the exact closed-form solution of
+ *     the strictly convex separable QP the reference assembles: PARITY UNPINNED against
+ *     qpOASES itself; pinned through KKT residual tests instead.
+ *   - fill_bounds (shapely/GEOS LineString.intersection(LinearRing), absent as well) is
+ *     restated geometrically: PARITY UNPINNED against GEOS.
+ */
+#ifndef MINCURV_ORACLE_H
+#define MINCURV_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Trajectory column indices -- models/trajectory.py:26-44 */
+enum {
+  ORC_X = 0, ORC_Y = 1, ORC_Z = 2, ORC_YAW = 3, ORC_SPEED = 4, ORC_CURVATURE = 5,
+  ORC_DIST_BWD = 6, ORC_DIST_FWD = 7, ORC_REGION = 8, ORC_LBX = 9, ORC_LBY = 10,
+  ORC_RBX = 11, ORC_RBY = 12, ORC_BANK = 13, ORC_LON_ACC = 14, ORC_LAT_ACC = 15,
+  ORC_TIME = 16, ORC_IDX = 17, ORC_ITER_FLAG = 18, ORC_NCOL = 19
+};
+
+/* scipy.interpolate.BSpline.__call__(x, nu=der, extrapolate=True) for one coordinate.
+ * (models/trajectory.py:247-259 call sites: interpolate.splev(t, BSpline, der)) */
+void orc_bspline_eval(const double* t, int nt, const double* c, int k,
+                      const double* x, int nx, int der, double* out);
+
+/* BSpline.derivative(nu) -- scipy splder recurrence; t_out has nt-2*nu knots,
+ * c_out has (nt - 2*nu) entries (padded with zeros like scipy). Returns new degree. */
+int orc_bspline_derivative(const double* t, int nt, const double* c, int nc, int k, int nu,
+                           double* t_out, double* c_out);
+
+/* BSpline.basis_element(tk[0..k+1])(x, nu=der)  -- optimizer.py:64, 231-233 */
+void orc_basis_element(const double* tk, int k, const double* x, int nx, int der, double* out);
+
+/* one 21-point Gauss-Kronrod panel of |r'(u)| on [a,b] -- what scipy.integrate.quad
+ * (QUADPACK qagse -> qk21) returns for models/trajectory.py:228-230 on a short segment */
+double orc_arc_gk21(const double* t, int nt, const double* cx, const double* cy, int k,
+                    double a, double b);
+
+/* Trajectory.__init__ -- models/trajectory.py:46-51 */
+void orc_trajectory_init(double* points, int N);
+
+/* BSplineTrajectory.sample_along(ts=u) -- models/trajectory.py:268-291.
+ * `length` is BSplineTrajectory._length (host-side scipy quad at fit time, :223). */
+void orc_sample_along(const double* t, int nt, const double* cx, const double* cy, int k,
+                      double length, const double* u, int N, double* points);
+
+/* Trajectory.fill_bounds(left_ring, right_ring, max_dist) -- models/trajectory.py:83-141.
+ * Rings are closed polylines given as [n,2] vertices (closing edge implied). */
+void orc_fill_bounds(double* points, int N, const double* ringL, int nL,
+                     const double* ringR, int nR, double max_dist);
+
+/* TrajectoryOptimizer.min_curvature_cost -- optimizer.py:24-86.  Returns support size M. */
+int orc_min_curvature_cost(const double z[2], int idx, const double* t, int nt,
+                           const double* cx, const double* cy, int k, int N,
+                           double H[4], double g[2]);
+
+/* TrajectoryOptimizer.track_constraint -- optimizer.py:222-254.
+ * A is [2M,2] row-major, lba/uba are [2M]; returns M (caller sizes buffers for N). */
+int orc_track_constraint(int idx, const double* t, int nt, const double* cx, const double* cy,
+                         int k, const double* points, int N,
+                         double* A, double* lba, double* uba);
+
+/* Exact solution of the QP handed to casadi.conic('qpoases') at optimizer.py:268-277:
+ *   min 1/2 x'Hx + g'x  s.t. lba <= A x <= uba, H diagonal, every A row has one non-zero.
+ * returns 0 = solved, 2 = infeasible, 3 = not strictly convex / non-finite data. */
+int orc_qp_solve_separable(const double H[4], const double g[2], const double* A,
+                           const double* lba, const double* uba, int M, double x[2]);
+
+/* TrajectoryOptimizer.run_min_curvature_qp -- optimizer.py:256-341, with the sweep start
+ * indices (np.random.randint at :303) supplied by the caller, without the simulator /
+ * visualizer calls (:261, :331-340) which never feed back into the spline.
+ * cx, cy are updated in place; points (N x 19, bounds filled on entry is not required) is
+ * the working discrete trajectory and holds the final one on return.
+ * n_success[2*max_iter]: successes of the forward / backward pass of each iteration (:314,:325). */
+void orc_run_min_curvature_qp(const double* t, int nt, double* cx, double* cy, int k,
+                              double length, double* points, int N,
+                              const double* ringL, int nL, const double* ringR, int nR,
+                              const int* i_start, int max_iter, int* n_success);
+
+/* Batched driver used by bench.py's cpu_baseline: the same solve for `B` instances whose
+ * rings are the width-perturbed offsets of one shared centre line (SURVEY.md section 8(d),
+ * config 2): ring vertex i = p0_i +/- w[b,i] * n0_i.  widths is [B,N,2] (left,right).
+ * out_ctrl is [B,n,2], out_xy is [B,N,2]. nthreads > 1 uses OpenMP over instances. */
+void orc_solve_width_batch(const double* t, int nt, const double* cx0, const double* cy0, int k,
+                           double length, int N, const double* widths, int B,
+                           const int* i_start, int max_iter,
+                           double* out_ctrl, double* out_xy, int* n_success, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

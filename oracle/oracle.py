@@ -1,0 +1,159 @@
+"""ctypes binding of oracle/libmincurv_oracle.so  --  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, tests/golden/make_golden.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this module.  The product package must never do so.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmincurv_oracle.so")
+
+NCOL = 19
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "mincurv_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_arc_gk21.restype = ctypes.c_double
+        _lib.orc_arc_gk21.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int,
+                                      ctypes.c_double, ctypes.c_double]
+        _lib.orc_sample_along.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double,
+                                          _dp, ctypes.c_int, _dp]
+        _lib.orc_run_min_curvature_qp.argtypes = [
+            _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp, ctypes.c_int,
+            _dp, ctypes.c_int, _dp, ctypes.c_int, _ip, ctypes.c_int, _ip]
+        _lib.orc_solve_width_batch.argtypes = [
+            _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp,
+            ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _ip, ctypes.c_int]
+        _lib.orc_fill_bounds.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int,
+                                         ctypes.c_double]
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def bspline_eval(t, c, k, x, der=0):
+    t, tp = _d(t); c, cp = _d(c); x, xp = _d(np.atleast_1d(x))
+    out = np.empty_like(x)
+    lib().orc_bspline_eval(tp, len(t), cp, int(k), xp, len(x), int(der), out.ctypes.data_as(_dp))
+    return out
+
+
+def bspline_derivative(t, c, k, nu=1):
+    t, tp = _d(t); c, cp = _d(c)
+    to = np.empty(len(t) - 2 * nu); co = np.empty(len(t) - 2 * nu)
+    k2 = lib().orc_bspline_derivative(tp, len(t), cp, len(c), int(k), int(nu),
+                                      to.ctypes.data_as(_dp), co.ctypes.data_as(_dp))
+    return to, co, k2
+
+
+def basis_element(tk, x, der=0):
+    tk, tp = _d(tk); x, xp = _d(np.atleast_1d(x))
+    out = np.empty_like(x)
+    lib().orc_basis_element(tp, len(tk) - 2, xp, len(x), int(der), out.ctypes.data_as(_dp))
+    return out
+
+
+def arc_gk21(t, cx, cy, k, a, b):
+    t, tp = _d(t); cx, xp = _d(cx); cy, yp = _d(cy)
+    return lib().orc_arc_gk21(tp, len(t), xp, yp, int(k), float(a), float(b))
+
+
+def sample_along(t, cx, cy, k, length, u):
+    t, tp = _d(t); cx, xp = _d(cx); cy, yp = _d(cy); u, up = _d(u)
+    pts = np.empty((len(u), NCOL))
+    lib().orc_sample_along(tp, len(t), xp, yp, int(k), float(length), up, len(u),
+                           pts.ctypes.data_as(_dp))
+    return pts
+
+
+def fill_bounds(points, ringL, ringR, max_dist=100.0):
+    """In place on a C-contiguous float64 [N,19] array."""
+    assert points.dtype == np.float64 and points.flags.c_contiguous and points.shape[1] == NCOL
+    ringL, lp = _d(ringL); ringR, rp = _d(ringR)
+    lib().orc_fill_bounds(points.ctypes.data_as(_dp), len(points), lp, len(ringL), rp, len(ringR),
+                          float(max_dist))
+    return points
+
+
+def min_curvature_cost(z, idx, t, cx, cy, k, N):
+    t, tp = _d(t); cx, xp = _d(cx); cy, yp = _d(cy); z, zp = _d(z)
+    H = np.zeros(4); g = np.zeros(2)
+    M = lib().orc_min_curvature_cost(zp, int(idx), tp, len(t), xp, yp, int(k), int(N),
+                                     H.ctypes.data_as(_dp), g.ctypes.data_as(_dp))
+    return H.reshape(2, 2), g, M
+
+
+def track_constraint(idx, t, cx, cy, k, points):
+    t, tp = _d(t); cx, xp = _d(cx); cy, yp = _d(cy); points, pp = _d(points)
+    N = len(points)
+    A = np.zeros((2 * N, 2)); lba = np.zeros(2 * N); uba = np.zeros(2 * N)
+    M = lib().orc_track_constraint(int(idx), tp, len(t), xp, yp, int(k), pp, N,
+                                   A.ctypes.data_as(_dp), lba.ctypes.data_as(_dp),
+                                   uba.ctypes.data_as(_dp))
+    return A[:2 * M].copy(), lba[:2 * M].copy(), uba[:2 * M].copy()
+
+
+def qp_solve_separable(H, g, A, lba, uba):
+    H, hp = _d(np.asarray(H).reshape(4)); g, gp = _d(g); A, ap = _d(A)
+    lba, lp = _d(lba); uba, up = _d(uba)
+    x = np.zeros(2)
+    st = lib().orc_qp_solve_separable(hp, gp, ap, lp, up, len(lba) // 2, x.ctypes.data_as(_dp))
+    return st, x
+
+
+def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None):
+    """Returns (cx, cy, points[N,19], n_success[max_iter,2])."""
+    t, tp = _d(t)
+    cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
+    ringL, lp = _d(ringL); ringR, rp = _d(ringR)
+    i_start, ip = _i(i_start)
+    max_iter = len(i_start) if max_iter is None else max_iter
+    pts = np.zeros((N, NCOL))
+    lib().orc_trajectory_init(pts.ctypes.data_as(_dp), N)
+    ns = np.zeros(2 * max_iter, dtype=np.int32)
+    lib().orc_run_min_curvature_qp(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k),
+                                   float(length), pts.ctypes.data_as(_dp), int(N), lp, len(ringL),
+                                   rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
+    return cx, cy, pts, ns.reshape(max_iter, 2)
+
+
+def solve_width_batch(t, cx0, cy0, k, length, N, widths, i_start, max_iter=None, nthreads=1):
+    """widths [B,N,2] -> (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2])."""
+    t, tp = _d(t); cx0, xp = _d(cx0); cy0, yp = _d(cy0); widths, wp = _d(widths)
+    i_start, ip = _i(i_start)
+    max_iter = len(i_start) if max_iter is None else max_iter
+    B = widths.shape[0]
+    n = len(t) - k - 1
+    ctrl = np.zeros((B, n, 2)); xy = np.zeros((B, N, 2))
+    ns = np.zeros((B, max_iter, 2), dtype=np.int32)
+    lib().orc_solve_width_batch(tp, len(t), xp, yp, int(k), float(length), int(N), wp, B, ip,
+                                int(max_iter), ctrl.ctypes.data_as(_dp), xy.ctypes.data_as(_dp),
+                                ns.ctypes.data_as(_ip), int(nthreads))
+    return ctrl, xy, ns
