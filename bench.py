@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- min-curvature QP solves/sec at N=2000 waypoints on 1/2/4/8 MI355X.
+
+Workload (BASELINE.json configs[1]): Monza centre line
+(BSplineTrajectory s=100, k=5 -> 66 control points), N=2000 samples, B=1024 track instances PER GPU
+whose half-widths are the Monza half-widths scaled per instance by 1+e, e~U(-0.15,0.15)
+(numpy default_rng(1234 + rank)), floor 1.5 m.
+
+One "solve" = the reference's complete TrajectoryOptimizer.run_min_curvature_qp for one instance
+(optimizer.py:256-341, max_iter=5 -> 5 x (forward + backward) sweeps over the 61 free control
+points = 610 control-point QPs, each followed by re-sampling and boundary re-intersection), sweep
+order pinned.  One "step" = one launch of the sweep kernel over the rank's whole batch, inputs
+already resident in HBM; for N>1 ranks the step ends with the single gather of the results to rank 0.
+
+Prints ONE JSON line (rank 0).  See the repo instructions for the field contract.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_WAYPOINTS = 2000
+BATCH_PER_GPU = 1024
+MAX_ITER = 5            # run_min_curvature_qp default (optimizer.py:256)
+SPLINE_S, SPLINE_K = 100.0, 5
+BYTES_PER_SOLVE = 8 * N_WAYPOINTS * (2 + 2)  # widths in (2 cols) + x,y out (2 cols)
+
+
+def cpu_baseline(t, cx, cy, k, length, widths, i_start, budget_instances):
+    """The oracle (a port of the reference's arithmetic, oracle/mincurv_oracle.c) timed on a bounded
+    sample of the same workload: `budget_instances` instances, one per host thread."""
+    from oracle import oracle as orc
+    cores = max(1, min(os.cpu_count() or 1, budget_instances))
+    sample = np.ascontiguousarray(widths[:budget_instances])
+    t0 = time.perf_counter()
+    ctrl, xy, ns = orc.solve_width_batch(t, cx, cy, k, length, N_WAYPOINTS, sample, i_start, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": budget_instances / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"{budget_instances} of the {BATCH_PER_GPU} instances (Monza N={N_WAYPOINTS}, "
+                      f"max_iter={MAX_ITER}), one per thread, {dt:.1f} s wall"}, xy
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
+    ap.add_argument("--search", choices=["culled", "brute"], default="culled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-instances", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    ge.build_hip()
+    from spline_trajectory_optimization_amd import _lib, batch, ops
+    from spline_trajectory_optimization_amd.models.race_track import RaceTrack
+
+    # ---- set-up (untimed): Monza track, base half-widths, per-instance widths resident in HBM
+    _lib.set_default_device(local_rank)  # one process per GPU
+    ctx = _lib.Context.get()
+    centre, left, right = batch.load_monza()
+    line = batch.monza_centerline(SPLINE_S, SPLINE_K)
+    t, cx, cy, k = line._tck()
+    n = len(cx)
+    track_geo = RaceTrack("Monza", left, right, centre)
+    traj = line.sample_along(ts=np.linspace(0.0, 1.0, N_WAYPOINTS, endpoint=False))
+    track_geo.fill_trajectory_boundaries(traj)
+    wl, wr = batch.half_widths_from_bounds(traj.points)
+    B = args.batch
+    widths = batch.width_batch(wl, wr, B, seed=1234 + rank)
+    i_start = batch.default_i_start(n, k, MAX_ITER, seed=0)
+    trk = _lib.Track(ctx, t, cx, cy, k, N_WAYPOINTS)
+    d_widths = torch.from_numpy(widths).to(dev)
+    search = _lib.SEARCH_CULLED if args.search == "culled" else _lib.SEARCH_BRUTE
+    out = ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search)
+    torch.cuda.synchronize()
+    stats = out["stats"]
+
+    def step():
+        ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search, out=out)
+        if world > 1:
+            batch.gather_to_root(out["xy"], rank, world, dist)
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: barrier + sync on both sides, exactly K steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search, out=out)
+        ev[s][1].record()  # kernel-only span on the launch stream (torch's current stream)
+        if world > 1:
+            batch.gather_to_root(out["xy"], rank, world, dist)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity outside the timed region: results are finite and the bookkeeping is consistent
+    status = out["status"].cpu().numpy()
+    ns = out["n_success"].cpu().numpy()
+    xy = out["xy"].cpu().numpy()
+    assert np.isfinite(xy).all()
+    assert np.array_equal(status, 2 * MAX_ITER * (n - 5) - ns.reshape(B, -1).sum(axis=1))
+
+    if rank == 0:
+        total_solves = world * B * args.steps
+        value = total_solves / elapsed
+        qp_per_solve = 2 * MAX_ITER * (n - 5)
+        achieved = (BYTES_PER_SOLVE * B) / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "min-curvature QP solves/sec (N=2000 waypoints)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Monza N={N_WAYPOINTS}, batch={B} width-perturbed instances per GPU "
+                            f"(BASELINE configs[1]); one solve = full run_min_curvature_qp, "
+                            f"max_iter={MAX_ITER}, {qp_per_solve} control-point QPs, sweep order pinned",
+                "spline": f"s={SPLINE_S:g} k={SPLINE_K} n={n}", "batch_per_gpu": B,
+                "control_point_qps_per_s": value * qp_per_solve, "search": args.search,
+                "parallelism": f"{world} rank(s) x independent instances"
+                               + (", 1 RCCL gather to rank 0 per step" if world > 1 else ""),
+                "lds_bytes_per_workgroup": int(stats.lds_bytes), "block_threads": int(stats.block_threads),
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_sweep", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ninst = min(args.cpu_instances, B)
+            cb, oxy = cpu_baseline(t, cx, cy, k, line.get_length(), widths, i_start, ninst)
+            dev_m = float(np.abs(oxy - xy[:ninst]).max())
+            cb["max_abs_dev_vs_gpu_m"] = dev_m
+            assert dev_m < 1e-4, f"GPU result deviates from the oracle by {dev_m} m"
+            res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * include/rl_mincurv.h -- C ABI of librl_mincurv.so, the MI355X (gfx950) implementation of the
+ * reference's min-curvature racing-line hot path.
+ *
+ * The reference (HaoruXue/spline-trajectory-optimization @ v1) is pure Python and has no FFI layer;
+ * the drop-in boundary is its Python class API.  Each entry point below names the reference
+ * function (file:line, relative to the reference root) whose work it replaces; the Python mirror
+ * in spline_trajectory_optimization_amd/ binds them with ctypes (INTEGRATION.md shows the stub a
+ * reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types, no exceptions across the boundary;
+ *   - every array is C-contiguous float64 (indices / counters int32);
+ *   - return 0 = OK, <0 = call-level error (text via rl_last_error(), thread-local);
+ *   - the caller owns every buffer; nothing is retained past the call except inside rl_track;
+ *   - a spline is (t[nt], cx[n], cy[n], k) with n = nt-k-1, exactly scipy's BSpline.t/.c/.k;
+ *   - "host" entry points take host pointers and synchronise; the *_dev entry points take DEVICE
+ *     pointers, enqueue on the context's stream (rl_ctx_set_stream) and do not synchronise;
+ *   - there is NO CPU fallback: without a usable HIP device rl_ctx_create fails.
+ */
+#ifndef RL_MINCURV_H
+#define RL_MINCURV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL_VERSION 100          /* 0.1.0 */
+#define RL_NCOL 19              /* Trajectory columns, models/trajectory.py:26-44 */
+#define RL_MAX_ITER 32          /* max outer iterations per sweep call */
+#define RL_MAX_DEGREE 5
+
+typedef struct rl_ctx rl_ctx;       /* one per GPU / stream */
+typedef struct rl_track rl_track;   /* device-resident tables of one (spline knots, sample grid) pair */
+
+/* per-instance QP/sweep outcome, mirrors "raise -> skip" at optimizer.py:291-293 */
+enum { RL_OK = 0, RL_ERR_ARG = -1, RL_ERR_HIP = -2, RL_ERR_NOMEM = -3, RL_ERR_UNSUPPORTED = -4 };
+
+/* how the per-instance track boundaries are given to rl_mincurv_solve_batch_dev */
+enum {
+  RL_BOUNDS_SHARED_RINGS = 0, /* every instance uses the rings attached with rl_track_set_rings      */
+  RL_BOUNDS_WIDTHS = 1,       /* in[B,N,2] = (w_left, w_right): ring vertex i = p0_i +/- w * n0_i     */
+  RL_BOUNDS_POINTS = 2        /* in[B,N,4] = (LBX,LBY,RBX,RBY): ring vertices given directly           */
+};
+
+enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1 };
+
+typedef struct rl_stats {
+  float kernel_ms;       /* duration of the sweep kernel of the last *_host call (hipEvent)  */
+  int lds_bytes;         /* dynamic LDS per workgroup                                          */
+  int block_threads;     /* workgroup size                                                     */
+  int rings_in_lds;      /* 1 = ring vertices LDS-resident, 0 = global scratch                 */
+  int reserved[4];
+} rl_stats;
+
+int rl_version(void);
+const char* rl_last_error(void);
+
+int rl_ctx_create(int device_id, rl_ctx** out);
+void rl_ctx_destroy(rl_ctx* ctx);
+/* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
+int rl_ctx_set_stream(rl_ctx* ctx, void* hip_stream);
+int rl_ctx_synchronize(rl_ctx* ctx);
+
+/* ---- a3: BSplineTrajectory.eval / interpolate.splev  (models/trajectory.py:247-251)
+ * out is [(der_max+1)*2, N]: x, y, x', y', x'', y'' rows. */
+int rl_spline_eval(rl_ctx* ctx, const double* t, int nt, const double* cx, const double* cy, int k,
+                   const double* u, int N, int der_max, double* out);
+
+/* ---- a3: BSplineTrajectory.sample_along(ts=u)  (models/trajectory.py:268-291)
+ * points is [N,19]; fills X,Y,YAW,CURVATURE(turn radius),DIST_BWD,DIST_FWD, IDX, ITER_FLAG=-1,
+ * everything else 0, as a fresh Trajectory (models/trajectory.py:46-51).
+ * `length` = BSplineTrajectory._length (models/trajectory.py:223). */
+int rl_sample_along(rl_ctx* ctx, const double* t, int nt, const double* cx, const double* cy, int k,
+                    double length, const double* u, int N, double* points);
+
+/* ---- a5: Trajectory.fill_bounds  (models/trajectory.py:83-141, via race_track.py:98-104)
+ * rings are closed polylines [n,2] (closing edge implied); updates LBX,LBY,RBX,RBY in place. */
+int rl_fill_bounds(rl_ctx* ctx, double* points, int N, const double* ringL, int nL,
+                   const double* ringR, int nR, double max_dist);
+
+/* ---- track tables: knots + uniform sample grid u_i = i/N (Trajectory.ts, trajectory.py:199-200)
+ * cx0/cy0 are the initial control points shared by every instance of a batch. */
+int rl_track_create(rl_ctx* ctx, const double* t, int nt, const double* cx0, const double* cy0,
+                    int k, int N, rl_track** out);
+void rl_track_destroy(rl_track* trk);
+/* RaceTrack.left_r / right_r (race_track.py:31-32) for RL_BOUNDS_SHARED_RINGS */
+int rl_track_set_rings(rl_track* trk, const double* ringL, int nL, const double* ringR, int nR);
+/* replace the shared initial control points (BSplineTrajectory.set_control_point, trajectory.py:296) */
+int rl_track_set_control_points(rl_track* trk, const double* cx0, const double* cy0);
+
+/* ---- a7: TrajectoryOptimizer.min_curvature_cost  (optimization/optimizer.py:24-86)
+ * for n_idx control points at once; z is [n_idx,2] (NULL = the current control points);
+ * H is [n_idx,4] (row-major 2x2), g is [n_idx,2], M (optional) the support sizes. */
+int rl_mincurv_cost(rl_ctx* ctx, const rl_track* trk, const int* idx, int n_idx, const double* z,
+                    double* H, double* g, int* M);
+
+/* ---- a8: TrajectoryOptimizer.track_constraint  (optimization/optimizer.py:222-254)
+ * points [N,19] supplies X,Y and the four bound columns.  Outputs for ONE control point:
+ * b[M] (the non-zero of A rows 2i and 2i+1: A[2i,0] = A[2i+1,1] = b_i), lba[2M], uba[2M]. */
+int rl_track_constraint(rl_ctx* ctx, const rl_track* trk, const double* points, int idx,
+                        double* b, double* lba, double* uba, int* M);
+
+/* ---- a7+a8+a11+a4+a3+a5+a12: TrajectoryOptimizer.run_min_curvature_qp
+ * (optimization/optimizer.py:256-341) for ONE instance bounded by the shared rings of `trk`.
+ * i_start[max_iter] pins np.random.randint of optimizer.py:303.  cx, cy [n] in/out;
+ * points [N,19] out (final sample_along table with bounds; may be NULL);
+ * n_success[2*max_iter] out (forward/backward successes per iteration, optimizer.py:314,325). */
+int rl_mincurv_sweep(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter,
+                     double* cx, double* cy, double* points, int* n_success, rl_stats* stats);
+
+/* ---- batched solve: B independent instances of the same sweep, one workgroup each.
+ * DEVICE pointers; enqueued on the ctx stream; no synchronisation.
+ *   in         bounds per `bounds_form` (NULL for RL_BOUNDS_SHARED_RINGS)
+ *   out_ctrl   [B,n,2] optimised control points           out_xy   [B,N,2] optimised line samples
+ *   n_success  [B,2*max_iter] (may be NULL)               status   [B]: number of skipped QPs    */
+int rl_mincurv_solve_batch_dev(rl_ctx* ctx, const rl_track* trk, int bounds_form, const double* in,
+                               int B, const int* i_start, int max_iter, int search,
+                               double* out_ctrl, double* out_xy, int* n_success, int* status,
+                               rl_stats* stats);
+
+/* same with HOST pointers (copies in/out, synchronises, fills stats->kernel_ms) */
+int rl_mincurv_solve_batch_host(rl_ctx* ctx, const rl_track* trk, int bounds_form, const double* in,
+                                int B, const int* i_start, int max_iter, int search,
+                                double* out_ctrl, double* out_xy, int* n_success, int* status,
+                                rl_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

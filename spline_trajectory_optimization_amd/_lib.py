@@ -1,0 +1,179 @@
+"""ctypes binding of librl_mincurv.so (include/rl_mincurv.h).
+
+The HIP library is the product; there is no CPU fallback anywhere in this package.  If the shared
+object is missing, or no MI355X/HIP device is usable, every compute entry point raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librl_mincurv.so")
+
+NCOL = 19
+MAX_ITER = 32
+BOUNDS_SHARED_RINGS, BOUNDS_WIDTHS, BOUNDS_POINTS = 0, 1, 2
+SEARCH_BRUTE, SEARCH_CULLED = 0, 1
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("kernel_ms", ctypes.c_float), ("lds_bytes", ctypes.c_int),
+                ("block_threads", ctypes.c_int), ("rings_in_lds", ctypes.c_int),
+                ("reserved", ctypes.c_int * 4)]
+
+
+class RlError(RuntimeError):
+    pass
+
+
+# every symbol include/rl_mincurv.h declares: (restype, argtypes)
+_SIGNATURES = {
+    "rl_version": (ctypes.c_int, []),
+    "rl_last_error": (ctypes.c_char_p, []),
+    "rl_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "rl_ctx_destroy": (None, [_vp]),
+    "rl_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "rl_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "rl_spline_eval": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp,
+                                      ctypes.c_int, ctypes.c_int, _dp]),
+    "rl_sample_along": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int,
+                                       ctypes.c_double, _dp, ctypes.c_int, _dp]),
+    "rl_fill_bounds": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int,
+                                      ctypes.c_double]),
+    "rl_track_create": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(_vp)]),
+    "rl_track_destroy": (None, [_vp]),
+    "rl_track_set_rings": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, ctypes.c_int]),
+    "rl_track_set_control_points": (ctypes.c_int, [_vp, _dp, _dp]),
+    "rl_mincurv_cost": (ctypes.c_int, [_vp, _vp, _ip, ctypes.c_int, _dp, _dp, _dp, _ip]),
+    "rl_track_constraint": (ctypes.c_int, [_vp, _vp, _dp, ctypes.c_int, _dp, _dp, _dp, _ip]),
+    "rl_mincurv_sweep": (ctypes.c_int, [_vp, _vp, _ip, ctypes.c_int, _dp, _dp, _dp, _ip,
+                                        ctypes.POINTER(Stats)]),
+    "rl_mincurv_solve_batch_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _ip,
+                                                  ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp,
+                                                  ctypes.POINTER(Stats)]),
+    "rl_mincurv_solve_batch_host": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _dp, ctypes.c_int, _ip,
+                                                   ctypes.c_int, ctypes.c_int, _dp, _dp, _ip, _ip,
+                                                   ctypes.POINTER(Stats)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load librl_mincurv.so (no GPU needed just to load and resolve symbols)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RlError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        if os.environ.get("RL_NO_TORCH", "0") != "1":
+            try:  # share ONE HIP runtime with torch when both live in the process
+                import torch  # noqa: F401
+            except Exception:
+                pass
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RlError(f"librl_mincurv error {rc}: {load().rl_last_error().decode()}")
+
+
+def as_d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def as_i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+_default_device = 0
+
+
+def set_default_device(device):
+    """Device used by the mirror classes / ops when none is given (one process per GPU: LOCAL_RANK)."""
+    global _default_device
+    _default_device = int(device)
+
+
+class Context:
+    """rl_ctx wrapper: one per (process, device).  Raises if no HIP device is usable."""
+
+    _cache = {}
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        check(self.lib.rl_ctx_create(int(device), ctypes.byref(h)))
+        self.h = h
+        self.device = device
+
+    @classmethod
+    def get(cls, device=None):
+        if device is None:
+            device = _default_device
+        ctx = cls._cache.get(device)
+        if ctx is None:
+            ctx = cls(device)
+            cls._cache[device] = ctx
+        return ctx
+
+    def set_stream(self, stream_handle):
+        check(self.lib.rl_ctx_set_stream(self.h, _vp(stream_handle or 0)))
+
+    def synchronize(self):
+        check(self.lib.rl_ctx_synchronize(self.h))
+
+
+class Track:
+    """rl_track wrapper: device tables for one (knots, degree, sample count, control points)."""
+
+    def __init__(self, ctx, t, cx, cy, k, N):
+        self.ctx = ctx
+        self.t, tp = as_d(t)
+        cx, xp = as_d(cx)
+        cy, yp = as_d(cy)
+        self.k, self.N = int(k), int(N)
+        self.n = len(self.t) - self.k - 1
+        assert len(cx) == self.n and len(cy) == self.n
+        h = _vp()
+        check(ctx.lib.rl_track_create(ctx.h, tp, len(self.t), xp, yp, self.k, self.N, ctypes.byref(h)))
+        self.h = h
+
+    def set_rings(self, ringL, ringR):
+        ringL, lp = as_d(ringL)
+        ringR, rp = as_d(ringR)
+        check(self.ctx.lib.rl_track_set_rings(self.h, lp, len(ringL), rp, len(ringR)))
+
+    def set_control_points(self, cx, cy):
+        cx, xp = as_d(cx)
+        cy, yp = as_d(cy)
+        check(self.ctx.lib.rl_track_set_control_points(self.h, xp, yp))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.rl_track_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

@@ -1,0 +1,92 @@
+"""Batched min-curvature solves: workload generators for the BASELINE.json configs and the
+rank-sharding helpers (one process per GPU, independent track instances, one gather).
+
+No arithmetic of the hot path lives here: instances are solved by rl_mincurv_solve_batch_* (HIP).
+"""
+import os
+
+import numpy as np
+
+from . import _lib, ops
+from .models.trajectory import BSplineTrajectory
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+MONZA_DIR = os.path.join(_PKG, "examples", "race_track", "monza")
+
+
+def load_track_csv(path):
+    """x,y columns of a track CSV (tests/test_trajectory.py:9-15 reads usecols=(0,1))."""
+    return np.loadtxt(path, dtype=np.float64, delimiter=",", skiprows=1, usecols=(0, 1))
+
+
+def load_monza():
+    return (load_track_csv(os.path.join(MONZA_DIR, "MONZA_UNOPTIMIZED_LINE_enu.csv")),
+            load_track_csv(os.path.join(MONZA_DIR, "MONZA_LEFT_BOUNDARY_enu.csv")),
+            load_track_csv(os.path.join(MONZA_DIR, "MONZA_RIGHT_BOUNDARY_enu.csv")))
+
+
+def monza_centerline(s=100.0, k=5):
+    """The centre-line spline of tests/test_optimizer.py:16-17 (host FITPACK fit)."""
+    centre, _, _ = load_monza()
+    return BSplineTrajectory(centre, s, k)
+
+
+def half_widths_from_bounds(points):
+    """|p - L|, |p - R| per sample from a bounds-filled [N,19] table."""
+    wl = np.hypot(points[:, 9] - points[:, 0], points[:, 10] - points[:, 1])
+    wr = np.hypot(points[:, 11] - points[:, 0], points[:, 12] - points[:, 1])
+    return wl, wr
+
+
+def width_batch(w_left, w_right, B, seed=1234, eps=0.15, floor=1.5):
+    """per-instance widths w[b,i] = w[i] * (1 + e[b]), e ~ U(-eps, eps)
+    from numpy.random.default_rng(seed), floored at `floor` metres.  Returns float64 [B,N,2]."""
+    rng = np.random.default_rng(seed)
+    e = rng.uniform(-eps, eps, size=(B, 2))
+    w = np.empty((B, len(w_left), 2))
+    w[:, :, 0] = np.maximum(w_left[None, :] * (1.0 + e[:, 0:1]), floor)
+    w[:, :, 1] = np.maximum(w_right[None, :] * (1.0 + e[:, 1:2]), floor)
+    return w
+
+
+def default_i_start(n, k, max_iter, seed=0):
+    """A pinned stand-in for the unseeded np.random.randint of optimizer.py:303."""
+    rng = np.random.RandomState(seed)
+    return np.array([rng.randint(k // 2, n - (k - k // 2)) for _ in range(max_iter)], dtype=np.int32)
+
+
+def make_track(spline: BSplineTrajectory, N: int, device=None):
+    t, cx, cy, k = spline._tck()
+    return _lib.Track(_lib.Context.get(device), t, cx, cy, k, N)
+
+
+# ---------------------------------------------------------------- rank sharding
+def shard_range(B, rank, world):
+    """Contiguous block partition: rank r takes instances [lo, hi)."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_to_root(tensor, rank, world, dist, total=None):
+    """The single collective of the path: every rank's result shard to rank 0 (RCCL `gather` over
+    xGMI; gloo in the CPU tests).  `total` = global instance count when the shards come from
+    shard_range(total, r, world) (they may then differ by one instance and are padded to the
+    largest); None = every rank holds the same number of instances (weak scaling)."""
+    import torch
+    if world == 1:
+        return tensor
+    if total is None:
+        counts = [tensor.shape[0]] * world
+    else:
+        counts = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    mx = max(counts)
+    pad = tensor
+    if tensor.shape[0] < mx:
+        pad = torch.cat([tensor, tensor.new_zeros((mx - tensor.shape[0],) + tuple(tensor.shape[1:]))])
+    pad = pad.contiguous()
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)])

@@ -1,0 +1,562 @@
+// rl_kernels.hpp -- HIP kernels of the min-curvature hot path (gfx950).
+//
+//   k_build_tables     per-track basis tables (de Boor values / derivatives on the sample grid)
+//   k_spline_eval      a3  BSplineTrajectory.eval
+//   k_sample_geometry  a3  sample_along: X,Y,YAW,radius + per-segment GK21 arc length
+//   k_sample_cumsum    a3  sequential DIST_BWD / DIST_FWD accumulation (trajectory.py:283-289)
+//   k_fill_bounds      a5  Trajectory.fill_bounds
+//   k_cost             a7  min_curvature_cost, one workgroup per control point
+//   k_constraint       a8  track_constraint
+//   k_sweep            a12 run_min_curvature_qp: one workgroup per track instance, the whole
+//                          Gauss-Seidel sweep (a7+a8+a11+a4+local a3+a5) resident in LDS
+#pragma once
+#include "rl_device.hpp"
+
+namespace rl {
+
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void k_build_tables(const double* __restrict__ t, int nt, const double* __restrict__ c0,
+                               int N, int* __restrict__ ell, double* __restrict__ D,
+                               double* __restrict__ base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int n = nt - K - 1;
+  const double u = (double)i * (1.0 / (double)N);  // np.linspace(0,1,N,endpoint=False)
+  const int l = find_interval(t, K, n, u);
+  ell[i] = l;
+  double h[K + 1];
+  double x = 0, y = 0, dx = 0, dy = 0;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    deboor<K>(t, u, l, m, h);
+#pragma unroll
+    for (int a = 0; a <= K; ++a) {
+      D[((size_t)m * (K + 1) + a) * N + i] = h[a];
+      if (m == 0) { x += c0[l - K + a] * h[a]; y += c0[n + l - K + a] * h[a]; }
+      if (m == 1) { dx += c0[l - K + a] * h[a]; dy += c0[n + l - K + a] * h[a]; }
+    }
+  }
+  const double inv = 1.0 / sqrt(dx * dx + dy * dy);
+  base[i] = x;
+  base[(size_t)N + i] = y;
+  base[(size_t)2 * N + i] = -dy * inv;  // unit left normal = (cos, sin)(yaw + pi/2)
+  base[(size_t)3 * N + i] = dx * inv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3: out[(2*m + c) * N + i] = m-th derivative of coordinate c at u_i  (arbitrary u, no tables)
+template <int K>
+__global__ void k_spline_eval(const double* __restrict__ t, int nt, const double* __restrict__ cx,
+                              const double* __restrict__ cy, const double* __restrict__ u, int N,
+                              int der_max, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int n = nt - K - 1;
+  const double x = u[i];
+  const int l = find_interval(t, K, n, x);
+  double h[K + 1];
+  for (int m = 0; m <= der_max; ++m) {
+    double sx = 0, sy = 0;
+    if (m <= K) {
+      deboor<K>(t, x, l, m, h);
+#pragma unroll
+      for (int a = 0; a <= K; ++a) { sx += cx[l - K + a] * h[a]; sy += cy[l - K + a] * h[a]; }
+    }
+    out[(size_t)(2 * m) * N + i] = sx;
+    out[(size_t)(2 * m + 1) * N + i] = sy;
+  }
+}
+
+// speed |r'(u)| for the arc-length quadrature (trajectory.py:225-226)
+template <int K>
+__device__ __forceinline__ double speed_at(const double* __restrict__ t, int n,
+                                           const double* __restrict__ cx,
+                                           const double* __restrict__ cy, double u) {
+  const int l = find_interval(t, K, n, u);
+  double h[K + 1];
+  deboor<K>(t, u, l, 1, h);
+  double dx = 0, dy = 0;
+#pragma unroll
+  for (int a = 0; a <= K; ++a) { dx += cx[l - K + a] * h[a]; dy += cy[l - K + a] * h[a]; }
+  return sqrt(dx * dx + dy * dy);
+}
+
+__constant__ double c_xgk[11] = {
+    0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+    0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+    0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+    0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+    0.294392862701460198131126603103866, 0.148874338981631210884826001129720,
+    0.000000000000000000000000000000000};
+__constant__ double c_wgk[11] = {
+    0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+    0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
+    0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+    0.123491976262065851077958109585166, 0.134709217311473325928054001771707,
+    0.142775938577060080797094273138717, 0.147739104901338491374841515972068,
+    0.149445554002916905664936468389821};
+
+// a3: one thread per sample: geometry columns + the GK21 length of segment [u_{i-1}, u_i]
+// (what scipy.integrate.quad returns for these short smooth segments: one qk21 panel).
+template <int K>
+__global__ void k_sample_geometry(const double* __restrict__ t, int nt,
+                                  const double* __restrict__ cx, const double* __restrict__ cy,
+                                  const double* __restrict__ u, int N, double* __restrict__ points,
+                                  double* __restrict__ seg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int n = nt - K - 1;
+  const double x = u[i];
+  const int l = find_interval(t, K, n, x);
+  double h[K + 1];
+  double v[6];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    deboor<K>(t, x, l, m, h);
+    double sx = 0, sy = 0;
+#pragma unroll
+    for (int a = 0; a <= K; ++a) { sx += cx[l - K + a] * h[a]; sy += cy[l - K + a] * h[a]; }
+    v[2 * m] = sx; v[2 * m + 1] = sy;
+  }
+  double* p = points + (size_t)i * 19;
+#pragma unroll
+  for (int c = 0; c < 19; ++c) p[c] = 0.0;
+  p[0] = v[0];
+  p[1] = v[1];
+  p[3] = atan2(v[3], v[2]);
+  const double s2 = v[2] * v[2] + v[3] * v[3];
+  const double curvature = fabs(v[2] * v[5] - v[3] * v[4]) / sqrt(s2 * s2 * s2);
+  p[5] = 1.0 / fabs(curvature);
+  p[17] = (double)i;
+  p[18] = -1.0;
+  double len = 0.0;
+  if (i > 0) {
+    const double a = u[i - 1], b = x;
+    const double centr = 0.5 * (a + b), hl = 0.5 * (b - a);
+    double resk = c_wgk[10] * speed_at<K>(t, n, cx, cy, centr);
+    for (int j = 0; j < 5; ++j) {
+      const int jt = 2 * j + 1;
+      const double ab = hl * c_xgk[jt];
+      resk += c_wgk[jt] * (speed_at<K>(t, n, cx, cy, centr - ab) + speed_at<K>(t, n, cx, cy, centr + ab));
+    }
+    for (int j = 0; j < 5; ++j) {
+      const int jt = 2 * j;
+      const double ab = hl * c_xgk[jt];
+      resk += c_wgk[jt] * (speed_at<K>(t, n, cx, cy, centr - ab) + speed_at<K>(t, n, cx, cy, centr + ab));
+    }
+    len = resk * hl;
+  }
+  seg[i] = len;
+}
+
+// sequential accumulation, in the reference's order (one lane; N adds)
+__global__ void k_sample_cumsum(const double* __restrict__ seg, int N, double length,
+                                double* __restrict__ points) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double acc = 0.0;
+  for (int i = 0; i < N; ++i) {
+    if (i > 0) acc = acc + seg[i];
+    points[(size_t)i * 19 + 6] = acc;
+    points[(size_t)i * 19 + 7] = length - acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5: one thread per (sample, ring); rings in global memory as double2
+__global__ void k_fill_bounds(double* __restrict__ points, int N, const double2* __restrict__ ringL,
+                              int nL, const double2* __restrict__ ringR, int nR, double max_dist) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= 2 * N) return;
+  const int side = tid / N;  // 0 = left, 1 = right  (wave-uniform except at the seam)
+  const int i = tid - side * N;
+  double* p = points + (size_t)i * 19;
+  const double px = p[0], py = p[1];
+  const double yaw_norm = p[3] + (side == 0 ? M_PI / 2.0 : -M_PI / 2.0);
+  const double dx = max_dist * cos(yaw_norm), dy = max_dist * sin(yaw_norm);
+  const double s = side == 0 ? search_ring_brute(ringL, nL, px, py, dx, dy)
+                             : search_ring_brute(ringR, nR, px, py, dx, dy);
+  p[9 + 2 * side] = px + s * dx;
+  p[10 + 2 * side] = py + s * dy;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared by k_cost and k_sweep: the six sums of optimizer.py:66-85 at one support sample.
+struct CostAcc {
+  double hxx, hyy, fx_pxx_b, fy_pxy_b, fy_pyy_b, b_pxy_fx;
+};
+__device__ __forceinline__ void cost_terms(double dx, double dy, double d2x, double d2y, double B,
+                                           double zx, double zy, CostAcc& a) {
+  const double Fx = d2x - B * zx;
+  const double Fy = d2y - B * zy;
+  const double s2 = dx * dx + dy * dy;
+  const double denom = s2 * s2 * s2;
+  const double Pxx = (dy * dy) / denom;
+  const double Pxy = (-2.0 * dx * dy) / denom;
+  const double Pyy = (dx * dx) / denom;
+  a.hxx += B * Pxx * B;
+  a.hyy += B * Pyy * B;
+  a.fx_pxx_b += Fx * Pxx * B;
+  a.fy_pxy_b += Fy * Pxy * B;
+  a.fy_pyy_b += Fy * Pyy * B;
+  a.b_pxy_fx += B * Pxy * Fx;
+}
+
+// a7: one workgroup (256 threads) per requested control point
+template <int K>
+__global__ __launch_bounds__(256) void k_cost(TrackDev tr, const double* __restrict__ cx,
+                                              const double* __restrict__ cy,
+                                              const int* __restrict__ idxs,
+                                              const double* __restrict__ z,
+                                              double* __restrict__ H, double* __restrict__ g,
+                                              int* __restrict__ Mout) {
+  __shared__ double red[6][4];
+  const int q = blockIdx.x;
+  const int idx = idxs[q];
+  const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+  const double zx = z ? z[2 * q] : cx[idx];
+  const double zy = z ? z[2 * q + 1] : cy[idx];
+  const double* __restrict__ D2 = tr.D + (size_t)2 * (K + 1) * tr.N;
+  CostAcc acc{0, 0, 0, 0, 0, 0};
+  for (int i = s0 + (int)threadIdx.x; i < s1; i += blockDim.x) {
+    const int l = tr.ell[i];
+    CurvePoint<K, 2> c;
+    eval_sample<K, 2>(tr, cx, cy, i, l, c);
+    const double B = D2[(size_t)(idx - l + K) * tr.N + i];
+    cost_terms(c.dx, c.dy, c.d2x, c.d2y, B, zx, zy, acc);
+  }
+  double v[6] = {acc.hxx, acc.hyy, acc.fx_pxx_b, acc.fy_pxy_b, acc.fy_pyy_b, acc.b_pxy_fx};
+  const int w = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double s = wave_sum(v[c]);
+    if (lane == 0) red[c][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s[6];
+    for (int c = 0; c < 6; ++c) s[c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+    H[4 * q + 0] = 2.0 * s[0]; H[4 * q + 1] = 0.0; H[4 * q + 2] = 0.0; H[4 * q + 3] = 2.0 * s[1];
+    g[2 * q + 0] = s[2] + s[2];
+    g[2 * q + 1] = (s[3] + s[4]) + (s[5] + s[4]);
+    if (Mout) Mout[q] = s1 - s0;
+  }
+}
+
+// a8: one workgroup for one control point; reads X,Y and the bound columns from `points`
+template <int K>
+__global__ void k_constraint(TrackDev tr, const double* __restrict__ cx,
+                             const double* __restrict__ cy, const double* __restrict__ points,
+                             int idx, double* __restrict__ b, double* __restrict__ lba,
+                             double* __restrict__ uba) {
+  const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+  const double zx = cx[idx], zy = cy[idx];
+  for (int i = s0 + blockIdx.x * blockDim.x + threadIdx.x; i < s1; i += gridDim.x * blockDim.x) {
+    const int l = tr.ell[i];
+    const double bi = tr.D[(size_t)(idx - l + K) * tr.N + i];
+    const double* p = points + (size_t)i * 19;
+    const double nzx = p[0] - bi * zx, nzy = p[1] - bi * zy;
+    const int r = i - s0;
+    b[r] = bi;
+    lba[2 * r] = fmin(p[9], p[11]) - nzx;
+    lba[2 * r + 1] = fmin(p[10], p[12]) - nzy;
+    uba[2 * r] = fmax(p[9], p[11]) - nzx;
+    uba[2 * r + 1] = fmax(p[10], p[12]) - nzy;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12: the sweep.
+struct SweepArgs {
+  TrackDev tr;
+  int B;
+  int form;             // RL_BOUNDS_*
+  const double* in;     // widths [B,N,2] or bound points [B,N,4]
+  const double2* ringL; // shared rings (form 0), global
+  const double2* ringR;
+  int nL, nR;           // ring vertex counts actually used (form 1/2: N)
+  int max_iter;
+  int i_start[32];
+  int search;           // RL_SEARCH_*
+  double max_dist;      // 100.0 (race_track.py:104)
+  double* out_ctrl;     // [B,n,2]
+  double* out_xy;       // [B,N,2]
+  double* out_points;   // optional [B,N,19]: X,Y,YAW,radius,bounds (single-instance API)
+  int* n_success;       // [B,2*max_iter] or null
+  int* status;          // [B] or null
+  double* gscratch;     // per-instance global scratch when rings/sigma do not fit LDS
+  size_t gscratch_stride;  // doubles per instance
+};
+
+// LDS carve (doubles).  cpad = n rounded up to even so every later array is 16-byte aligned.
+struct SweepLds {
+  int cpad, nLp, nRp, ncL, ncR;
+  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, total;
+};
+
+__host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds) {
+  SweepLds L;
+  L.cpad = (n + 1) & ~1;
+  L.nLp = nL; L.nRp = nR;
+  L.ncL = (nL + kChunk - 1) / kChunk;
+  L.ncR = (nR + kChunk - 1) / kChunk;
+  size_t o = 0;
+  L.off_cx = o; o += L.cpad;
+  L.off_cy = o; o += L.cpad;
+  L.off_red = o; o += 16 * 12;           // up to 16 waves x 12 partials
+  L.off_cL = o; o += (size_t)((3 * L.ncL + 1) & ~1);
+  L.off_cR = o; o += (size_t)((3 * L.ncR + 1) & ~1);
+  if (rings_in_lds) {
+    L.off_sL = o; o += (size_t)((N + 1) & ~1);
+    L.off_sR = o; o += (size_t)((N + 1) & ~1);
+    L.off_rL = o; o += (size_t)2 * nL;
+    L.off_rR = o; o += (size_t)2 * nR;
+  } else {
+    L.off_sL = L.off_sR = L.off_rL = L.off_rR = 0;
+  }
+  L.total = o;
+  return L;
+}
+
+template <int K, int BLOCK, bool RINGS_LDS>
+__global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* smem = reinterpret_cast<double*>(smem_raw);
+  const TrackDev& tr = a.tr;
+  const int n = tr.n, N = tr.N;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid % kWave, wave = tid / kWave;
+  constexpr int NW = BLOCK / kWave;
+  const SweepLds L = sweep_lds_layout(n, N, a.nL, a.nR, RINGS_LDS);
+  double* cx = smem + L.off_cx;
+  double* cy = smem + L.off_cy;
+  double* red = smem + L.off_red;
+  double* circL = smem + L.off_cL;
+  double* circR = smem + L.off_cR;
+  double* sL; double* sR; double2* rL; double2* rR;
+  if (RINGS_LDS) {
+    sL = smem + L.off_sL; sR = smem + L.off_sR;
+    rL = reinterpret_cast<double2*>(smem + L.off_rL);
+    rR = reinterpret_cast<double2*>(smem + L.off_rR);
+  } else {
+    double* g = a.gscratch + (size_t)b * a.gscratch_stride;
+    sL = g; sR = sL + ((N + 1) & ~1);
+    rL = reinterpret_cast<double2*>(sR + ((N + 1) & ~1));
+    rR = rL + a.nL;
+  }
+  const int nL = a.nL, nR = a.nR;
+
+  // ---- prologue: control points, ring vertices, chunk circles
+  for (int j = tid; j < n; j += BLOCK) { cx[j] = tr.c0[j]; cy[j] = tr.c0[n + j]; }
+  if (a.form == 1) {  // widths: vertex i = p0_i + w_l n0_i  /  p0_i - w_r n0_i
+    const double2* w = reinterpret_cast<const double2*>(a.in) + (size_t)b * N;
+    for (int i = tid; i < N; i += BLOCK) {
+      const double2 wi = w[i];
+      const double px = tr.base[i], py = tr.base[(size_t)N + i];
+      const double nx = tr.base[(size_t)2 * N + i], ny = tr.base[(size_t)3 * N + i];
+      rL[i] = make_double2(px + wi.x * nx, py + wi.x * ny);
+      rR[i] = make_double2(px - wi.y * nx, py - wi.y * ny);
+    }
+  } else if (a.form == 2) {  // bound points
+    const double4* w = reinterpret_cast<const double4*>(a.in) + (size_t)b * N;
+    for (int i = tid; i < N; i += BLOCK) {
+      const double4 wi = w[i];
+      rL[i] = make_double2(wi.x, wi.y);
+      rR[i] = make_double2(wi.z, wi.w);
+    }
+  } else {
+    for (int i = tid; i < nL; i += BLOCK) rL[i] = a.ringL[i];
+    for (int i = tid; i < nR; i += BLOCK) rR[i] = a.ringR[i];
+  }
+  __syncthreads();
+  if (a.search == 1) {
+    for (int c = tid; c < L.ncL + L.ncR; c += BLOCK) {
+      const bool left = c < L.ncL;
+      const int cc = left ? c : c - L.ncL;
+      const double2* ring = left ? rL : rR;
+      const int nr = left ? nL : nR;
+      const int j0 = cc * kChunk, j1 = min(j0 + kChunk, nr);
+      double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+      for (int j = j0; j <= j1; ++j) {
+        const double2 v = ring[j >= nr ? j - nr : j];
+        xmin = fmin(xmin, v.x); xmax = fmax(xmax, v.x);
+        ymin = fmin(ymin, v.y); ymax = fmax(ymax, v.y);
+      }
+      const double mx = 0.5 * (xmin + xmax), my = 0.5 * (ymin + ymax);
+      double r2 = 0.0;
+      for (int j = j0; j <= j1; ++j) {
+        const double2 v = ring[j >= nr ? j - nr : j];
+        const double ex = v.x - mx, ey = v.y - my;
+        r2 = fmax(r2, ex * ex + ey * ey);
+      }
+      double* o = (left ? circL : circR) + 3 * cc;
+      o[0] = mx; o[1] = my; o[2] = sqrt(r2) * (1.0 + 1e-12);
+    }
+    __syncthreads();
+  }
+
+  // refresh(i0,i1): new p, normal and closest ring crossings for samples [i0,i1)
+  auto refresh = [&](int i0, int i1, int j0, int j1) {
+    // tasks: (sample, ring) pairs of two sample ranges; a wave mostly works on one ring
+    const int m0 = i1 - i0, m1 = j1 - j0, m = m0 + m1;
+    for (int task = tid; task < 2 * m; task += BLOCK) {
+      const int side = task >= m;
+      const int r = side ? task - m : task;
+      const int i = r < m0 ? i0 + r : j0 + (r - m0);
+      const int l = tr.ell[i];
+      CurvePoint<K, 1> c;
+      eval_sample<K, 1>(tr, cx, cy, i, l, c);
+      const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
+      double dx = -c.dy * inv, dy = c.dx * inv;  // max_dist * (cos, sin)(yaw + pi/2)
+      if (side) { dx = -dx; dy = -dy; }          // yaw - pi/2
+      double s;
+      if (a.search == 1) {
+        s = side ? search_ring_culled(rR, nR, circR, L.ncR, c.x, c.y, dx, dy, a.max_dist)
+                 : search_ring_culled(rL, nL, circL, L.ncL, c.x, c.y, dx, dy, a.max_dist);
+      } else {
+        s = side ? search_ring_brute(rR, nR, c.x, c.y, dx, dy)
+                 : search_ring_brute(rL, nL, c.x, c.y, dx, dy);
+      }
+      (side ? sR : sL)[i] = s;
+    }
+  };
+
+  refresh(0, N, 0, 0);  // optimizer.py:259
+  __syncthreads();
+
+  const int ignore_front = K / 2, ignore_rear = K - ignore_front;  // optimizer.py:297-302
+  const int i_max = n - ignore_rear, i_min = ignore_front;
+  const double* __restrict__ D0 = tr.D;
+  const double* __restrict__ D2 = tr.D + (size_t)2 * (K + 1) * N;
+  int n_skipped = 0;
+
+  for (int it = 0; it < a.max_iter; ++it) {
+    const int st = a.i_start[it];
+    for (int pass = 0; pass < 2; ++pass) {
+      int ok_count = 0;
+      const int steps = i_max - i_min;
+      for (int stp = 0; stp < steps; ++stp) {
+        const int i_loop = pass == 0 ? stp : steps - stp;  // :305 / :316
+        int idx = i_loop + st;
+        if (idx >= i_max) idx = idx - i_max + i_min;
+        const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+        const double zx = cx[idx], zy = cy[idx];
+
+        // ---- phase 1: cost sums (a7) and the clamp interval of the box constraints (a8)
+        CostAcc acc{0, 0, 0, 0, 0, 0};
+        double lox = -INFINITY, hix = INFINITY, loy = -INFINITY, hiy = INFINITY;
+        double bad = 0.0;
+        for (int i = s0 + tid; i < s1; i += BLOCK) {
+          const int l = tr.ell[i];
+          CurvePoint<K, 2> c;
+          eval_sample<K, 2>(tr, cx, cy, i, l, c);
+          const int aa = idx - l + K;
+          const double B2 = D2[(size_t)aa * N + i];
+          const double B0 = D0[(size_t)aa * N + i];
+          cost_terms(c.dx, c.dy, c.d2x, c.d2y, B2, zx, zy, acc);
+          // bound points of this sample from the stored crossings (same arithmetic as refresh)
+          const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
+          const double ndx = -c.dy * inv, ndy = c.dx * inv;
+          const double sl = sL[i], sr = sR[i];
+          const double Lx = c.x + sl * ndx, Ly = c.y + sl * ndy;
+          const double Rx = c.x + sr * (-ndx), Ry = c.y + sr * (-ndy);
+          const double nzx = c.x - B0 * zx, nzy = c.y - B0 * zy;
+          const double lbx = fmin(Lx, Rx) - nzx, ubx = fmax(Lx, Rx) - nzx;
+          const double lby = fmin(Ly, Ry) - nzy, uby = fmax(Ly, Ry) - nzy;
+          if (B0 > 0.0) {
+            lox = fmax(lox, lbx / B0); hix = fmin(hix, ubx / B0);
+            loy = fmax(loy, lby / B0); hiy = fmin(hiy, uby / B0);
+          } else {
+            if (lbx > 0.0 || ubx < 0.0 || lby > 0.0 || uby < 0.0) bad = 1.0;
+          }
+          if (!(lbx == lbx) || !(ubx == ubx) || !(lby == lby) || !(uby == uby)) bad = 1.0;
+        }
+        {
+          double v[11];
+          v[0] = wave_sum(acc.hxx); v[1] = wave_sum(acc.hyy); v[2] = wave_sum(acc.fx_pxx_b);
+          v[3] = wave_sum(acc.fy_pxy_b); v[4] = wave_sum(acc.fy_pyy_b); v[5] = wave_sum(acc.b_pxy_fx);
+          v[6] = wave_max(lox); v[7] = wave_min(hix); v[8] = wave_max(loy); v[9] = wave_min(hiy);
+          v[10] = wave_max(bad);
+          if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 11; ++c) red[wave * 12 + c] = v[c];
+          }
+        }
+        __syncthreads();
+        // ---- phase 2: closed-form QP (a11), every thread redundantly
+        double s[11];
+#pragma unroll
+        for (int c = 0; c < 11; ++c) s[c] = red[c];
+        for (int w = 1; w < NW; ++w) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) s[c] += red[w * 12 + c];
+          s[6] = fmax(s[6], red[w * 12 + 6]); s[7] = fmin(s[7], red[w * 12 + 7]);
+          s[8] = fmax(s[8], red[w * 12 + 8]); s[9] = fmin(s[9], red[w * 12 + 9]);
+          s[10] = fmax(s[10], red[w * 12 + 10]);
+        }
+        const double H0 = 2.0 * s[0], H1 = 2.0 * s[1];
+        const double g0 = s[2] + s[2];
+        const double g1 = (s[3] + s[4]) + (s[5] + s[4]);
+        bool ok = (s[10] == 0.0) && (H0 > 0.0) && (H1 > 0.0) && isfinite(H0) && isfinite(H1) &&
+                  isfinite(g0) && isfinite(g1) && (s[6] <= s[7]) && (s[8] <= s[9]);
+        __syncthreads();  // everyone has read `red` and the old control points
+        if (ok) {
+          double nzx = -g0 / H0, nzy = -g1 / H1;
+          nzx = fmin(fmax(nzx, s[6]), s[7]);
+          nzy = fmin(fmax(nzy, s[8]), s[9]);
+          if (tid == 0) {
+            // optimizer.py:280-285 (wrap hard-coded for k = 5 in the reference)
+            cx[idx] = nzx;         cy[idx] = nzy;
+            cx[0] = cx[n - 5];     cy[0] = cy[n - 5];
+            cx[1] = cx[n - 4];     cy[1] = cy[n - 4];
+            cx[n - 3] = cx[2];     cy[n - 3] = cy[2];
+            cx[n - 2] = cx[3];     cy[n - 2] = cy[3];
+            cx[n - 1] = cx[4];     cy[n - 1] = cy[4];
+          }
+          __syncthreads();
+          // ---- phase 3: re-sample (a3) and re-intersect (a5) what moved
+          int alias = -1;
+          if (idx <= 4 && idx >= 2) alias = idx + (n - 5);
+          else if (idx >= n - 5 && idx <= n - 4) alias = idx - (n - 5);
+          int j0 = 0, j1 = 0;
+          if (alias >= 0) { j0 = tr.sup[2 * alias]; j1 = tr.sup[2 * alias + 1]; }
+          refresh(s0, s1, j0, j1);
+          __syncthreads();
+          ++ok_count;
+        } else {
+          ++n_skipped;
+        }
+      }
+      if (tid == 0 && a.n_success) a.n_success[(size_t)b * 2 * a.max_iter + 2 * it + pass] = ok_count;
+    }
+  }
+
+  // ---- epilogue
+  if (tid == 0 && a.status) a.status[b] = n_skipped;
+  for (int j = tid; j < n; j += BLOCK) {
+    reinterpret_cast<double2*>(a.out_ctrl)[(size_t)b * n + j] = make_double2(cx[j], cy[j]);
+  }
+  for (int i = tid; i < N; i += BLOCK) {
+    const int l = tr.ell[i];
+    if (a.out_points) {
+      CurvePoint<K, 2> c;
+      eval_sample<K, 2>(tr, cx, cy, i, l, c);
+      double* p = a.out_points + ((size_t)b * N + i) * 19;
+      const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
+      const double ndx = -c.dy * inv, ndy = c.dx * inv;
+      p[0] = c.x; p[1] = c.y; p[3] = atan2(c.dy, c.dx);
+      const double s2 = c.dx * c.dx + c.dy * c.dy;
+      p[5] = 1.0 / fabs(fabs(c.dx * c.d2y - c.dy * c.d2x) / sqrt(s2 * s2 * s2));
+      p[9] = c.x + sL[i] * ndx;  p[10] = c.y + sL[i] * ndy;
+      p[11] = c.x - sR[i] * ndx; p[12] = c.y - sR[i] * ndy;
+      if (a.out_xy) reinterpret_cast<double2*>(a.out_xy)[(size_t)b * N + i] = make_double2(c.x, c.y);
+    } else {
+      CurvePoint<K, 0> c;
+      eval_sample<K, 0>(tr, cx, cy, i, l, c);
+      reinterpret_cast<double2*>(a.out_xy)[(size_t)b * N + i] = make_double2(c.x, c.y);
+    }
+  }
+}
+
+}  // namespace rl

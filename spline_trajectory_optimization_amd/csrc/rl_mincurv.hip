@@ -1,0 +1,563 @@
+// rl_mincurv.hip -- C ABI (include/rl_mincurv.h) over the HIP kernels in rl_kernels.hpp.
+// Built for gfx950 only:  hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC
+//
+// There is deliberately no CPU path in this library: every entry point launches HIP kernels and
+// fails with RL_ERR_HIP when no device is usable.
+#include "../../include/rl_mincurv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rl_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define RL_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      return fail(RL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    }                                                                                     \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+}  // namespace
+
+struct rl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int max_lds = 65536;
+  int num_cu = 0;
+};
+
+struct rl_track {
+  rl_ctx* ctx = nullptr;
+  int k = 0, n = 0, nt = 0, N = 0;
+  std::vector<double> t_host;
+  DevBuf<double> t, c0, D, base;
+  DevBuf<int> ell, sup;
+  DevBuf<double> ringL, ringR;  // shared rings as (x,y) pairs
+  int nL = 0, nR = 0;
+  mutable DevBuf<double> gscratch;  // for the non-LDS-resident sweep variant
+  rl::TrackDev dev() const {
+    rl::TrackDev d;
+    d.k = k; d.n = n; d.nt = nt; d.N = N;
+    d.t = t.p; d.c0 = c0.p; d.ell = ell.p; d.D = D.p; d.sup = sup.p; d.base = base.p;
+    return d;
+  }
+};
+
+namespace {
+
+bool degree_supported(int k) { return k == 3 || k == 5; }
+
+// dispatch a callable templated on the spline degree
+template <typename F3, typename F5>
+int by_degree(int k, F3&& f3, F5&& f5) {
+  if (k == 3) return f3();
+  if (k == 5) return f5();
+  return fail(RL_ERR_UNSUPPORTED, "spline degree must be 3 or 5");
+}
+
+int check_spline(const double* t, int nt, const double* cx, const double* cy, int k) {
+  if (!t || !cx || !cy) return fail(RL_ERR_ARG, "null spline pointer");
+  if (!degree_supported(k)) return fail(RL_ERR_UNSUPPORTED, "spline degree must be 3 or 5");
+  if (nt < 2 * (k + 1)) return fail(RL_ERR_ARG, "knot vector too short");
+  return RL_OK;
+}
+
+struct SweepPlan {
+  bool rings_in_lds;
+  size_t lds_bytes;
+  size_t gscratch_doubles;  // per instance, 0 if rings_in_lds
+  int block;
+};
+
+SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR) {
+  SweepPlan p;
+  rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true);
+  p.block = 256;
+  if (in.total * sizeof(double) <= (size_t)ctx->max_lds) {
+    p.rings_in_lds = true;
+    p.lds_bytes = in.total * sizeof(double);
+    p.gscratch_doubles = 0;
+  } else {
+    rl::SweepLds out = rl::sweep_lds_layout(n, N, nL, nR, false);
+    p.rings_in_lds = false;
+    p.lds_bytes = out.total * sizeof(double);
+    p.gscratch_doubles = (size_t)2 * ((N + 1) & ~1) + (size_t)2 * nL + (size_t)2 * nR;
+  }
+  return p;
+}
+
+template <int K, int BLOCK, bool RL>
+int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
+  auto kern = rl::k_sweep<K, BLOCK, RL>;
+  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
+  RL_HIP(hipGetLastError());
+  return RL_OK;
+}
+
+int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a) {
+  if (k == 5) {
+    return p.rings_in_lds ? launch_sweep_t<5, 256, true>(ctx, a, p.lds_bytes)
+                          : launch_sweep_t<5, 256, false>(ctx, a, p.lds_bytes);
+  }
+  if (k == 3) {
+    return p.rings_in_lds ? launch_sweep_t<3, 256, true>(ctx, a, p.lds_bytes)
+                          : launch_sweep_t<3, 256, false>(ctx, a, p.lds_bytes);
+  }
+  return fail(RL_ERR_UNSUPPORTED, "spline degree must be 3 or 5");
+}
+
+}  // namespace
+
+extern "C" {
+
+int rl_version(void) { return RL_VERSION; }
+
+const char* rl_last_error(void) { return g_err.c_str(); }
+
+int rl_ctx_create(int device_id, rl_ctx** out) {
+  if (!out) return fail(RL_ERR_ARG, "out is null");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(RL_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= count) return fail(RL_ERR_ARG, "bad device id");
+  RL_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  RL_HIP(hipGetDeviceProperties(&prop, device_id));
+  rl_ctx* c = new rl_ctx();
+  c->device = device_id;
+  c->max_lds = (int)prop.sharedMemPerBlock;  // 160 KiB on gfx950
+  {
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess &&
+        optin > c->max_lds)
+      c->max_lds = optin;
+  }
+  c->num_cu = prop.multiProcessorCount;
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return fail(RL_ERR_HIP, "hipEventCreate failed");
+  }
+  *out = c;
+  return RL_OK;
+}
+
+void rl_ctx_destroy(rl_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+}
+
+int rl_ctx_set_stream(rl_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return RL_OK;
+}
+
+int rl_ctx_synchronize(rl_ctx* ctx) {
+  if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int rl_spline_eval(rl_ctx* ctx, const double* t, int nt, const double* cx, const double* cy, int k,
+                   const double* u, int N, int der_max, double* out) {
+  if (!ctx || !u || !out) return fail(RL_ERR_ARG, "null argument");
+  if (int rc = check_spline(t, nt, cx, cy, k)) return rc;
+  if (N <= 0 || der_max < 0 || der_max > 2) return fail(RL_ERR_ARG, "bad N / der_max");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = nt - k - 1;
+  DevBuf<double> dt, dcx, dcy, du, dout;
+  RL_HIP(dt.alloc(nt)); RL_HIP(dcx.alloc(n)); RL_HIP(dcy.alloc(n)); RL_HIP(du.alloc(N));
+  RL_HIP(dout.alloc((size_t)2 * (der_max + 1) * N));
+  RL_HIP(hipMemcpyAsync(dt.p, t, nt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dcx.p, cx, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dcy.p, cy, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(du.p, u, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const dim3 grid((N + 255) / 256), block(256);
+  int rc = by_degree(
+      k,
+      [&] { hipLaunchKernelGGL(rl::k_spline_eval<3>, grid, block, 0, ctx->stream, dt.p, nt, dcx.p, dcy.p, du.p, N, der_max, dout.p); return RL_OK; },
+      [&] { hipLaunchKernelGGL(rl::k_spline_eval<5>, grid, block, 0, ctx->stream, dt.p, nt, dcx.p, dcy.p, du.p, N, der_max, dout.p); return RL_OK; });
+  if (rc) return rc;
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(out, dout.p, dout.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+int rl_sample_along(rl_ctx* ctx, const double* t, int nt, const double* cx, const double* cy, int k,
+                    double length, const double* u, int N, double* points) {
+  if (!ctx || !u || !points) return fail(RL_ERR_ARG, "null argument");
+  if (int rc = check_spline(t, nt, cx, cy, k)) return rc;
+  if (N <= 0) return fail(RL_ERR_ARG, "bad N");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = nt - k - 1;
+  DevBuf<double> dt, dcx, dcy, du, dpts, dseg;
+  RL_HIP(dt.alloc(nt)); RL_HIP(dcx.alloc(n)); RL_HIP(dcy.alloc(n)); RL_HIP(du.alloc(N));
+  RL_HIP(dpts.alloc((size_t)N * RL_NCOL)); RL_HIP(dseg.alloc(N));
+  RL_HIP(hipMemcpyAsync(dt.p, t, nt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dcx.p, cx, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dcy.p, cy, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(du.p, u, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const dim3 grid((N + 127) / 128), block(128);
+  int rc = by_degree(
+      k,
+      [&] { hipLaunchKernelGGL(rl::k_sample_geometry<3>, grid, block, 0, ctx->stream, dt.p, nt, dcx.p, dcy.p, du.p, N, dpts.p, dseg.p); return RL_OK; },
+      [&] { hipLaunchKernelGGL(rl::k_sample_geometry<5>, grid, block, 0, ctx->stream, dt.p, nt, dcx.p, dcy.p, du.p, N, dpts.p, dseg.p); return RL_OK; });
+  if (rc) return rc;
+  RL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rl::k_sample_cumsum, dim3(1), dim3(64), 0, ctx->stream, dseg.p, N, length, dpts.p);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+int rl_fill_bounds(rl_ctx* ctx, double* points, int N, const double* ringL, int nL,
+                   const double* ringR, int nR, double max_dist) {
+  if (!ctx || !points || !ringL || !ringR) return fail(RL_ERR_ARG, "null argument");
+  if (N <= 0 || nL < 2 || nR < 2) return fail(RL_ERR_ARG, "bad sizes");
+  RL_HIP(hipSetDevice(ctx->device));
+  DevBuf<double> dpts, dL, dR;
+  RL_HIP(dpts.alloc((size_t)N * RL_NCOL)); RL_HIP(dL.alloc((size_t)2 * nL)); RL_HIP(dR.alloc((size_t)2 * nR));
+  RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dL.p, ringL, dL.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dR.p, ringR, dR.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(rl::k_fill_bounds, dim3((2 * N + 63) / 64), dim3(64), 0, ctx->stream, dpts.p, N,
+                     reinterpret_cast<const double2*>(dL.p), nL,
+                     reinterpret_cast<const double2*>(dR.p), nR, max_dist);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int rl_track_create(rl_ctx* ctx, const double* t, int nt, const double* cx0, const double* cy0,
+                    int k, int N, rl_track** out) {
+  if (!ctx || !out) return fail(RL_ERR_ARG, "null argument");
+  if (int rc = check_spline(t, nt, cx0, cy0, k)) return rc;
+  if (N <= 0) return fail(RL_ERR_ARG, "bad N");
+  const int n = nt - k - 1;
+  if (n < 2 * k + 1) return fail(RL_ERR_ARG, "too few control points for the periodic wrap");
+  RL_HIP(hipSetDevice(ctx->device));
+  rl_track* trk = new rl_track();
+  trk->ctx = ctx;
+  trk->k = k; trk->n = n; trk->nt = nt; trk->N = N;
+  trk->t_host.assign(t, t + nt);
+  // support ranges with the reference's own mask: (u >= t[j]) & (u < t[j+k+1]), u_i = i * (1/N)
+  std::vector<int> sup(2 * (size_t)n);
+  const double step = 1.0 / (double)N;
+  for (int j = 0; j < n; ++j) {
+    const double ts = t[j], te = t[j + k + 1];
+    int a = 0;
+    while (a < N && !((double)a * step >= ts)) ++a;
+    int b = a;
+    while (b < N && (double)b * step < te) ++b;
+    sup[2 * j] = a;
+    sup[2 * j + 1] = b;
+  }
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  ok(trk->t.alloc(nt)); ok(trk->c0.alloc((size_t)2 * n)); ok(trk->D.alloc((size_t)3 * (k + 1) * N));
+  ok(trk->base.alloc((size_t)4 * N)); ok(trk->ell.alloc(N)); ok(trk->sup.alloc((size_t)2 * n));
+  if (e == hipSuccess) ok(hipMemcpyAsync(trk->t.p, t, nt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) ok(hipMemcpyAsync(trk->c0.p, cx0, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) ok(hipMemcpyAsync(trk->c0.p + n, cy0, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) ok(hipMemcpyAsync(trk->sup.p, sup.data(), sup.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) {
+    const dim3 grid((N + 127) / 128), block(128);
+    if (k == 3)
+      hipLaunchKernelGGL(rl::k_build_tables<3>, grid, block, 0, ctx->stream, trk->t.p, nt, trk->c0.p, N, trk->ell.p, trk->D.p, trk->base.p);
+    else
+      hipLaunchKernelGGL(rl::k_build_tables<5>, grid, block, 0, ctx->stream, trk->t.p, nt, trk->c0.p, N, trk->ell.p, trk->D.p, trk->base.p);
+    ok(hipGetLastError());
+    ok(hipStreamSynchronize(ctx->stream));
+  }
+  if (e != hipSuccess) {
+    delete trk;
+    return fail(RL_ERR_HIP, std::string("rl_track_create: ") + hipGetErrorString(e));
+  }
+  *out = trk;
+  return RL_OK;
+}
+
+void rl_track_destroy(rl_track* trk) { delete trk; }
+
+int rl_track_set_rings(rl_track* trk, const double* ringL, int nL, const double* ringR, int nR) {
+  if (!trk || !ringL || !ringR) return fail(RL_ERR_ARG, "null argument");
+  if (nL < 3 || nR < 3) return fail(RL_ERR_ARG, "a ring needs at least 3 vertices");
+  RL_HIP(hipSetDevice(trk->ctx->device));
+  // shapely's LinearRing drops an explicit closing vertex; do the same
+  if (ringL[0] == ringL[2 * (nL - 1)] && ringL[1] == ringL[2 * (nL - 1) + 1]) --nL;
+  if (ringR[0] == ringR[2 * (nR - 1)] && ringR[1] == ringR[2 * (nR - 1) + 1]) --nR;
+  RL_HIP(trk->ringL.alloc((size_t)2 * nL));
+  RL_HIP(trk->ringR.alloc((size_t)2 * nR));
+  RL_HIP(hipMemcpy(trk->ringL.p, ringL, (size_t)2 * nL * sizeof(double), hipMemcpyHostToDevice));
+  RL_HIP(hipMemcpy(trk->ringR.p, ringR, (size_t)2 * nR * sizeof(double), hipMemcpyHostToDevice));
+  trk->nL = nL;
+  trk->nR = nR;
+  return RL_OK;
+}
+
+int rl_track_set_control_points(rl_track* trk, const double* cx0, const double* cy0) {
+  if (!trk || !cx0 || !cy0) return fail(RL_ERR_ARG, "null argument");
+  rl_ctx* ctx = trk->ctx;
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = trk->n, N = trk->N;
+  RL_HIP(hipMemcpyAsync(trk->c0.p, cx0, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(trk->c0.p + n, cy0, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const dim3 grid((N + 127) / 128), block(128);
+  if (trk->k == 3)
+    hipLaunchKernelGGL(rl::k_build_tables<3>, grid, block, 0, ctx->stream, trk->t.p, trk->nt, trk->c0.p, N, trk->ell.p, trk->D.p, trk->base.p);
+  else
+    hipLaunchKernelGGL(rl::k_build_tables<5>, grid, block, 0, ctx->stream, trk->t.p, trk->nt, trk->c0.p, N, trk->ell.p, trk->D.p, trk->base.p);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int rl_mincurv_cost(rl_ctx* ctx, const rl_track* trk, const int* idx, int n_idx, const double* z,
+                    double* H, double* g, int* M) {
+  if (!ctx || !trk || !idx || !H || !g) return fail(RL_ERR_ARG, "null argument");
+  if (n_idx <= 0) return fail(RL_ERR_ARG, "n_idx <= 0");
+  for (int q = 0; q < n_idx; ++q)
+    if (idx[q] < 0 || idx[q] >= trk->n) return fail(RL_ERR_ARG, "control point index out of range");
+  RL_HIP(hipSetDevice(ctx->device));
+  DevBuf<int> didx, dM;
+  DevBuf<double> dz, dH, dg;
+  RL_HIP(didx.alloc(n_idx)); RL_HIP(dM.alloc(n_idx));
+  RL_HIP(dH.alloc((size_t)4 * n_idx)); RL_HIP(dg.alloc((size_t)2 * n_idx));
+  RL_HIP(hipMemcpyAsync(didx.p, idx, n_idx * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (z) {
+    RL_HIP(dz.alloc((size_t)2 * n_idx));
+    RL_HIP(hipMemcpyAsync(dz.p, z, (size_t)2 * n_idx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  const rl::TrackDev td = trk->dev();
+  const double* cx = trk->c0.p;
+  const double* cy = trk->c0.p + trk->n;
+  if (trk->k == 3)
+    hipLaunchKernelGGL(rl::k_cost<3>, dim3(n_idx), dim3(256), 0, ctx->stream, td, cx, cy, didx.p, dz.p, dH.p, dg.p, dM.p);
+  else
+    hipLaunchKernelGGL(rl::k_cost<5>, dim3(n_idx), dim3(256), 0, ctx->stream, td, cx, cy, didx.p, dz.p, dH.p, dg.p, dM.p);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(H, dH.p, dH.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(g, dg.p, dg.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (M) RL_HIP(hipMemcpyAsync(M, dM.p, n_idx * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+int rl_track_constraint(rl_ctx* ctx, const rl_track* trk, const double* points, int idx,
+                        double* b, double* lba, double* uba, int* M) {
+  if (!ctx || !trk || !points || !b || !lba || !uba || !M) return fail(RL_ERR_ARG, "null argument");
+  if (idx < 0 || idx >= trk->n) return fail(RL_ERR_ARG, "control point index out of range");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int N = trk->N, k = trk->k;
+  // support size on the host (same mask as rl_track_create)
+  const double step = 1.0 / (double)N;
+  const double ts = trk->t_host[idx], te = trk->t_host[idx + k + 1];
+  int s0 = 0;
+  while (s0 < N && !((double)s0 * step >= ts)) ++s0;
+  int s1 = s0;
+  while (s1 < N && (double)s1 * step < te) ++s1;
+  const int m = s1 - s0;
+  *M = m;
+  if (m == 0) return RL_OK;
+  DevBuf<double> dpts, db, dl, du;
+  RL_HIP(dpts.alloc((size_t)N * RL_NCOL)); RL_HIP(db.alloc(m)); RL_HIP(dl.alloc((size_t)2 * m)); RL_HIP(du.alloc((size_t)2 * m));
+  RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const rl::TrackDev td = trk->dev();
+  const double* cx = trk->c0.p;
+  const double* cy = trk->c0.p + trk->n;
+  const dim3 grid((m + 255) / 256), block(256);
+  if (k == 3)
+    hipLaunchKernelGGL(rl::k_constraint<3>, grid, block, 0, ctx->stream, td, cx, cy, dpts.p, idx, db.p, dl.p, du.p);
+  else
+    hipLaunchKernelGGL(rl::k_constraint<5>, grid, block, 0, ctx->stream, td, cx, cy, dpts.p, idx, db.p, dl.p, du.p);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(b, db.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(lba, dl.p, (size_t)2 * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(uba, du.p, (size_t)2 * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const double* in_dev,
+                              int B, const int* i_start, int max_iter, int search,
+                              double* out_ctrl, double* out_xy, double* out_points, int* n_success,
+                              int* status, rl_stats* stats, SweepPlan* plan_out) {
+  if (!ctx || !trk || !i_start || !out_ctrl) return fail(RL_ERR_ARG, "null argument");
+  if (!out_xy && !out_points) return fail(RL_ERR_ARG, "need out_xy or out_points");
+  if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
+  if (max_iter <= 0 || max_iter > RL_MAX_ITER) return fail(RL_ERR_ARG, "max_iter out of range");
+  if (search != RL_SEARCH_BRUTE && search != RL_SEARCH_CULLED) return fail(RL_ERR_ARG, "bad search mode");
+  const int n = trk->n, N = trk->N, k = trk->k;
+  const int i_min = k / 2, i_max = n - (k - k / 2);
+  for (int j = 0; j < max_iter; ++j)
+    if (i_start[j] < i_min || i_start[j] >= i_max)
+      return fail(RL_ERR_ARG, "i_start outside [k//2, n-(k-k//2)) (optimizer.py:301-303)");
+  rl::SweepArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.tr = trk->dev();
+  a.B = B;
+  a.form = form;
+  a.in = in_dev;
+  if (form == RL_BOUNDS_SHARED_RINGS) {
+    if (trk->nL == 0) return fail(RL_ERR_ARG, "rl_track_set_rings was not called");
+    a.ringL = reinterpret_cast<const double2*>(trk->ringL.p);
+    a.ringR = reinterpret_cast<const double2*>(trk->ringR.p);
+    a.nL = trk->nL; a.nR = trk->nR;
+  } else if (form == RL_BOUNDS_WIDTHS || form == RL_BOUNDS_POINTS) {
+    if (!in_dev) return fail(RL_ERR_ARG, "bounds input is null");
+    a.nL = N; a.nR = N;
+  } else {
+    return fail(RL_ERR_ARG, "bad bounds_form");
+  }
+  a.max_iter = max_iter;
+  for (int j = 0; j < max_iter; ++j) a.i_start[j] = i_start[j];
+  a.search = search;
+  a.max_dist = 100.0;  // race_track.py:104
+  a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_points = out_points;
+  a.n_success = n_success; a.status = status;
+  RL_HIP(hipSetDevice(ctx->device));
+  SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR);
+  if (p.lds_bytes > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "problem does not fit LDS");
+  if (!p.rings_in_lds) {
+    const size_t need = p.gscratch_doubles * (size_t)B;
+    if (trk->gscratch.n < need) RL_HIP(trk->gscratch.alloc(need));
+    a.gscratch = trk->gscratch.p;
+    a.gscratch_stride = p.gscratch_doubles;
+  }
+  if (stats) {
+    stats->lds_bytes = (int)p.lds_bytes;
+    stats->block_threads = p.block;
+    stats->rings_in_lds = p.rings_in_lds ? 1 : 0;
+  }
+  if (plan_out) *plan_out = p;
+  return launch_sweep(ctx, k, p, a);
+}
+
+int rl_mincurv_solve_batch_dev(rl_ctx* ctx, const rl_track* trk, int bounds_form, const double* in,
+                               int B, const int* i_start, int max_iter, int search,
+                               double* out_ctrl, double* out_xy, int* n_success, int* status,
+                               rl_stats* stats) {
+  if (!out_xy) return fail(RL_ERR_ARG, "out_xy is null");
+  return solve_batch_common(ctx, trk, bounds_form, in, B, i_start, max_iter, search, out_ctrl, out_xy,
+                            nullptr, n_success, status, stats, nullptr);
+}
+
+int rl_mincurv_solve_batch_host(rl_ctx* ctx, const rl_track* trk, int bounds_form, const double* in,
+                                int B, const int* i_start, int max_iter, int search,
+                                double* out_ctrl, double* out_xy, int* n_success, int* status,
+                                rl_stats* stats) {
+  if (!ctx || !trk || !out_ctrl || !out_xy) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = trk->n, N = trk->N;
+  const int cols = bounds_form == RL_BOUNDS_WIDTHS ? 2 : (bounds_form == RL_BOUNDS_POINTS ? 4 : 0);
+  DevBuf<double> din, dctrl, dxy;
+  DevBuf<int> dns, dst;
+  if (cols) {
+    if (!in) return fail(RL_ERR_ARG, "bounds input is null");
+    RL_HIP(din.alloc((size_t)B * N * cols));
+    RL_HIP(hipMemcpyAsync(din.p, in, din.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  RL_HIP(dctrl.alloc((size_t)B * n * 2)); RL_HIP(dxy.alloc((size_t)B * N * 2));
+  RL_HIP(dns.alloc((size_t)B * 2 * (max_iter > 0 ? max_iter : 1))); RL_HIP(dst.alloc(B));
+  RL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = solve_batch_common(ctx, trk, bounds_form, din.p, B, i_start, max_iter, search, dctrl.p, dxy.p,
+                              nullptr, dns.p, dst.p, stats, nullptr);
+  if (rc) return rc;
+  RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  RL_HIP(hipMemcpyAsync(out_ctrl, dctrl.p, dctrl.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(out_xy, dxy.p, dxy.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (n_success) RL_HIP(hipMemcpyAsync(n_success, dns.p, (size_t)B * 2 * max_iter * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (status) RL_HIP(hipMemcpyAsync(status, dst.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  if (stats) {
+    float ms = 0.f;
+    RL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->kernel_ms = ms;
+  }
+  return RL_OK;
+}
+
+int rl_mincurv_sweep(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter,
+                     double* cx, double* cy, double* points, int* n_success, rl_stats* stats) {
+  if (!ctx || !trk || !cx || !cy) return fail(RL_ERR_ARG, "null argument");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = trk->n, N = trk->N;
+  if (int rc = rl_track_set_control_points(trk, cx, cy)) return rc;
+  DevBuf<double> dctrl, dpts;
+  DevBuf<int> dns, dst;
+  RL_HIP(dctrl.alloc((size_t)n * 2)); RL_HIP(dpts.alloc((size_t)N * RL_NCOL));
+  RL_HIP(dns.alloc((size_t)2 * (max_iter > 0 ? max_iter : 1))); RL_HIP(dst.alloc(1));
+  RL_HIP(hipMemsetAsync(dpts.p, 0, dpts.n * sizeof(double), ctx->stream));
+  RL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = solve_batch_common(ctx, trk, RL_BOUNDS_SHARED_RINGS, nullptr, 1, i_start, max_iter,
+                              RL_SEARCH_CULLED, dctrl.p, nullptr, dpts.p, dns.p, dst.p, stats, nullptr);
+  if (rc) return rc;
+  RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  std::vector<double> ctrl((size_t)2 * n);
+  RL_HIP(hipMemcpyAsync(ctrl.data(), dctrl.p, ctrl.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (points) RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (n_success) RL_HIP(hipMemcpyAsync(n_success, dns.p, (size_t)2 * max_iter * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  for (int j = 0; j < n; ++j) { cx[j] = ctrl[2 * j]; cy[j] = ctrl[2 * j + 1]; }
+  if (points) {
+    for (int i = 0; i < N; ++i) { points[(size_t)i * RL_NCOL + 17] = (double)i; points[(size_t)i * RL_NCOL + 18] = -1.0; }
+  }
+  if (stats) {
+    float ms = 0.f;
+    RL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->kernel_ms = ms;
+  }
+  return RL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+"""Functional numpy/torch-facing wrappers of the C ABI (include/rl_mincurv.h).
+
+All arithmetic happens in the HIP kernels of librl_mincurv.so; these functions only marshal
+pointers.  Each wrapper names the reference function it stands in for.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, Stats, Track, as_d, as_i, check
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def spline_eval(t, cx, cy, k, u, der_max=2, device=None):
+    """BSplineTrajectory.eval for der = 0..der_max (models/trajectory.py:247-248).
+    Returns array [(der_max+1)*2, N]: rows x, y, x', y', x'', y''."""
+    ctx = Context.get(device)
+    t, tp = as_d(t); cx, xp = as_d(cx); cy, yp = as_d(cy); u, up = as_d(np.atleast_1d(u))
+    out = np.empty(((der_max + 1) * 2, len(u)))
+    check(ctx.lib.rl_spline_eval(ctx.h, tp, len(t), xp, yp, int(k), up, len(u), int(der_max),
+                                 out.ctypes.data_as(_dp)))
+    return out
+
+
+def sample_along(t, cx, cy, k, length, u, device=None):
+    """BSplineTrajectory.sample_along(ts=u) -> points [N,19] (models/trajectory.py:268-291)."""
+    ctx = Context.get(device)
+    t, tp = as_d(t); cx, xp = as_d(cx); cy, yp = as_d(cy); u, up = as_d(u)
+    pts = np.empty((len(u), _lib.NCOL))
+    check(ctx.lib.rl_sample_along(ctx.h, tp, len(t), xp, yp, int(k), float(length), up, len(u),
+                                  pts.ctypes.data_as(_dp)))
+    return pts
+
+
+def fill_bounds(points, ringL, ringR, max_dist=100.0, device=None):
+    """Trajectory.fill_bounds in place on a C-contiguous [N,19] table (models/trajectory.py:83-141)."""
+    ctx = Context.get(device)
+    assert points.dtype == np.float64 and points.flags.c_contiguous and points.shape[1] == _lib.NCOL
+    ringL, lp = as_d(ringL); ringR, rp = as_d(ringR)
+    check(ctx.lib.rl_fill_bounds(ctx.h, points.ctypes.data_as(_dp), len(points), lp, len(ringL), rp,
+                                 len(ringR), float(max_dist)))
+    return points
+
+
+def mincurv_cost(track, idx, z=None):
+    """TrajectoryOptimizer.min_curvature_cost for several control points at once
+    (optimization/optimizer.py:24-86).  Returns H [n_idx,2,2], g [n_idx,2], M [n_idx]."""
+    ctx = track.ctx
+    idx, ip = as_i(np.atleast_1d(idx))
+    n_idx = len(idx)
+    H = np.zeros((n_idx, 4)); g = np.zeros((n_idx, 2)); M = np.zeros(n_idx, dtype=np.int32)
+    if z is not None:
+        z, zp = as_d(np.asarray(z).reshape(n_idx, 2))
+    else:
+        zp = None
+    check(ctx.lib.rl_mincurv_cost(ctx.h, track.h, ip, n_idx, zp, H.ctypes.data_as(_dp),
+                                  g.ctypes.data_as(_dp), M.ctypes.data_as(_ip)))
+    return H.reshape(n_idx, 2, 2), g, M
+
+
+def track_constraint(track, points, idx):
+    """TrajectoryOptimizer.track_constraint (optimization/optimizer.py:222-254).
+    Returns (A [2M,2], lba [2M], uba [2M]) exactly shaped like the reference's return value."""
+    ctx = track.ctx
+    points, pp = as_d(points)
+    N = track.N
+    assert points.shape == (N, _lib.NCOL)
+    b = np.zeros(N); lba = np.zeros(2 * N); uba = np.zeros(2 * N)
+    M = ctypes.c_int(0)
+    check(ctx.lib.rl_track_constraint(ctx.h, track.h, pp, int(idx), b.ctypes.data_as(_dp),
+                                      lba.ctypes.data_as(_dp), uba.ctypes.data_as(_dp),
+                                      ctypes.byref(M)))
+    m = M.value
+    A = np.zeros((2 * m, 2))
+    A[0::2, 0] = b[:m]
+    A[1::2, 1] = b[:m]
+    return A, lba[:2 * m].copy(), uba[:2 * m].copy()
+
+
+def mincurv_sweep(track, cx, cy, i_start, want_points=True):
+    """TrajectoryOptimizer.run_min_curvature_qp for one instance bounded by the track's shared
+    rings (optimization/optimizer.py:256-341).  Returns (cx, cy, points|None, n_success, stats)."""
+    ctx = track.ctx
+    cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
+    i_start, ip = as_i(i_start)
+    max_iter = len(i_start)
+    pts = np.zeros((track.N, _lib.NCOL)) if want_points else None
+    ns = np.zeros(2 * max_iter, dtype=np.int32)
+    st = Stats()
+    check(ctx.lib.rl_mincurv_sweep(ctx.h, track.h, ip, max_iter, cx.ctypes.data_as(_dp),
+                                   cy.ctypes.data_as(_dp),
+                                   pts.ctypes.data_as(_dp) if want_points else None,
+                                   ns.ctypes.data_as(_ip), ctypes.byref(st)))
+    return cx, cy, pts, ns.reshape(max_iter, 2), st
+
+
+def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_CULLED, B=None):
+    """Batched sweep with host (numpy) buffers.  bounds: widths [B,N,2] / points [B,N,4] / None.
+    Returns (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2], status [B], stats)."""
+    ctx = track.ctx
+    i_start, ip = as_i(i_start)
+    max_iter = len(i_start)
+    if bounds is not None:
+        bounds, bp = as_d(bounds)
+        B = bounds.shape[0]
+        cols = {_lib.BOUNDS_WIDTHS: 2, _lib.BOUNDS_POINTS: 4}[bounds_form]
+        assert bounds.shape == (B, track.N, cols), bounds.shape
+    else:
+        bp = None
+        assert B is not None and bounds_form == _lib.BOUNDS_SHARED_RINGS
+    ctrl = np.zeros((B, track.n, 2)); xy = np.zeros((B, track.N, 2))
+    ns = np.zeros((B, max_iter, 2), dtype=np.int32); status = np.zeros(B, dtype=np.int32)
+    st = Stats()
+    check(ctx.lib.rl_mincurv_solve_batch_host(ctx.h, track.h, int(bounds_form), bp, int(B), ip,
+                                              max_iter, int(search), ctrl.ctypes.data_as(_dp),
+                                              xy.ctypes.data_as(_dp), ns.ctypes.data_as(_ip),
+                                              status.ctypes.data_as(_ip), ctypes.byref(st)))
+    return ctrl, xy, ns, status, st
+
+
+def solve_batch_torch(track, bounds_form, bounds, i_start, search=_lib.SEARCH_CULLED, out=None):
+    """Batched sweep on DEVICE tensors (torch is plumbing for memory and streams only).
+    bounds: float64 cuda tensor [B,N,2|4].  Enqueues on torch's current stream, no sync.
+    Returns dict(ctrl, xy, n_success, status) of cuda tensors."""
+    import torch
+    ctx = track.ctx
+    assert bounds.is_cuda and bounds.dtype == torch.float64 and bounds.is_contiguous()
+    B = bounds.shape[0]
+    cols = {_lib.BOUNDS_WIDTHS: 2, _lib.BOUNDS_POINTS: 4}[bounds_form]
+    assert tuple(bounds.shape) == (B, track.N, cols)
+    i_start, ip = as_i(i_start)
+    max_iter = len(i_start)
+    dev = bounds.device
+    if out is None:
+        out = {
+            "ctrl": torch.empty((B, track.n, 2), dtype=torch.float64, device=dev),
+            "xy": torch.empty((B, track.N, 2), dtype=torch.float64, device=dev),
+            "n_success": torch.empty((B, max_iter, 2), dtype=torch.int32, device=dev),
+            "status": torch.empty((B,), dtype=torch.int32, device=dev),
+        }
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    st = Stats()
+    check(ctx.lib.rl_mincurv_solve_batch_dev(
+        ctx.h, track.h, int(bounds_form), ctypes.c_void_p(bounds.data_ptr()), int(B), ip, max_iter,
+        int(search), ctypes.c_void_p(out["ctrl"].data_ptr()), ctypes.c_void_p(out["xy"].data_ptr()),
+        ctypes.c_void_p(out["n_success"].data_ptr()), ctypes.c_void_p(out["status"].data_ptr()),
+        ctypes.byref(st)))
+    out["stats"] = st
+    return out

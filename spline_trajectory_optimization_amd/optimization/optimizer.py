@@ -1,0 +1,149 @@
+"""Host-side mirror of `spline_traj_optm.optimization.optimizer.TrajectoryOptimizer`
+(optimization/optimizer.py:15-341): same constructor, the same six methods with the same argument
+order, defaults and return types.  All arithmetic runs in HIP kernels behind the C ABI
+(include/rl_mincurv.h); casadi/qpOASES and shapely are not needed.
+
+Differences from the reference, all additive and keyword-only:
+  * `i_start=` pins the sweep start indices the reference draws with an UNSEEDED
+    np.random.randint (optimizer.py:303).  Without it the same np.random.randint calls are made,
+    in the same order, so `np.random.seed(s)` reproduces the reference's order.
+  * the per-iteration `Simulator.run_simulation` calls (optimizer.py:333-339) never feed back
+    into the returned spline (they only rewrite SPEED/ACC/TIME columns of a table that is
+    discarded); they are skipped unless `simulate=True`.
+  * the matplotlib visualiser (optimizer.py:261, 331-340) is not constructed.
+"""
+import numpy as np
+
+from .. import _lib, ops
+from ..models.race_track import RaceTrack
+from ..models.trajectory import BSplineTrajectory, Trajectory, _ring_coords
+from ..models.vehicle import Vehicle
+from ..simulator.simulator import Simulator
+
+
+class TrajectoryOptimizer:
+    def __init__(self, race_track: RaceTrack, center_line: BSplineTrajectory, vehicle: Vehicle) -> None:
+        self.track = race_track
+        self.left_bound = race_track.left_s
+        self.right_bound = race_track.right_s
+        self.center_line = center_line
+        self.vehicle = vehicle
+        self.sim = Simulator(self.vehicle)
+        self._trk_cache = {}
+
+    # ---- device tables for (knots, degree, N); control points are refreshed on every call
+    def _device_track(self, traj_s: BSplineTrajectory, N: int):
+        t, cx, cy, k = traj_s._tck()
+        key = (t.tobytes(), k, int(N))
+        trk = self._trk_cache.get(key)
+        if trk is None:
+            trk = _lib.Track(_lib.Context.get(), t, cx, cy, k, N)
+            if len(self._trk_cache) > 8:
+                self._trk_cache.clear()
+            self._trk_cache[key] = trk
+        else:
+            trk.set_control_points(cx, cy)
+        return trk
+
+    def min_curvature_cost(self, z: np.ndarray, idx: int, traj_s: BSplineTrajectory, traj_d: Trajectory):
+        """optimizer.py:24-86 -> k_cost.  Returns H (2x2), g (2)."""
+        trk = self._device_track(traj_s, len(traj_d))
+        H, g, _ = ops.mincurv_cost(trk, [idx], z=np.asarray(z, dtype=np.float64).reshape(1, 2))
+        return H[0], g[0]
+
+    def joint_min_curvature_cost(self, traj_s: BSplineTrajectory, traj_d: Trajectory, start_idx=None, span=None):
+        """optimizer.py:88-110: the 2x2 blocks of the window's control points on the diagonal."""
+        num_ctrl_pt = len(traj_s._spl_x.c)
+        ignore_front = traj_s._spl_x.k // 2
+        ignore_rear = traj_s._spl_x.k - ignore_front
+        if start_idx is None:
+            i_min, i_max = ignore_front, num_ctrl_pt - ignore_rear
+        else:
+            i_min, i_max = start_idx, start_idx + span
+        nw = i_max - i_min
+        trk = self._device_track(traj_s, len(traj_d))
+        H, g, _ = ops.mincurv_cost(trk, np.arange(i_min, i_max))  # z = current control points
+        joint_H = np.zeros((nw * 2, nw * 2), np.float64)
+        joint_g = np.zeros(nw * 2, np.float64)
+        for j in range(nw):
+            joint_H[2 * j:2 * j + 2, 2 * j:2 * j + 2] = H[j]
+            joint_g[2 * j:2 * j + 2] = g[j]
+        return joint_H, joint_g
+
+    def track_constraint(self, idx: int, traj_s: BSplineTrajectory, traj_d: Trajectory):
+        """optimizer.py:222-254 -> k_constraint.  Returns A (2M x 2), lba (2M), uba (2M)."""
+        trk = self._device_track(traj_s, len(traj_d))
+        return ops.track_constraint(trk, traj_d.points, idx)
+
+    def joint_track_constraint(self, traj_s: BSplineTrajectory, traj_d: Trajectory, start_idx=None, span=None):
+        """optimizer.py:112-161: dense A over ALL samples for the window's control points."""
+        num_ctrl_pt = len(traj_s._spl_x.c)
+        k = traj_s._spl_x.k
+        ignore_front = k // 2
+        ignore_rear = k - ignore_front
+        if start_idx is None:
+            i_min, i_max = ignore_front, num_ctrl_pt - ignore_rear
+        else:
+            i_min, i_max = start_idx, start_idx + span
+        nw = i_max - i_min
+        M = len(traj_d)
+        ts = traj_d.ts()
+        trk = self._device_track(traj_s, M)
+        joint_A = np.zeros((2 * M, 2 * nw), dtype=np.float64)
+        z = np.zeros(nw * 2, np.float64)
+        for i in range(i_min, i_max):
+            j = i - i_min
+            A, _, _ = ops.track_constraint(trk, traj_d.points, i)
+            t_mask = (ts >= traj_s._spl_x.t[i]) & (ts < traj_s._spl_x.t[i + k + 1])
+            s0 = int(np.argmax(t_mask)) if t_mask.any() else 0
+            m = len(A) // 2
+            joint_A[2 * s0:2 * (s0 + m):2, 2 * j] = A[0::2, 0]
+            joint_A[2 * s0 + 1:2 * (s0 + m):2, 2 * j + 1] = A[1::2, 1]
+            z[2 * j:2 * j + 2] = np.array(traj_s.get_control_point(i))
+        non_z = traj_d[:, :2] - (joint_A @ z).reshape((-1, 2))
+        left_x = traj_d[:, Trajectory.LEFT_BOUND_X]; left_y = traj_d[:, Trajectory.LEFT_BOUND_Y]
+        right_x = traj_d[:, Trajectory.RIGHT_BOUND_X]; right_y = traj_d[:, Trajectory.RIGHT_BOUND_Y]
+        min_bound = np.empty(2 * M, dtype=np.float64)
+        max_bound = np.empty(2 * M, dtype=np.float64)
+        min_bound[0::2] = np.minimum(left_x, right_x) - non_z[:, 0]
+        min_bound[1::2] = np.minimum(left_y, right_y) - non_z[:, 1]
+        max_bound[0::2] = np.maximum(left_x, right_x) - non_z[:, 0]
+        max_bound[1::2] = np.maximum(left_y, right_y) - non_z[:, 1]
+        return joint_A, min_bound, max_bound
+
+    def run_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, visualize=False,
+                             max_iter=5, *, i_start=None, simulate=False):
+        """optimizer.py:256-341 -> ONE launch of the LDS-resident sweep kernel (k_sweep)."""
+        traj_out_s = traj_in_s.copy()
+        n = len(traj_out_s._spl_x.c)
+        k = traj_out_s._spl_x.k
+        i_min, i_max = k // 2, n - (k - k // 2)
+        if i_start is None:
+            i_start = []
+            for _ in range(max_iter):
+                i_start.append(int(np.random.randint(i_min, i_max)))  # optimizer.py:303
+                print(f'Starting from {i_start[-1]}-th control point.')
+        i_start = np.asarray(i_start, dtype=np.int32)
+        assert len(i_start) == max_iter
+        trk = self._device_track(traj_out_s, len(traj_in_d))
+        trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
+        t, cx, cy, _ = traj_out_s._tck()
+        cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start, want_points=True)
+        traj_out_s._spl_x.c[:] = cx
+        traj_out_s._spl_y.c[:] = cy
+        for j in range(max_iter):
+            print(f"Forward pass: number of control points successfully updated: {ns[j, 0]}")
+            print(f"Backward pass: number of control points successfully updated: {ns[j, 1]}")
+        self.last_n_success = ns
+        self.last_stats = stats
+        if simulate:
+            traj_out_d = traj_out_s.sample_along(ts=traj_in_d.ts())
+            traj_out_d[:, Trajectory.LEFT_BOUND_X:Trajectory.RIGHT_BOUND_Y + 1] = pts[:, 9:13]
+            print(self.sim.run_simulation(traj_out_d, enable_vis=False))
+        return traj_out_s
+
+    def run_joint_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, max_iter=3,
+                                   visualize=False):
+        """optimizer.py:163-220 (sliding window, span 5).  Has no caller in the reference tree;
+        the 10-variable window QP kernel is the next row of the build plan."""
+        raise NotImplementedError("run_joint_min_curvature_qp: window-QP kernel not built yet")

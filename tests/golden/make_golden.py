@@ -112,7 +112,7 @@ def exact_separable_qp(H, g, A, lba, uba):
 
 # --------------------------------------------------------------------------- helpers
 def load_xy(name):
-    return np.loadtxt(os.path.join(HERE, "monza", name), dtype=np.float64, delimiter=",",
+    return np.loadtxt(os.path.join(ROOT, "spline_trajectory_optimization_amd", "examples", "race_track", "monza", name), dtype=np.float64, delimiter=",",
                       skiprows=1, usecols=(0, 1))
 
 
