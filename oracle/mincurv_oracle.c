@@ -362,14 +362,28 @@ int orc_track_constraint(int idx, const double* t, int nt, const double* cx, con
   return M;
 }
 
+/* Conditioning indicator (test diagnostics only).  The reference forms each row as
+ * lba_i = min(L,R)_i - (p_i - b_i z_old)  (optimizer.py:236-248), so the bound it implies on z,
+ * lba_i / b_i, carries the rounding noise of the O(1e3) coordinates divided by b_i.  Rows at the
+ * edge of a basis function's support have b_i down to 1e-11: when such a row is the binding one
+ * (its sample sits on its own box edge, e.g. after an earlier clamp pushed it onto the ring) the
+ * clamp -- or the feasible/infeasible decision -- is decided by rounding noise, in the reference as
+ * much as here.  kappa = largest noise radius [m] among the rows that decided an outcome. */
+static _Thread_local double g_kappa = 0.0;
+static _Thread_local double g_coord_scale = 2048.0;
+double orc_last_kappa(void) { return g_kappa; }
+void orc_reset_kappa(void) { g_kappa = 0.0; }
+
 int orc_qp_solve_separable(const double H[4], const double g[2], const double* A,
                            const double* lba, const double* uba, int M, double x[2]) {
   /* per coordinate c: minimise 1/2 H_cc z^2 + g_c z over the interval cut out by the rows
    * a_i z in [lba_i, uba_i]; rows with a_i == 0 only decide feasibility. */
+  const double eps = 8.0 * 2.220446049250313e-16 * g_coord_scale;
   for (int c = 0; c < 2; ++c) {
     double h = H[3 * c], gc = g[c];
     if (!(h > 0.0) || !isfinite(h) || !isfinite(gc)) return 3;
     double lo = -INFINITY, hi = INFINITY;
+    double a_lo = 1.0, a_hi = 1.0;
     for (int i = 0; i < M; ++i) {
       int r = 2 * i + c;
       double a = A[2 * r + c];
@@ -377,8 +391,8 @@ int orc_qp_solve_separable(const double H[4], const double g[2], const double* A
       if (!isfinite(a) || l != l || u != u) return 3;
       if (a > 0.0) {
         double ql = l / a, qu = u / a;
-        if (ql > lo) lo = ql;
-        if (qu < hi) hi = qu;
+        if (ql > lo) { lo = ql; a_lo = a; }
+        if (qu < hi) { hi = qu; a_hi = a; }
       } else if (a < 0.0) {
         double ql = u / a, qu = l / a;
         if (ql > lo) lo = ql;
@@ -387,10 +401,12 @@ int orc_qp_solve_separable(const double H[4], const double g[2], const double* A
         if (l > 0.0 || u < 0.0) return 2;
       }
     }
+    const double r_lo = eps / a_lo, r_hi = eps / a_hi;
+    if (fabs(hi - lo) < r_lo + r_hi) g_kappa = INFINITY; /* feasibility decided by noise */
     if (lo > hi) return 2;
     double z = -gc / h;
-    if (z < lo) z = lo;
-    if (z > hi) z = hi;
+    if (z < lo) { z = lo; if (r_lo > g_kappa) g_kappa = r_lo; }
+    if (z > hi) { z = hi; if (r_hi > g_kappa) g_kappa = r_hi; }
     x[c] = z;
   }
   return 0;
@@ -481,7 +497,8 @@ void orc_run_min_curvature_qp(const double* t, int nt, double* cx, double* cy, i
 void orc_solve_width_batch(const double* t, int nt, const double* cx0, const double* cy0, int k,
                            double length, int N, const double* widths, int B,
                            const int* i_start, int max_iter,
-                           double* out_ctrl, double* out_xy, int* n_success, int nthreads) {
+                           double* out_ctrl, double* out_xy, int* n_success, int nthreads,
+                           double* kappa) {
   int n = nt - k - 1;
   /* shared initial line: p0_i, yaw0_i */
   double* base = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
@@ -510,8 +527,10 @@ void orc_solve_width_batch(const double* t, int nt, const double* cx0, const dou
     }
     double* pts = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
     orc_trajectory_init(pts, N);
+    orc_reset_kappa();
     orc_run_min_curvature_qp(t, nt, cx, cy, k, length, pts, N, ringL, N, ringR, N, i_start,
                              max_iter, n_success + (size_t)b * 2 * max_iter);
+    if (kappa) kappa[b] = orc_last_kappa();
     for (int j = 0; j < n; ++j) {
       out_ctrl[((size_t)b * n + j) * 2] = cx[j];
       out_ctrl[((size_t)b * n + j) * 2 + 1] = cy[j];

@@ -100,7 +100,15 @@ void orc_run_min_curvature_qp(const double* t, int nt, double* cx, double* cy, i
 void orc_solve_width_batch(const double* t, int nt, const double* cx0, const double* cy0, int k,
                            double length, int N, const double* widths, int B,
                            const int* i_start, int max_iter,
-                           double* out_ctrl, double* out_xy, int* n_success, int nthreads);
+                           double* out_ctrl, double* out_xy, int* n_success, int nthreads,
+                           double* kappa /* [B] conditioning indicator per instance, may be NULL */);
+
+/* Conditioning indicator of the sweeps run on this thread since orc_reset_kappa(): the largest
+ * rounding-noise radius [m] of a constraint row that decided a clamp (inf = a feasible/infeasible
+ * decision was within noise).  Diagnostics for the parity tests: the reference's own row
+ * formulation (optimizer.py:236-248) is noise-dominated when kappa is large. */
+double orc_last_kappa(void);
+void orc_reset_kappa(void);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,8 @@ def lib():
             _dp, ctypes.c_int, _dp, ctypes.c_int, _ip, ctypes.c_int, _ip]
         _lib.orc_solve_width_batch.argtypes = [
             _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp,
-            ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _ip, ctypes.c_int]
+            ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _ip, ctypes.c_int, _dp]
+        _lib.orc_last_kappa.restype = ctypes.c_double
         _lib.orc_fill_bounds.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int,
                                          ctypes.c_double]
     return _lib
@@ -138,14 +139,21 @@ def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_ite
     pts = np.zeros((N, NCOL))
     lib().orc_trajectory_init(pts.ctypes.data_as(_dp), N)
     ns = np.zeros(2 * max_iter, dtype=np.int32)
+    lib().orc_reset_kappa()
     lib().orc_run_min_curvature_qp(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k),
                                    float(length), pts.ctypes.data_as(_dp), int(N), lp, len(ringL),
                                    rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
     return cx, cy, pts, ns.reshape(max_iter, 2)
 
 
-def solve_width_batch(t, cx0, cy0, k, length, N, widths, i_start, max_iter=None, nthreads=1):
-    """widths [B,N,2] -> (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2])."""
+def last_kappa():
+    """Conditioning indicator of the last run_min_curvature_qp on this thread (see the header)."""
+    return lib().orc_last_kappa()
+
+
+def solve_width_batch(t, cx0, cy0, k, length, N, widths, i_start, max_iter=None, nthreads=1,
+                      want_kappa=False):
+    """widths [B,N,2] -> (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2][, kappa [B]])."""
     t, tp = _d(t); cx0, xp = _d(cx0); cy0, yp = _d(cy0); widths, wp = _d(widths)
     i_start, ip = _i(i_start)
     max_iter = len(i_start) if max_iter is None else max_iter
@@ -153,7 +161,10 @@ def solve_width_batch(t, cx0, cy0, k, length, N, widths, i_start, max_iter=None,
     n = len(t) - k - 1
     ctrl = np.zeros((B, n, 2)); xy = np.zeros((B, N, 2))
     ns = np.zeros((B, max_iter, 2), dtype=np.int32)
+    kappa = np.zeros(B)
     lib().orc_solve_width_batch(tp, len(t), xp, yp, int(k), float(length), int(N), wp, B, ip,
                                 int(max_iter), ctrl.ctypes.data_as(_dp), xy.ctypes.data_as(_dp),
-                                ns.ctypes.data_as(_ip), int(nthreads))
+                                ns.ctypes.data_as(_ip), int(nthreads), kappa.ctypes.data_as(_dp))
+    if want_kappa:
+        return ctrl, xy, ns, kappa
     return ctrl, xy, ns
