@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
-    ap.add_argument("--search", choices=["culled", "brute"], default="culled")
+    ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-instances", type=int, default=8)
     args = ap.parse_args()
@@ -97,7 +97,7 @@ def main():
     i_start = batch.default_i_start(n, k, MAX_ITER, seed=0)
     trk = _lib.Track(ctx, t, cx, cy, k, N_WAYPOINTS)
     d_widths = torch.from_numpy(widths).to(dev)
-    search = _lib.SEARCH_CULLED if args.search == "culled" else _lib.SEARCH_BRUTE
+    search = {"windowed": _lib.SEARCH_WINDOWED, "culled": _lib.SEARCH_CULLED, "brute": _lib.SEARCH_BRUTE}[args.search]
     out = ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search)
     torch.cuda.synchronize()
     stats = out["stats"]

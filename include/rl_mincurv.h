@@ -43,7 +43,10 @@ enum {
   RL_BOUNDS_POINTS = 2        /* in[B,N,4] = (LBX,LBY,RBX,RBY): ring vertices given directly           */
 };
 
-enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1 };
+/* boundary re-intersection strategy; all three return bit-identical results (tests):
+ * brute = every edge; culled = per-lane chunk-circle culling; windowed = hinted window + wave-wide
+ * chunk-circle guard (the fast one) */
+enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1, RL_SEARCH_WINDOWED = 2 };
 
 typedef struct rl_stats {
   float kernel_ms;       /* duration of the sweep kernel of the last *_host call (hipEvent)  */

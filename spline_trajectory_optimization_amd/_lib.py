@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "librl_mincurv.so")
 NCOL = 19
 MAX_ITER = 32
 BOUNDS_SHARED_RINGS, BOUNDS_WIDTHS, BOUNDS_POINTS = 0, 1, 2
-SEARCH_BRUTE, SEARCH_CULLED = 0, 1
+SEARCH_BRUTE, SEARCH_CULLED, SEARCH_WINDOWED = 0, 1, 2
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)

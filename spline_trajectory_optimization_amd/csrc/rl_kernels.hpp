@@ -174,8 +174,9 @@ __global__ void k_fill_bounds(double* __restrict__ points, int N, const double2*
   const double px = p[0], py = p[1];
   const double yaw_norm = p[3] + (side == 0 ? M_PI / 2.0 : -M_PI / 2.0);
   const double dx = max_dist * cos(yaw_norm), dy = max_dist * sin(yaw_norm);
-  const double s = side == 0 ? search_ring_brute(ringL, nL, px, py, dx, dy)
-                             : search_ring_brute(ringR, nR, px, py, dx, dy);
+  const Hit h = side == 0 ? search_ring_brute(ringL, nL, px, py, dx, dy)
+                          : search_ring_brute(ringR, nR, px, py, dx, dy);
+  const double s = h.best_s;  // 0 when there is no crossing: the waypoint itself (trajectory.py:127)
   p[9 + 2 * side] = px + s * dx;
   p[10 + 2 * side] = py + s * dy;
 }
@@ -291,7 +292,7 @@ struct SweepArgs {
 // LDS carve (doubles).  cpad = n rounded up to even so every later array is 16-byte aligned.
 struct SweepLds {
   int cpad, nLp, nRp, ncL, ncR;
-  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, total;
+  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_hint, total;
 };
 
 __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds) {
@@ -306,6 +307,7 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   L.off_red = o; o += 16 * 12;           // up to 16 waves x 12 partials
   L.off_cL = o; o += (size_t)((3 * L.ncL + 1) & ~1);
   L.off_cR = o; o += (size_t)((3 * L.ncR + 1) & ~1);
+  L.off_hint = o; o += (size_t)(((size_t)2 * ((N + 3) & ~3) * sizeof(unsigned short) + 15) / 16) * 2;  // u16 [2][Npad]
   if (rings_in_lds) {
     L.off_sL = o; o += (size_t)((N + 1) & ~1);
     L.off_sR = o; o += (size_t)((N + 1) & ~1);
@@ -334,6 +336,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   double* red = smem + L.off_red;
   double* circL = smem + L.off_cL;
   double* circR = smem + L.off_cR;
+  unsigned short* hints = reinterpret_cast<unsigned short*>(smem + L.off_hint);  // [2][Npad]
+  const int Npad = (N + 3) & ~3;
   double* sL; double* sR; double2* rL; double2* rR;
   if (RINGS_LDS) {
     sL = smem + L.off_sL; sR = smem + L.off_sR;
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     for (int i = tid; i < nR; i += BLOCK) rR[i] = a.ringR[i];
   }
   __syncthreads();
-  if (a.search == 1) {
+  if (a.search >= 1) {
     for (int c = tid; c < L.ncL + L.ncR; c += BLOCK) {
       const bool left = c < L.ncL;
       const int cc = left ? c : c - L.ncL;
@@ -396,10 +400,34 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     __syncthreads();
   }
 
-  // refresh(i0,i1): new p, normal and closest ring crossings for samples [i0,i1)
-  auto refresh = [&](int i0, int i1, int j0, int j1) {
-    // tasks: (sample, ring) pairs of two sample ranges; a wave mostly works on one ring
+  // refresh(i0,i1,j0,j1): new p, normal and closest ring crossings for the samples of two ranges
+  auto refresh = [&](int i0, int i1, int j0, int j1, int mode) {
     const int m0 = i1 - i0, m1 = j1 - j0, m = m0 + m1;
+    if (mode == 2) {
+      // windowed, wave-cooperative search: a wave takes 64 consecutive samples of ONE ring
+      const int nwt = (m + kWave - 1) / kWave;
+      for (int wt = wave; wt < 2 * nwt; wt += NW) {
+        const int side = wt >= nwt;
+        const int r = ((side ? wt - nwt : wt) * kWave) + lane;
+        const bool active = r < m;
+        const int i = active ? (r < m0 ? i0 + r : j0 + (r - m0)) : (m0 > 0 ? i0 : j0);
+        const int l = tr.ell[i];
+        CurvePoint<K, 1> c;
+        eval_sample<K, 1>(tr, cx, cy, i, l, c);
+        const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
+        double dx = -c.dy * inv, dy = c.dx * inv;  // max_dist * (cos, sin)(yaw + pi/2)
+        if (side) { dx = -dx; dy = -dy; }          // yaw - pi/2
+        const int hint = hints[side * Npad + i];
+        const Hit h = side ? search_ring_windowed(rR, nR, circR, L.ncR, active, hint, c.x, c.y, dx, dy, a.max_dist)
+                           : search_ring_windowed(rL, nL, circL, L.ncL, active, hint, c.x, c.y, dx, dy, a.max_dist);
+        if (active) {
+          (side ? sR : sL)[i] = h.best_s;
+          hints[side * Npad + i] = (unsigned short)(h.edge == kNoEdge ? 0xFFFF : h.edge);
+        }
+      }
+      return;
+    }
+    // per-lane searches: (sample, ring) pairs; a wave mostly works on one ring
     for (int task = tid; task < 2 * m; task += BLOCK) {
       const int side = task >= m;
       const int r = side ? task - m : task;
@@ -410,19 +438,30 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
       const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
       double dx = -c.dy * inv, dy = c.dx * inv;  // max_dist * (cos, sin)(yaw + pi/2)
       if (side) { dx = -dx; dy = -dy; }          // yaw - pi/2
-      double s;
-      if (a.search == 1) {
-        s = side ? search_ring_culled(rR, nR, circR, L.ncR, c.x, c.y, dx, dy, a.max_dist)
+      Hit h;
+      if (mode == 1) {
+        h = side ? search_ring_culled(rR, nR, circR, L.ncR, c.x, c.y, dx, dy, a.max_dist)
                  : search_ring_culled(rL, nL, circL, L.ncL, c.x, c.y, dx, dy, a.max_dist);
       } else {
-        s = side ? search_ring_brute(rR, nR, c.x, c.y, dx, dy)
+        h = side ? search_ring_brute(rR, nR, c.x, c.y, dx, dy)
                  : search_ring_brute(rL, nL, c.x, c.y, dx, dy);
       }
-      (side ? sR : sL)[i] = s;
+      (side ? sR : sL)[i] = h.best_s;
+      hints[side * Npad + i] = (unsigned short)(h.edge == kNoEdge ? 0xFFFF : h.edge);
     }
   };
 
-  refresh(0, N, 0, 0);  // optimizer.py:259
+  // the windowed mode needs rings longer than its window and edge indices that fit 16 bits
+  const int mode = (a.search == 2 && nL > 2 * kWin + 1 && nR > 2 * kWin + 1 && nL < 0xFFFF && nR < 0xFFFF) ? 2
+                   : (a.search >= 1 ? 1 : 0);
+  if (mode == 2 && a.form != 0) {
+    // rings built from per-sample widths / bound points: vertex i sits on sample i's normal
+    for (int i = tid; i < 2 * Npad; i += BLOCK) hints[i] = (unsigned short)(i >= Npad ? i - Npad : i);
+    __syncthreads();
+    refresh(0, N, 0, 0, 2);  // optimizer.py:259
+  } else {
+    refresh(0, N, 0, 0, mode == 2 ? 1 : mode);  // first fill also seeds the hints
+  }
   __syncthreads();
 
   const int ignore_front = K / 2, ignore_rear = K - ignore_front;  // optimizer.py:297-302
@@ -521,7 +560,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           else if (idx >= n - 5 && idx <= n - 4) alias = idx - (n - 5);
           int j0 = 0, j1 = 0;
           if (alias >= 0) { j0 = tr.sup[2 * alias]; j1 = tr.sup[2 * alias + 1]; }
-          refresh(s0, s1, j0, j1);
+          refresh(s0, s1, j0, j1, mode);
           __syncthreads();
           ++ok_count;
         } else {

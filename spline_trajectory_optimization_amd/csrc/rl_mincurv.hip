@@ -435,7 +435,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   if (!out_xy && !out_points) return fail(RL_ERR_ARG, "need out_xy or out_points");
   if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
   if (max_iter <= 0 || max_iter > RL_MAX_ITER) return fail(RL_ERR_ARG, "max_iter out of range");
-  if (search != RL_SEARCH_BRUTE && search != RL_SEARCH_CULLED) return fail(RL_ERR_ARG, "bad search mode");
+  if (search < RL_SEARCH_BRUTE || search > RL_SEARCH_WINDOWED) return fail(RL_ERR_ARG, "bad search mode");
   const int n = trk->n, N = trk->N, k = trk->k;
   const int i_min = k / 2, i_max = n - (k - k / 2);
   for (int j = 0; j < max_iter; ++j)
@@ -540,7 +540,7 @@ int rl_mincurv_sweep(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_ite
   RL_HIP(hipMemsetAsync(dpts.p, 0, dpts.n * sizeof(double), ctx->stream));
   RL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   int rc = solve_batch_common(ctx, trk, RL_BOUNDS_SHARED_RINGS, nullptr, 1, i_start, max_iter,
-                              RL_SEARCH_CULLED, dctrl.p, nullptr, dpts.p, dns.p, dst.p, stats, nullptr);
+                              RL_SEARCH_WINDOWED, dctrl.p, nullptr, dpts.p, dns.p, dst.p, stats, nullptr);
   if (rc) return rc;
   RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   std::vector<double> ctrl((size_t)2 * n);

@@ -97,7 +97,7 @@ def mincurv_sweep(track, cx, cy, i_start, want_points=True):
     return cx, cy, pts, ns.reshape(max_iter, 2), st
 
 
-def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_CULLED, B=None):
+def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WINDOWED, B=None):
     """Batched sweep with host (numpy) buffers.  bounds: widths [B,N,2] / points [B,N,4] / None.
     Returns (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2], status [B], stats)."""
     ctx = track.ctx
@@ -121,7 +121,7 @@ def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_CUL
     return ctrl, xy, ns, status, st
 
 
-def solve_batch_torch(track, bounds_form, bounds, i_start, search=_lib.SEARCH_CULLED, out=None):
+def solve_batch_torch(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WINDOWED, out=None):
     """Batched sweep on DEVICE tensors (torch is plumbing for memory and streams only).
     bounds: float64 cuda tensor [B,N,2|4].  Enqueues on torch's current stream, no sync.
     Returns dict(ctrl, xy, n_success, status) of cuda tensors."""

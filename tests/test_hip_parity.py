@@ -219,7 +219,7 @@ def monza_like_widths(rl, fits, rings, tag, N, B, seed):
     return rl.batch.width_batch(wl, wr, B, seed=seed)
 
 
-@pytest.mark.parametrize("search", [0, 1])
+@pytest.mark.parametrize("search", [0, 1, 2])
 @pytest.mark.parametrize("tag,N,B,max_iter", [("c100", 200, 24, 2), ("c30", 333, 16, 1), ("c100", 500, 16, 2)])
 def test_batch_widths_vs_oracle(rl, fits, rings, tag, N, B, max_iter, search):
     """BASELINE config 2 in small: width-perturbed Monza instances, HIP batch vs oracle batch."""
@@ -234,16 +234,24 @@ def test_batch_widths_vs_oracle(rl, fits, rings, tag, N, B, max_iter, search):
     np.testing.assert_array_equal(status, steps - ns.reshape(B, -1).sum(axis=1))
 
 
-def test_search_modes_bitwise_equal(rl, fits):
+def test_search_modes_bitwise_equal(rl, fits, rings):
+    """brute force, per-lane culling and the windowed wave-cooperative search are all exact:
+    identical results bit for bit, on width-form rings and on the shared Monza rings."""
     t, cx, cy, k, length = spline(fits, "c100")
     N, B = 400, 6
-    widths = rl.batch.width_batch(np.full(N, 5.0), np.full(N, 4.5), B, seed=9)
+    widths = monza_like_widths(rl, fits, rings, "c100", N, B, seed=9)
+    widths[1] = 9.0        # very wide: offset rings self-intersect at the chicanes
+    widths[2, :, 0] = 1.0  # very narrow left side
     i_start = rl.batch.default_i_start(len(cx), k, 2, seed=1)
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
-    a = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=0)
-    b = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=1)
-    np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
-    np.testing.assert_array_equal(a[2], b[2])
+    res = [rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=m) for m in (0, 1, 2)]
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][0], r[0]); np.testing.assert_array_equal(res[0][1], r[1])
+        np.testing.assert_array_equal(res[0][2], r[2])
+    trk.set_rings(rings[0], rings[1])
+    res = [rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_SHARED_RINGS, None, i_start, search=m, B=2) for m in (0, 1, 2)]
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][0], r[0]); np.testing.assert_array_equal(res[0][2], r[2])
 
 
 def test_bound_points_form_matches_widths_form(rl, fits):
