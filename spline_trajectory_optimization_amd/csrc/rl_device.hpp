@@ -115,7 +115,11 @@ __device__ __forceinline__ double edge_side(double vx, double vy, double dx, dou
 
 __device__ __forceinline__ void edge_hit(double ax, double ay, double ea, double bx, double by,
                                          double eb, double dx, double dy, int edge, Hit& h) {
-  if ((ea > 0.0 && eb > 0.0) || (ea < 0.0 && eb < 0.0)) return;  // edge on one side of the line
+  // edge strictly on one side of the line <=> ea, eb non-zero with equal signs.  One multiply
+  // decides it; a zero product with two non-zero factors (underflow) is re-checked exactly.
+  const double prod = ea * eb;
+  if (prod > 0.0) return;
+  if (prod == 0.0 && ea != 0.0 && eb != 0.0 && ((ea > 0.0) == (eb > 0.0))) return;
   const double sx = bx - ax, sy = by - ay;
   const double den = dx * sy - dy * sx;
   if (den == 0.0) return;  // parallel / collinear: not a Point intersection
@@ -141,6 +145,49 @@ __device__ __forceinline__ void scan_edges(RingPtr ring, int nr, int j0, int cou
     edge_hit(ax, ay, ea, bx, by, eb, dx, dy, j, h);
     ax = bx; ay = by; ea = eb;
     j = j1;
+  }
+}
+
+// Same scan with the vertex loads issued BATCH at a time ahead of the arithmetic: with one wave per
+// SIMD nothing else hides the LDS latency, so the loads of a batch share one wait.
+template <int BATCH, typename RingPtr>
+__device__ __forceinline__ void scan_edges_batched(RingPtr ring, int nr, int j0, int count, double px,
+                                                   double py, double dx, double dy, Hit& h) {
+  int j = j0;
+  double2 v = ring[j];
+  double ax = v.x - px, ay = v.y - py;
+  double ea = edge_side(ax, ay, dx, dy);
+  int q = 0;
+  for (; q + BATCH <= count; q += BATCH) {
+    double2 w[BATCH];
+    int jj[BATCH];
+    int t = j;
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      t = (t + 1 == nr) ? 0 : t + 1;
+      jj[u] = t;
+      w[u] = ring[t];
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const double bx = w[u].x - px, by = w[u].y - py;
+      const double eb = edge_side(bx, by, dx, dy);
+      edge_hit(ax, ay, ea, bx, by, eb, dx, dy, u == 0 ? j : jj[u - 1], h);
+      ax = bx; ay = by; ea = eb;
+    }
+    j = jj[BATCH - 1];
+  }
+  if (q < count) {
+    // tail: re-derive the state for the plain loop (the current vertex is j)
+    for (; q < count; ++q) {
+      const int j1 = (j + 1 == nr) ? 0 : j + 1;
+      v = ring[j1];
+      const double bx = v.x - px, by = v.y - py;
+      const double eb = edge_side(bx, by, dx, dy);
+      edge_hit(ax, ay, ea, bx, by, eb, dx, dy, j, h);
+      ax = bx; ay = by; ea = eb;
+      j = j1;
+    }
   }
 }
 
@@ -177,54 +224,116 @@ __device__ __forceinline__ Hit search_ring_culled(RingPtr ring, int nr, CirclePt
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave64 reductions
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-  return v;
+// wave64 reductions on the DPP path (no LDS crossbar traffic): an inclusive row scan with
+// row_shr 1/2/4/8, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 leaves the total
+// in lane 63; v_readlane broadcasts it as a wave-uniform (SGPR) value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double identity, double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(identity), lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));
-  return v;
+struct OpSum { static __device__ __forceinline__ double id() { return 0.0; }
+               static __device__ __forceinline__ double f(double a, double b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ double id() { return -INFINITY; }
+               static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); } };
+struct OpMin { static __device__ __forceinline__ double id() { return INFINITY; }
+               static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); } };
+
+template <typename Op>
+__device__ __forceinline__ double wave_reduce(double v) {
+  const double e = Op::id();
+  v = Op::f(v, dpp_mov<0x111, 0xf>(e, v));  // row_shr:1
+  v = Op::f(v, dpp_mov<0x112, 0xf>(e, v));  // row_shr:2
+  v = Op::f(v, dpp_mov<0x114, 0xf>(e, v));  // row_shr:4
+  v = Op::f(v, dpp_mov<0x118, 0xf>(e, v));  // row_shr:8
+  v = Op::f(v, dpp_mov<0x142, 0xa>(e, v));  // row_bcast:15 -> rows 1 and 3
+  v = Op::f(v, dpp_mov<0x143, 0xc>(e, v));  // row_bcast:31 -> rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, kWave));
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMax>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }
 
 // Windowed search, wave-cooperative and exact.  Every lane of the wave calls it (inactive lanes
-// pass active = false).  Each lane first scans the 2W+1 edges around its hint (the edge its last
-// crossing was on; consecutive lanes -> consecutive LDS addresses).  That gives an upper bound
-// d_i on the distance of the closest crossing.  A crossing closer than d_i can only sit on an
-// edge whose chunk circle comes within d_i of p_i, so:
-//   1. the wave forms ONE disk that contains every lane's disk (p_i, d_i) and tests all chunk
-//      circles against it, 64 chunks per instruction (ballot);
-//   2. for each chunk that passes, every lane checks its own disk; lanes whose window already
-//      covers the chunk skip it;
-//   3. only if some lane still needs the chunk does the wave scan its edges (uniform addresses,
-//      LDS broadcast), and every active lane folds them into its result -- which is harmless:
-//      the result is the lexicographic minimum of (|s|, edge) over all edges seen.
-// Result == search_ring_brute, bit for bit.
-constexpr int kWin = 12;
+// pass active = false).
+//
+// Fast path, per lane, no cross-lane traffic:
+//   * scan the 2*kWin+1 edges around the hint (the edge of the last crossing); consecutive lanes ->
+//     consecutive LDS addresses.  This yields a crossing at distance d_i on an
+//     edge of chunk ce.
+//   * certificate that nothing closer exists anywhere else on the ring:
+//       - chunks further than 3 chunks (in ring order) from ce:  sep[ce] > 2 d_i, where sep[c] is the
+//         smallest gap between chunk c's bounding circle and the circle of any chunk outside
+//         [c-3, c+3] (precomputed once per instance).  A point q of such a chunk has
+//         |q - h_i| >= sep[ce] (h_i = the crossing found, inside circle ce), hence
+//         |q - p_i| >= sep[ce] - d_i > d_i.
+//       - the chunks of [ce-3, ce+3] that are not entirely inside the window: their circles must
+//         not come within d_i of p_i.
+// Slow path (any lane without a certificate): the wave forms ONE disk that contains the disks
+// (p_i, d_i) of those lanes, tests all chunk circles against it 64 at a time (ballot), and scans,
+// with wave-uniform LDS addresses, every chunk some lane still needs.
+// Either way the result is the lexicographic minimum of (|s|, edge) over a set of edges that
+// contains every edge with a crossing not farther than the best one == search_ring_brute, bit for bit.
+constexpr int kWin = 12;                  // window = hint +- kWin edges
+constexpr int kWinEdges = 2 * kWin + 1;   // rings must be longer than twice this
 
 template <typename RingPtr, typename CirclePtr>
 __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, CirclePtr circ,
-                                                    int nchunk, bool active, int hint, double px,
-                                                    double py, double dx, double dy, double dlen) {
+                                                    CirclePtr sep, int nchunk, bool active, int hint,
+                                                    double px, double py, double dx, double dy,
+                                                    double dlen, bool skip_guard = false) {
   const int lane = threadIdx.x & (kWave - 1);
   Hit h{INFINITY, 0.0, kNoEdge};
   const bool windowed = active && hint >= 0 && hint < nr;
-  int lo = hint - kWin;
+  int lo = hint - kWin;  // first edge of the window (consecutive lanes -> consecutive addresses)
   if (lo < 0) lo += nr;
-  if (windowed) scan_edges(ring, nr, lo, 2 * kWin + 1, px, py, dx, dy, h);
-  double di = active ? ((h.best <= 1.0 ? h.best * dlen : dlen) * (1.0 + 1e-9) + 1e-9) : 0.0;
-  const double xmin = wave_min(active ? px : INFINITY), xmax = wave_max(active ? px : -INFINITY);
-  const double ymin = wave_min(active ? py : INFINITY), ymax = wave_max(active ? py : -INFINITY);
-  const double ccx = 0.5 * (xmin + xmax), ccy = 0.5 * (ymin + ymax);
+  if (windowed) scan_edges_batched<5>(ring, nr, lo, kWinEdges, px, py, dx, dy, h);
+  if (skip_guard) return h;
+  const bool found = h.best <= 1.0;
+  const double di = active ? ((found ? h.best * dlen : dlen) * (1.0 + 1e-9) + 1e-9) : 0.0;
+  // is chunk c entirely inside this lane's window?
+  auto chunk_in_window = [&](int c) {
+    const int e0 = c * kChunk;
+    const int cnt = min(kChunk, nr - e0);
+    int off = e0 - lo;
+    if (off < 0) off += nr;
+    return off + cnt - 1 <= 2 * kWin;
+  };
+  bool slow = active;
+  if (windowed && found && nchunk > 7) {
+    const int ce = h.edge / kChunk;
+    bool ok = sep[ce] > 2.0 * di;
+    if (ok) {
+#pragma unroll
+      for (int u = -3; u <= 3; ++u) {
+        int c = ce + u;
+        if (c < 0) c += nchunk;
+        if (c >= nchunk) c -= nchunk;
+        if (!chunk_in_window(c)) {
+          const double mx = circ[3 * c] - px, my = circ[3 * c + 1] - py;
+          const double lim = (di + circ[3 * c + 2]) * (1.0 + 1e-9);
+          ok = ok && !(mx * mx + my * my <= lim * lim);
+        }
+      }
+    }
+    slow = !ok;
+  }
+  const unsigned long long sm = __ballot(slow);
+  if (sm == 0ull) return h;
+  // ---- slow path for the lanes in `sm`
+  const int first = __ffsll((long long)sm) - 1, last = 63 - __builtin_clzll(sm);
+  auto bcast = [](double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+  };
+  const double ccx = 0.5 * (bcast(px, first) + bcast(px, last));
+  const double ccy = 0.5 * (bcast(py, first) + bcast(py, last));
   const double ex = px - ccx, ey = py - ccy;
-  const double rho = wave_max(active ? sqrt(ex * ex + ey * ey) + di : 0.0) * (1.0 + 1e-9);
+  const double rho = wave_max(slow ? sqrt(ex * ex + ey * ey) + di : 0.0) * (1.0 + 1e-9);
   for (int c0 = 0; c0 < nchunk; c0 += kWave) {
     const int c = c0 + lane;
     bool pass = false;
@@ -240,14 +349,8 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
       const int e0 = cc * kChunk;
       const int cnt = min(kChunk, nr - e0);
       bool need = false;
-      if (active) {
-        bool inside = false;
-        if (windowed) {
-          int off = e0 - lo;
-          if (off < 0) off += nr;
-          inside = off + cnt - 1 <= 2 * kWin;
-        }
-        if (!inside) {
+      if (slow) {
+        if (!(windowed && chunk_in_window(cc))) {
           const double mx = circ[3 * cc] - px, my = circ[3 * cc + 1] - py;
           const double lim = (di + circ[3 * cc + 2]) * (1.0 + 1e-9);
           need = mx * mx + my * my <= lim * lim;
@@ -255,8 +358,8 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
       }
       if (__any(need)) {
         Hit h2 = h;
-        scan_edges(ring, nr, e0, cnt, px, py, dx, dy, h2);
-        if (active) h = h2;
+        scan_edges_batched<kChunk>(ring, nr, e0, cnt, px, py, dx, dy, h2);
+        if (slow) h = h2;
       }
     }
   }

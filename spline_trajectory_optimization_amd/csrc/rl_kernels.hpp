@@ -287,12 +287,13 @@ struct SweepArgs {
   int* status;          // [B] or null
   double* gscratch;     // per-instance global scratch when rings/sigma do not fit LDS
   size_t gscratch_stride;  // doubles per instance
+  int debug;            // timing ablations only (RL_DEBUG_FLAGS): results are WRONG when non-zero
 };
 
 // LDS carve (doubles).  cpad = n rounded up to even so every later array is 16-byte aligned.
 struct SweepLds {
   int cpad, nLp, nRp, ncL, ncR;
-  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_hint, total;
+  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, total;
 };
 
 __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds) {
@@ -307,6 +308,8 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   L.off_red = o; o += 16 * 12;           // up to 16 waves x 12 partials
   L.off_cL = o; o += (size_t)((3 * L.ncL + 1) & ~1);
   L.off_cR = o; o += (size_t)((3 * L.ncR + 1) & ~1);
+  L.off_pL = o; o += (size_t)((L.ncL + 1) & ~1);
+  L.off_pR = o; o += (size_t)((L.ncR + 1) & ~1);
   L.off_hint = o; o += (size_t)(((size_t)2 * ((N + 3) & ~3) * sizeof(unsigned short) + 15) / 16) * 2;  // u16 [2][Npad]
   if (rings_in_lds) {
     L.off_sL = o; o += (size_t)((N + 1) & ~1);
@@ -336,6 +339,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   double* red = smem + L.off_red;
   double* circL = smem + L.off_cL;
   double* circR = smem + L.off_cR;
+  double* sepL = smem + L.off_pL;   // per chunk: gap to the nearest chunk further than 3 away in ring order
+  double* sepR = smem + L.off_pR;
   unsigned short* hints = reinterpret_cast<unsigned short*>(smem + L.off_hint);  // [2][Npad]
   const int Npad = (N + 3) & ~3;
   double* sL; double* sR; double2* rL; double2* rR;
@@ -398,6 +403,26 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
       o[0] = mx; o[1] = my; o[2] = sqrt(r2) * (1.0 + 1e-12);
     }
     __syncthreads();
+    if (a.search == 2) {
+      for (int c = tid; c < L.ncL + L.ncR; c += BLOCK) {
+        const bool left = c < L.ncL;
+        const int cc = left ? c : c - L.ncL;
+        const double* circ = left ? circL : circR;
+        const int nc = left ? L.ncL : L.ncR;
+        const double mx = circ[3 * cc], my = circ[3 * cc + 1], r = circ[3 * cc + 2];
+        double gap = INFINITY;
+        for (int q = 0; q < nc; ++q) {
+          int dq = q - cc;
+          if (dq < 0) dq = -dq;
+          if (nc - dq < dq) dq = nc - dq;  // cyclic distance in ring order
+          if (dq <= 3) continue;
+          const double ex = circ[3 * q] - mx, ey = circ[3 * q + 1] - my;
+          gap = fmin(gap, sqrt(ex * ex + ey * ey) - r - circ[3 * q + 2]);
+        }
+        (left ? sepL : sepR)[cc] = gap * (1.0 - 1e-9) - 1e-9;
+      }
+      __syncthreads();
+    }
   }
 
   // refresh(i0,i1,j0,j1): new p, normal and closest ring crossings for the samples of two ranges
@@ -418,8 +443,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         double dx = -c.dy * inv, dy = c.dx * inv;  // max_dist * (cos, sin)(yaw + pi/2)
         if (side) { dx = -dx; dy = -dy; }          // yaw - pi/2
         const int hint = hints[side * Npad + i];
-        const Hit h = side ? search_ring_windowed(rR, nR, circR, L.ncR, active, hint, c.x, c.y, dx, dy, a.max_dist)
-                           : search_ring_windowed(rL, nL, circL, L.ncL, active, hint, c.x, c.y, dx, dy, a.max_dist);
+        const Hit h = side ? search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, hint, c.x, c.y, dx, dy, a.max_dist, (a.debug & 2) != 0)
+                           : search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, hint, c.x, c.y, dx, dy, a.max_dist, (a.debug & 2) != 0);
         if (active) {
           (side ? sR : sL)[i] = h.best_s;
           hints[side * Npad + i] = (unsigned short)(h.edge == kNoEdge ? 0xFFFF : h.edge);
@@ -452,7 +477,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   };
 
   // the windowed mode needs rings longer than its window and edge indices that fit 16 bits
-  const int mode = (a.search == 2 && nL > 2 * kWin + 1 && nR > 2 * kWin + 1 && nL < 0xFFFF && nR < 0xFFFF) ? 2
+  const int mode = (a.search == 2 && nL > 2 * kWinEdges && nR > 2 * kWinEdges && nL < 0xFFFF && nR < 0xFFFF) ? 2
                    : (a.search >= 1 ? 1 : 0);
   if (mode == 2 && a.form != 0) {
     // rings built from per-sample widths / bound points: vertex i sits on sample i's normal
@@ -486,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         CostAcc acc{0, 0, 0, 0, 0, 0};
         double lox = -INFINITY, hix = INFINITY, loy = -INFINITY, hiy = INFINITY;
         double bad = 0.0;
-        for (int i = s0 + tid; i < s1; i += BLOCK) {
+        for (int i = s0 + tid; i < s1 && !(a.debug & 4); i += BLOCK) {
           const int l = tr.ell[i];
           CurvePoint<K, 2> c;
           eval_sample<K, 2>(tr, cx, cy, i, l, c);
@@ -560,7 +585,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           else if (idx >= n - 5 && idx <= n - 4) alias = idx - (n - 5);
           int j0 = 0, j1 = 0;
           if (alias >= 0) { j0 = tr.sup[2 * alias]; j1 = tr.sup[2 * alias + 1]; }
-          refresh(s0, s1, j0, j1, mode);
+          if (!(a.debug & 1)) refresh(s0, s1, j0, j1, mode);
           __syncthreads();
           ++ok_count;
         } else {

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -110,7 +111,8 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR) {
   SweepPlan p;
   rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true);
   p.block = 256;
-  if (in.total * sizeof(double) <= (size_t)ctx->max_lds) {
+  const char* force_global = getenv("RL_FORCE_GLOBAL_RINGS");  // tuning / test knob
+  if (in.total * sizeof(double) <= (size_t)ctx->max_lds && !(force_global && force_global[0] == '1')) {
     p.rings_in_lds = true;
     p.lds_bytes = in.total * sizeof(double);
     p.gscratch_doubles = 0;
@@ -462,6 +464,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   for (int j = 0; j < max_iter; ++j) a.i_start[j] = i_start[j];
   a.search = search;
   a.max_dist = 100.0;  // race_track.py:104
+  if (const char* dbg = getenv("RL_DEBUG_FLAGS")) a.debug = atoi(dbg);
   a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_points = out_points;
   a.n_success = n_success; a.status = status;
   RL_HIP(hipSetDevice(ctx->device));
