@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+
 namespace rl {
 
 constexpr int kWave = 64;
@@ -90,11 +91,24 @@ __device__ __forceinline__ void eval_sample(const TrackDev& tr, CPtr cx, CPtr cy
   for (int a = 0; a <= K; ++a) {
     const double c_x = cx[l - K + a], c_y = cy[l - K + a];
     const double b0 = D0[(size_t)a * N + i];
-    x += c_x * b0; y += c_y * b0;
-    if (NDER >= 1) { const double b1 = D1[(size_t)a * N + i]; dx += c_x * b1; dy += c_y * b1; }
-    if (NDER >= 2) { const double b2 = D2[(size_t)a * N + i]; d2x += c_x * b2; d2y += c_y * b2; }
+    x = fma(c_x, b0, x); y = fma(c_y, b0, y);  // explicit: identical rounding at every call site
+    if (NDER >= 1) { const double b1 = D1[(size_t)a * N + i]; dx = fma(c_x, b1, dx); dy = fma(c_y, b1, dy); }
+    if (NDER >= 2) { const double b2 = D2[(size_t)a * N + i]; d2x = fma(c_x, b2, d2x); d2y = fma(c_y, b2, d2y); }
   }
   o.x = x; o.y = y; o.dx = dx; o.dy = dy; o.d2x = d2x; o.d2y = d2y;
+}
+
+// Left normal of the curve scaled to max_dist: max_dist * (cos, sin)(yaw + pi/2) without the trip
+// through atan2/cos/sin (the oracle takes that trip; the two agree to rounding).  One place, so
+// that the re-intersection and the constraint assembly see bit-identical direction vectors.
+__device__ __forceinline__ void scaled_normal(double dx, double dy, double max_dist, double& nx,
+                                              double& ny, double& inv_s2) {
+  const double s2 = fma(dx, dx, dy * dy);
+  const double rs = rsqrt(s2);
+  inv_s2 = rs * rs;
+  const double k = max_dist * rs;
+  nx = -dy * k;
+  ny = dx * k;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -109,8 +123,12 @@ struct Hit {
 };
 constexpr int kNoEdge = 0x7fffffff;
 
+// cross(V - p, d).  Written with an explicit fma so that EVERY inlined copy rounds identically:
+// the sign of this value decides on which edge a crossing through a ring vertex is found, and the
+// window scan evaluates it twice (candidate pass, exact pass).  Left to the compiler, the
+// contraction of a*b - c*d differs between call sites.
 __device__ __forceinline__ double edge_side(double vx, double vy, double dx, double dy) {
-  return vx * dy - vy * dx;  // cross(V - p, d)
+  return fma(vx, dy, -(vy * dx));
 }
 
 __device__ __forceinline__ void edge_hit(double ax, double ay, double ea, double bx, double by,
@@ -121,9 +139,9 @@ __device__ __forceinline__ void edge_hit(double ax, double ay, double ea, double
   if (prod > 0.0) return;
   if (prod == 0.0 && ea != 0.0 && eb != 0.0 && ((ea > 0.0) == (eb > 0.0))) return;
   const double sx = bx - ax, sy = by - ay;
-  const double den = dx * sy - dy * sx;
+  const double den = fma(dx, sy, -(dy * sx));
   if (den == 0.0) return;  // parallel / collinear: not a Point intersection
-  const double s = (ax * sy - ay * sx) / den;
+  const double s = fma(ax, sy, -(ay * sx)) / den;
   const double as = fabs(s);
   if (as > 1.0) return;  // beyond +-max_dist
   if (as < h.best || (as == h.best && edge < h.edge)) { h.best = as; h.best_s = s; h.edge = edge; }
@@ -187,6 +205,50 @@ __device__ __forceinline__ void scan_edges_batched(RingPtr ring, int nr, int j0,
       edge_hit(ax, ay, ea, bx, by, eb, dx, dy, j, h);
       ax = bx; ay = by; ea = eb;
       j = j1;
+    }
+  }
+}
+
+// Window scan over kWinEdges consecutive edges starting at edge `lo` of a ring stored with its
+// first kRingPad vertices repeated after the last one (no index wrap inside the loop).
+// Pass 1 touches every vertex once (4 FP64 ops + 1 multiply per edge) and only records, as one bit
+// per edge, where the line changes side; pass 2 runs the exact edge test (with its division) on
+// the recorded edges -- all lanes work on their own first candidate at the same time, so the
+// expensive block runs once or twice per window instead of once per distinct candidate position.
+constexpr int kWin = 12;                  // window = hint +- kWin edges
+constexpr int kWinEdges = 2 * kWin + 1;   // rings must be longer than twice this
+constexpr int kRingPad = kWinEdges + 1;   // vertices repeated behind the ring
+
+template <typename RingPtr>
+__device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, double px, double py,
+                                            double dx, double dy, Hit& h) {
+  unsigned cand = 0u;
+  {
+    double2 v = ring[lo];
+    double ea = edge_side(v.x - px, v.y - py, dx, dy);
+#pragma unroll
+    for (int q0 = 0; q0 < kWinEdges; q0 += 5) {
+      double2 w[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) w[u] = ring[lo + q0 + u + 1];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const double eb = edge_side(w[u].x - px, w[u].y - py, dx, dy);
+        if (!(ea * eb > 0.0)) cand |= 1u << (q0 + u);
+        ea = eb;
+      }
+    }
+  }
+  static_assert(kWinEdges % 5 == 0, "window scan is unrolled in batches of 5");
+  while (__any(cand != 0u)) {
+    if (cand != 0u) {
+      const int q = __ffs((int)cand) - 1;
+      cand &= cand - 1u;
+      const int j = lo + q;
+      const double2 va = ring[j], vb = ring[j + 1];
+      const double ax = va.x - px, ay = va.y - py, bx = vb.x - px, by = vb.y - py;
+      edge_hit(ax, ay, edge_side(ax, ay, dx, dy), bx, by, edge_side(bx, by, dx, dy), dx, dy,
+               j >= nr ? j - nr : j, h);
     }
   }
 }
@@ -278,9 +340,6 @@ __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>
 // with wave-uniform LDS addresses, every chunk some lane still needs.
 // Either way the result is the lexicographic minimum of (|s|, edge) over a set of edges that
 // contains every edge with a crossing not farther than the best one == search_ring_brute, bit for bit.
-constexpr int kWin = 12;                  // window = hint +- kWin edges
-constexpr int kWinEdges = 2 * kWin + 1;   // rings must be longer than twice this
-
 template <typename RingPtr, typename CirclePtr>
 __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, CirclePtr circ,
                                                     CirclePtr sep, int nchunk, bool active, int hint,
@@ -291,7 +350,7 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
   const bool windowed = active && hint >= 0 && hint < nr;
   int lo = hint - kWin;  // first edge of the window (consecutive lanes -> consecutive addresses)
   if (lo < 0) lo += nr;
-  if (windowed) scan_edges_batched<5>(ring, nr, lo, kWinEdges, px, py, dx, dy, h);
+  if (windowed) scan_window(ring, nr, lo, px, py, dx, dy, h);
   if (skip_guard) return h;
   const bool found = h.best <= 1.0;
   const double di = active ? ((found ? h.best * dlen : dlen) * (1.0 + 1e-9) + 1e-9) : 0.0;

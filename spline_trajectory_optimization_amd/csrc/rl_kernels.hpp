@@ -12,6 +12,7 @@
 #pragma once
 #include "rl_device.hpp"
 
+
 namespace rl {
 
 // ------------------------------------------------------------------------------------------------
@@ -305,7 +306,7 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   size_t o = 0;
   L.off_cx = o; o += L.cpad;
   L.off_cy = o; o += L.cpad;
-  L.off_red = o; o += 16 * 12;           // up to 16 waves x 12 partials
+  L.off_red = o; o += 16 * 12 + 4;       // up to 16 waves x 12 partials + verdict
   L.off_cL = o; o += (size_t)((3 * L.ncL + 1) & ~1);
   L.off_cR = o; o += (size_t)((3 * L.ncR + 1) & ~1);
   L.off_pL = o; o += (size_t)((L.ncL + 1) & ~1);
@@ -314,8 +315,8 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   if (rings_in_lds) {
     L.off_sL = o; o += (size_t)((N + 1) & ~1);
     L.off_sR = o; o += (size_t)((N + 1) & ~1);
-    L.off_rL = o; o += (size_t)2 * nL;
-    L.off_rR = o; o += (size_t)2 * nR;
+    L.off_rL = o; o += (size_t)2 * (nL + kRingPad);
+    L.off_rR = o; o += (size_t)2 * (nR + kRingPad);
   } else {
     L.off_sL = L.off_sR = L.off_rL = L.off_rR = 0;
   }
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     double* g = a.gscratch + (size_t)b * a.gscratch_stride;
     sL = g; sR = sL + ((N + 1) & ~1);
     rL = reinterpret_cast<double2*>(sR + ((N + 1) & ~1));
-    rR = rL + a.nL;
+    rR = rL + a.nL + kRingPad;
   }
   const int nL = a.nL, nR = a.nR;
 
@@ -377,6 +378,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   } else {
     for (int i = tid; i < nL; i += BLOCK) rL[i] = a.ringL[i];
     for (int i = tid; i < nR; i += BLOCK) rR[i] = a.ringR[i];
+  }
+  __syncthreads();
+  for (int q = tid; q < 2 * kRingPad; q += BLOCK) {  // repeat the first vertices behind the last
+    if (q < kRingPad) rL[nL + q] = rL[q % nL]; else rR[nR + q - kRingPad] = rR[(q - kRingPad) % nR];
   }
   __syncthreads();
   if (a.search >= 1) {
@@ -439,9 +444,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         const int l = tr.ell[i];
         CurvePoint<K, 1> c;
         eval_sample<K, 1>(tr, cx, cy, i, l, c);
-        const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
-        double dx = -c.dy * inv, dy = c.dx * inv;  // max_dist * (cos, sin)(yaw + pi/2)
-        if (side) { dx = -dx; dy = -dy; }          // yaw - pi/2
+        double dx, dy, inv_s2;
+        scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);  // max_dist * (cos, sin)(yaw + pi/2)
+        if (side) { dx = -dx; dy = -dy; }                        // yaw - pi/2
         const int hint = hints[side * Npad + i];
         const Hit h = side ? search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, hint, c.x, c.y, dx, dy, a.max_dist, (a.debug & 2) != 0)
                            : search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, hint, c.x, c.y, dx, dy, a.max_dist, (a.debug & 2) != 0);
@@ -460,9 +465,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
       const int l = tr.ell[i];
       CurvePoint<K, 1> c;
       eval_sample<K, 1>(tr, cx, cy, i, l, c);
-      const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
-      double dx = -c.dy * inv, dy = c.dx * inv;  // max_dist * (cos, sin)(yaw + pi/2)
-      if (side) { dx = -dx; dy = -dy; }          // yaw - pi/2
+      double dx, dy, inv_s2;
+      scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);
+      if (side) { dx = -dx; dy = -dy; }
       Hit h;
       if (mode == 1) {
         h = side ? search_ring_culled(rR, nR, circR, L.ncR, c.x, c.y, dx, dy, a.max_dist)
@@ -488,7 +493,6 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     refresh(0, N, 0, 0, mode == 2 ? 1 : mode);  // first fill also seeds the hints
   }
   __syncthreads();
-
   const int ignore_front = K / 2, ignore_rear = K - ignore_front;  // optimizer.py:297-302
   const int i_max = n - ignore_rear, i_min = ignore_front;
   const double* __restrict__ D0 = tr.D;
@@ -508,9 +512,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         const double zx = cx[idx], zy = cy[idx];
 
         // ---- phase 1: cost sums (a7) and the clamp interval of the box constraints (a8)
-        CostAcc acc{0, 0, 0, 0, 0, 0};
+        double hxx = 0.0, hyy = 0.0, gx = 0.0, gy = 0.0;
         double lox = -INFINITY, hix = INFINITY, loy = -INFINITY, hiy = INFINITY;
-        double bad = 0.0;
+        bool bad = false;
         for (int i = s0 + tid; i < s1 && !(a.debug & 4); i += BLOCK) {
           const int l = tr.ell[i];
           CurvePoint<K, 2> c;
@@ -518,10 +522,20 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           const int aa = idx - l + K;
           const double B2 = D2[(size_t)aa * N + i];
           const double B0 = D0[(size_t)aa * N + i];
-          cost_terms(c.dx, c.dy, c.d2x, c.d2y, B2, zx, zy, acc);
+          double ndx, ndy, inv_s2;
+          scaled_normal(c.dx, c.dy, a.max_dist, ndx, ndy, inv_s2);
+          {
+            // optimizer.py:66-85 with v = 1: P = (y'^2, -2x'y', x'^2) / (x'^2+y'^2)^3
+            const double inv_den = inv_s2 * inv_s2 * inv_s2;
+            const double Fx = c.d2x - B2 * zx, Fy = c.d2y - B2 * zy;
+            const double Pxx = c.dy * c.dy * inv_den, Pyy = c.dx * c.dx * inv_den;
+            const double Pxy = -2.0 * c.dx * c.dy * inv_den;
+            hxx += B2 * Pxx * B2;
+            hyy += B2 * Pyy * B2;
+            gx += Fx * Pxx * B2;                                              // g_x = 2 * this
+            gy += (Fy * Pxy * B2 + Fy * Pyy * B2) + (B2 * Pxy * Fx + Fy * Pyy * B2);  // g_y (:85)
+          }
           // bound points of this sample from the stored crossings (same arithmetic as refresh)
-          const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
-          const double ndx = -c.dy * inv, ndy = c.dx * inv;
           const double sl = sL[i], sr = sR[i];
           const double Lx = c.x + sl * ndx, Ly = c.y + sl * ndy;
           const double Rx = c.x + sr * (-ndx), Ry = c.y + sr * (-ndy);
@@ -529,56 +543,61 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           const double lbx = fmin(Lx, Rx) - nzx, ubx = fmax(Lx, Rx) - nzx;
           const double lby = fmin(Ly, Ry) - nzy, uby = fmax(Ly, Ry) - nzy;
           if (B0 > 0.0) {
+            // true divisions, like the reference's row / coefficient: these quotients are the
+            // noise-amplified quantities (b down to 1e-11), a reciprocal-multiply lands elsewhere
             lox = fmax(lox, lbx / B0); hix = fmin(hix, ubx / B0);
             loy = fmax(loy, lby / B0); hiy = fmin(hiy, uby / B0);
           } else {
-            if (lbx > 0.0 || ubx < 0.0 || lby > 0.0 || uby < 0.0) bad = 1.0;
+            if (lbx > 0.0 || ubx < 0.0 || lby > 0.0 || uby < 0.0) bad = true;
           }
-          if (!(lbx == lbx) || !(ubx == ubx) || !(lby == lby) || !(uby == uby)) bad = 1.0;
+          if (!(lbx == lbx) || !(ubx == ubx) || !(lby == lby) || !(uby == uby)) bad = true;
         }
         {
-          double v[11];
-          v[0] = wave_sum(acc.hxx); v[1] = wave_sum(acc.hyy); v[2] = wave_sum(acc.fx_pxx_b);
-          v[3] = wave_sum(acc.fy_pxy_b); v[4] = wave_sum(acc.fy_pyy_b); v[5] = wave_sum(acc.b_pxy_fx);
-          v[6] = wave_max(lox); v[7] = wave_min(hix); v[8] = wave_max(loy); v[9] = wave_min(hiy);
-          v[10] = wave_max(bad);
+          const double v0 = wave_sum(hxx), v1 = wave_sum(hyy), v2 = wave_sum(gx), v3 = wave_sum(gy);
+          const double v4 = wave_max(lox), v5 = wave_min(hix), v6 = wave_max(loy), v7 = wave_min(hiy);
+          const bool wbad = __any(bad);
           if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < 11; ++c) red[wave * 12 + c] = v[c];
+            double* r = red + wave * 12;
+            r[0] = v0; r[1] = v1; r[2] = v2; r[3] = v3; r[4] = v4; r[5] = v5; r[6] = v6; r[7] = v7;
+            r[8] = wbad ? 1.0 : 0.0;
           }
         }
         __syncthreads();
-        // ---- phase 2: closed-form QP (a11), every thread redundantly
-        double s[11];
+        // ---- phase 2: closed-form QP (a11) on wave 0 only; the verdict goes through LDS
+        if (wave == 0) {
+          double s[9];
 #pragma unroll
-        for (int c = 0; c < 11; ++c) s[c] = red[c];
-        for (int w = 1; w < NW; ++w) {
+          for (int c = 0; c < 9; ++c) s[c] = red[c];
+          for (int w = 1; w < NW; ++w) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) s[c] += red[w * 12 + c];
-          s[6] = fmax(s[6], red[w * 12 + 6]); s[7] = fmin(s[7], red[w * 12 + 7]);
-          s[8] = fmax(s[8], red[w * 12 + 8]); s[9] = fmin(s[9], red[w * 12 + 9]);
-          s[10] = fmax(s[10], red[w * 12 + 10]);
-        }
-        const double H0 = 2.0 * s[0], H1 = 2.0 * s[1];
-        const double g0 = s[2] + s[2];
-        const double g1 = (s[3] + s[4]) + (s[5] + s[4]);
-        bool ok = (s[10] == 0.0) && (H0 > 0.0) && (H1 > 0.0) && isfinite(H0) && isfinite(H1) &&
-                  isfinite(g0) && isfinite(g1) && (s[6] <= s[7]) && (s[8] <= s[9]);
-        __syncthreads();  // everyone has read `red` and the old control points
-        if (ok) {
-          double nzx = -g0 / H0, nzy = -g1 / H1;
-          nzx = fmin(fmax(nzx, s[6]), s[7]);
-          nzy = fmin(fmax(nzy, s[8]), s[9]);
-          if (tid == 0) {
-            // optimizer.py:280-285 (wrap hard-coded for k = 5 in the reference)
-            cx[idx] = nzx;         cy[idx] = nzy;
-            cx[0] = cx[n - 5];     cy[0] = cy[n - 5];
-            cx[1] = cx[n - 4];     cy[1] = cy[n - 4];
-            cx[n - 3] = cx[2];     cy[n - 3] = cy[2];
-            cx[n - 2] = cx[3];     cy[n - 2] = cy[3];
-            cx[n - 1] = cx[4];     cy[n - 1] = cy[4];
+            for (int c = 0; c < 4; ++c) s[c] += red[w * 12 + c];
+            s[4] = fmax(s[4], red[w * 12 + 4]); s[5] = fmin(s[5], red[w * 12 + 5]);
+            s[6] = fmax(s[6], red[w * 12 + 6]); s[7] = fmin(s[7], red[w * 12 + 7]);
+            s[8] = fmax(s[8], red[w * 12 + 8]);
           }
-          __syncthreads();
+          const double H0 = 2.0 * s[0], H1 = 2.0 * s[1];
+          const double g0 = s[2] + s[2], g1 = s[3];
+          const bool okw = (s[8] == 0.0) && (H0 > 0.0) && (H1 > 0.0) && isfinite(H0) && isfinite(H1) &&
+                           isfinite(g0) && isfinite(g1) && (s[4] <= s[5]) && (s[6] <= s[7]);
+          if (tid == 0) {
+            if (okw) {
+              double nzx = -g0 / H0, nzy = -g1 / H1;
+              nzx = fmin(fmax(nzx, s[4]), s[5]);
+              nzy = fmin(fmax(nzy, s[6]), s[7]);
+              // optimizer.py:280-285 (wrap hard-coded for k = 5 in the reference)
+              cx[idx] = nzx;         cy[idx] = nzy;
+              cx[0] = cx[n - 5];     cy[0] = cy[n - 5];
+              cx[1] = cx[n - 4];     cy[1] = cy[n - 4];
+              cx[n - 3] = cx[2];     cy[n - 3] = cy[2];
+              cx[n - 2] = cx[3];     cy[n - 2] = cy[3];
+              cx[n - 1] = cx[4];     cy[n - 1] = cy[4];
+            }
+            red[NW * 12] = okw ? 1.0 : 0.0;
+          }
+        }
+        __syncthreads();
+        const bool ok = red[NW * 12] != 0.0;
+        if (ok) {
           // ---- phase 3: re-sample (a3) and re-intersect (a5) what moved
           int alias = -1;
           if (idx <= 4 && idx >= 2) alias = idx + (n - 5);
@@ -607,8 +626,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
       CurvePoint<K, 2> c;
       eval_sample<K, 2>(tr, cx, cy, i, l, c);
       double* p = a.out_points + ((size_t)b * N + i) * 19;
-      const double inv = a.max_dist / sqrt(c.dx * c.dx + c.dy * c.dy);
-      const double ndx = -c.dy * inv, ndy = c.dx * inv;
+      double ndx, ndy, inv_s2;
+      scaled_normal(c.dx, c.dy, a.max_dist, ndx, ndy, inv_s2);
       p[0] = c.x; p[1] = c.y; p[3] = atan2(c.dy, c.dx);
       const double s2 = c.dx * c.dx + c.dy * c.dy;
       p[5] = 1.0 / fabs(fabs(c.dx * c.d2y - c.dy * c.d2x) / sqrt(s2 * s2 * s2));

@@ -107,12 +107,20 @@ struct SweepPlan {
   int block;
 };
 
-SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR) {
+SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B) {
   SweepPlan p;
   rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true);
   p.block = 256;
-  const char* force_global = getenv("RL_FORCE_GLOBAL_RINGS");  // tuning / test knob
-  if (in.total * sizeof(double) <= (size_t)ctx->max_lds && !(force_global && force_global[0] == '1')) {
+  // Two residencies for the per-instance rings / crossings:
+  //   LDS    : lowest latency per step, but ~120 KB at N = 2000 -> one workgroup per CU;
+  //   global : ~25 KB of LDS -> four workgroups per CU (VGPR-limited), rings served by L1/L2.
+  // The kernel is FP64-issue / latency bound, so once a batch offers more than ~2 workgroups per
+  // CU the occupancy wins (measured: 12.5 ms vs 20.2 ms for 1024 instances, N = 2000).
+  // RL_FORCE_GLOBAL_RINGS=0/1 overrides (tests cover both variants).
+  const char* force = getenv("RL_FORCE_GLOBAL_RINGS");
+  bool want_global = B >= 2 * ctx->num_cu;
+  if (force && (force[0] == '0' || force[0] == '1')) want_global = force[0] == '1';
+  if (in.total * sizeof(double) <= (size_t)ctx->max_lds && !want_global) {
     p.rings_in_lds = true;
     p.lds_bytes = in.total * sizeof(double);
     p.gscratch_doubles = 0;
@@ -120,7 +128,7 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR) {
     rl::SweepLds out = rl::sweep_lds_layout(n, N, nL, nR, false);
     p.rings_in_lds = false;
     p.lds_bytes = out.total * sizeof(double);
-    p.gscratch_doubles = (size_t)2 * ((N + 1) & ~1) + (size_t)2 * nL + (size_t)2 * nR;
+    p.gscratch_doubles = (size_t)2 * ((N + 1) & ~1) + (size_t)2 * (nL + rl::kRingPad) + (size_t)2 * (nR + rl::kRingPad);
   }
   return p;
 }
@@ -468,7 +476,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_points = out_points;
   a.n_success = n_success; a.status = status;
   RL_HIP(hipSetDevice(ctx->device));
-  SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR);
+  SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR, B);
   if (p.lds_bytes > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "problem does not fit LDS");
   if (!p.rings_in_lds) {
     const size_t need = p.gscratch_doubles * (size_t)B;
