@@ -215,9 +215,14 @@ __device__ __forceinline__ void scan_edges_batched(RingPtr ring, int nr, int j0,
 // per edge, where the line changes side; pass 2 runs the exact edge test (with its division) on
 // the recorded edges -- all lanes work on their own first candidate at the same time, so the
 // expensive block runs once or twice per window instead of once per distinct candidate position.
-constexpr int kWin = 12;                  // window = hint +- kWin edges
+#ifndef RL_WIN
+#define RL_WIN 12
+#endif
+constexpr int kWin = RL_WIN;              // window = hint +- kWin edges
+constexpr int kNear = 2;                  // chunks ce-kNear..ce+kNear are checked one by one
 constexpr int kWinEdges = 2 * kWin + 1;   // rings must be longer than twice this
 constexpr int kRingPad = kWinEdges + 1;   // vertices repeated behind the ring
+constexpr int kWinBatch = kWinEdges % 5 == 0 ? 5 : (kWinEdges % 7 == 0 ? 7 : 3);
 
 template <typename RingPtr>
 __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, double px, double py,
@@ -227,19 +232,19 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, double
     double2 v = ring[lo];
     double ea = edge_side(v.x - px, v.y - py, dx, dy);
 #pragma unroll
-    for (int q0 = 0; q0 < kWinEdges; q0 += 5) {
-      double2 w[5];
+    for (int q0 = 0; q0 < kWinEdges; q0 += kWinBatch) {
+      double2 w[kWinBatch];
 #pragma unroll
-      for (int u = 0; u < 5; ++u) w[u] = ring[lo + q0 + u + 1];
+      for (int u = 0; u < kWinBatch; ++u) w[u] = ring[lo + q0 + u + 1];
 #pragma unroll
-      for (int u = 0; u < 5; ++u) {
+      for (int u = 0; u < kWinBatch; ++u) {
         const double eb = edge_side(w[u].x - px, w[u].y - py, dx, dy);
         if (!(ea * eb > 0.0)) cand |= 1u << (q0 + u);
         ea = eb;
       }
     }
   }
-  static_assert(kWinEdges % 5 == 0, "window scan is unrolled in batches of 5");
+  static_assert(kWinEdges % kWinBatch == 0, "window scan is unrolled in whole batches");
   while (__any(cand != 0u)) {
     if (cand != 0u) {
       const int q = __ffs((int)cand) - 1;
@@ -328,12 +333,12 @@ __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>
 //     consecutive LDS addresses.  This yields a crossing at distance d_i on an
 //     edge of chunk ce.
 //   * certificate that nothing closer exists anywhere else on the ring:
-//       - chunks further than 3 chunks (in ring order) from ce:  sep[ce] > 2 d_i, where sep[c] is the
+//       - chunks further than kNear chunks (in ring order) from ce:  sep[ce] > 2 d_i, where sep[c] is the
 //         smallest gap between chunk c's bounding circle and the circle of any chunk outside
 //         [c-3, c+3] (precomputed once per instance).  A point q of such a chunk has
 //         |q - h_i| >= sep[ce] (h_i = the crossing found, inside circle ce), hence
 //         |q - p_i| >= sep[ce] - d_i > d_i.
-//       - the chunks of [ce-3, ce+3] that are not entirely inside the window: their circles must
+//       - the chunks of [ce-kNear, ce+kNear] that are not entirely inside the window: their circles must
 //         not come within d_i of p_i.
 // Slow path (any lane without a certificate): the wave forms ONE disk that contains the disks
 // (p_i, d_i) of those lanes, tests all chunk circles against it 64 at a time (ballot), and scans,
@@ -363,12 +368,12 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
     return off + cnt - 1 <= 2 * kWin;
   };
   bool slow = active;
-  if (windowed && found && nchunk > 7) {
+  if (windowed && found && nchunk > 2 * kNear + 1) {
     const int ce = h.edge / kChunk;
     bool ok = sep[ce] > 2.0 * di;
     if (ok) {
 #pragma unroll
-      for (int u = -3; u <= 3; ++u) {
+      for (int u = -kNear; u <= kNear; ++u) {
         int c = ce + u;
         if (c < 0) c += nchunk;
         if (c >= nchunk) c -= nchunk;

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   double* red = smem + L.off_red;
   double* circL = smem + L.off_cL;
   double* circR = smem + L.off_cR;
-  double* sepL = smem + L.off_pL;   // per chunk: gap to the nearest chunk further than 3 away in ring order
+  double* sepL = smem + L.off_pL;   // per chunk: gap to the nearest chunk further than kNear away in ring order
   double* sepR = smem + L.off_pR;
   unsigned short* hints = reinterpret_cast<unsigned short*>(smem + L.off_hint);  // [2][Npad]
   const int Npad = (N + 3) & ~3;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           int dq = q - cc;
           if (dq < 0) dq = -dq;
           if (nc - dq < dq) dq = nc - dq;  // cyclic distance in ring order
-          if (dq <= 3) continue;
+          if (dq <= kNear) continue;
           const double ex = circ[3 * q] - mx, ey = circ[3 * q + 1] - my;
           gap = fmin(gap, sqrt(ex * ex + ey * ey) - r - circ[3 * q + 2]);
         }
@@ -434,11 +434,11 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   auto refresh = [&](int i0, int i1, int j0, int j1, int mode) {
     const int m0 = i1 - i0, m1 = j1 - j0, m = m0 + m1;
     if (mode == 2) {
-      // windowed, wave-cooperative search: a wave takes 64 consecutive samples of ONE ring
+      // windowed, wave-cooperative search: a wave takes 64 consecutive samples and intersects
+      // their normals with the left ring, then with the right ring (one curve evaluation for both)
       const int nwt = (m + kWave - 1) / kWave;
-      for (int wt = wave; wt < 2 * nwt; wt += NW) {
-        const int side = wt >= nwt;
-        const int r = ((side ? wt - nwt : wt) * kWave) + lane;
+      for (int wt = wave; wt < nwt; wt += NW) {
+        const int r = wt * kWave + lane;
         const bool active = r < m;
         const int i = active ? (r < m0 ? i0 + r : j0 + (r - m0)) : (m0 > 0 ? i0 : j0);
         const int l = tr.ell[i];
@@ -446,13 +446,16 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         eval_sample<K, 1>(tr, cx, cy, i, l, c);
         double dx, dy, inv_s2;
         scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);  // max_dist * (cos, sin)(yaw + pi/2)
-        if (side) { dx = -dx; dy = -dy; }                        // yaw - pi/2
-        const int hint = hints[side * Npad + i];
-        const Hit h = side ? search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, hint, c.x, c.y, dx, dy, a.max_dist, (a.debug & 2) != 0)
-                           : search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, hint, c.x, c.y, dx, dy, a.max_dist, (a.debug & 2) != 0);
+        const bool skip = (a.debug & 2) != 0;
+        const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
+                                            dx, dy, a.max_dist, skip);
+        const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
+                                            c.y, -dx, -dy, a.max_dist, skip);  // yaw - pi/2
         if (active) {
-          (side ? sR : sL)[i] = h.best_s;
-          hints[side * Npad + i] = (unsigned short)(h.edge == kNoEdge ? 0xFFFF : h.edge);
+          sL[i] = hl.best_s;
+          sR[i] = hr.best_s;
+          hints[i] = (unsigned short)(hl.edge == kNoEdge ? 0xFFFF : hl.edge);
+          hints[Npad + i] = (unsigned short)(hr.edge == kNoEdge ? 0xFFFF : hr.edge);
         }
       }
       return;
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           }
           if (!(lbx == lbx) || !(ubx == ubx) || !(lby == lby) || !(uby == uby)) bad = true;
         }
-        {
+        if (s0 + wave * kWave < s1) {  // this wave held samples (wave-uniform)
           const double v0 = wave_sum(hxx), v1 = wave_sum(hyy), v2 = wave_sum(gx), v3 = wave_sum(gy);
           const double v4 = wave_max(lox), v5 = wave_min(hix), v6 = wave_max(loy), v7 = wave_min(hiy);
           const bool wbad = __any(bad);
@@ -561,6 +564,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
             r[0] = v0; r[1] = v1; r[2] = v2; r[3] = v3; r[4] = v4; r[5] = v5; r[6] = v6; r[7] = v7;
             r[8] = wbad ? 1.0 : 0.0;
           }
+        } else if (lane == 0) {        // identities
+          double* r = red + wave * 12;
+          r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = 0.0;
+          r[4] = -INFINITY; r[5] = INFINITY; r[6] = -INFINITY; r[7] = INFINITY; r[8] = 0.0;
         }
         __syncthreads();
         // ---- phase 2: closed-form QP (a11) on wave 0 only; the verdict goes through LDS
