@@ -77,7 +77,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as ge
-    ge.build_hip()
+    if local_rank == 0:
+        ge.build_hip()          # the .so normally ships prebuilt; never let N ranks race on hipcc
+    if world > 1:
+        dist.barrier()
     from spline_trajectory_optimization_amd import _lib, batch, ops
     from spline_trajectory_optimization_amd.models.race_track import RaceTrack
 

@@ -168,3 +168,11 @@ def solve_width_batch(t, cx0, cy0, k, length, N, widths, i_start, max_iter=None,
     if want_kappa:
         return ctrl, xy, ns, kappa
     return ctrl, xy, ns
+
+
+def qss_sim(points, acc_x, acc_c, dcc_x, dcc_c, params):
+    """Simulator.run_simulation on a copy of points [N,19]; returns (points, n_iterations)."""
+    pts = np.array(points, dtype=np.float64, copy=True, order="C")
+    ax, axp = _d(acc_x); ac, acp = _d(acc_c); dx, dxp = _d(dcc_x); dc, dcp = _d(dcc_c); pr, prp = _d(params)
+    it = lib().orc_qss_sim(pts.ctypes.data_as(_dp), len(pts), axp, acp, ac.shape[1], dxp, dcp, dc.shape[1], prp)
+    return pts, it

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "rl_mincurv_solve_batch_host": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _dp, ctypes.c_int, _ip,
                                                    ctypes.c_int, ctypes.c_int, _dp, _dp, _ip, _ip,
                                                    ctypes.POINTER(Stats)]),
+    "rl_qss_sim": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp,
+                                  ctypes.c_int, _dp, _ip]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -571,4 +571,38 @@ int rl_mincurv_sweep(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_ite
   return RL_OK;
 }
 
+int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, const double* acc_c,
+               int acc_m, const double* dcc_x, const double* dcc_c, int dcc_m, const double* params,
+               int* iters) {
+  if (!ctx || !points || !acc_x || !acc_c || !dcc_x || !dcc_c || !params || !iters)
+    return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0 || N < 2 || acc_m < 1 || dcc_m < 1) return fail(RL_ERR_ARG, "bad sizes");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int cap = 4 * N + 16;
+  DevBuf<double> dpts, dax, dac, ddx, ddc;
+  DevBuf<int> dfl, dnw, dit;
+  RL_HIP(dpts.alloc((size_t)B * N * RL_NCOL));
+  RL_HIP(dax.alloc(acc_m + 1)); RL_HIP(dac.alloc((size_t)4 * acc_m));
+  RL_HIP(ddx.alloc(dcc_m + 1)); RL_HIP(ddc.alloc((size_t)4 * dcc_m));
+  RL_HIP(dfl.alloc((size_t)B * cap * 5)); RL_HIP(dnw.alloc((size_t)B * cap)); RL_HIP(dit.alloc(B));
+  RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dax.p, acc_x, dax.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dac.p, acc_c, dac.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(ddx.p, dcc_x, ddx.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(ddc.p, dcc_c, ddc.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rl::QssArgs a;
+  a.points = dpts.p; a.B = B; a.N = N;
+  a.acc_x = dax.p; a.acc_c = dac.p; a.acc_m = acc_m;
+  a.dcc_x = ddx.p; a.dcc_c = ddc.p; a.dcc_m = dcc_m;
+  a.max_lon_acc = params[0]; a.max_lon_dcc = params[1]; a.max_left_acc = params[2];
+  a.max_right_acc = params[3]; a.max_speed = params[4]; a.max_jerk = params[5];
+  a.flags = dfl.p; a.fresh = dnw.p; a.cap = cap; a.iters = dit.p;
+  hipLaunchKernelGGL(rl::k_qss_sim, dim3(B), dim3(64), 0, ctx->stream, a);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(iters, dit.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
 }  // extern "C"

@@ -209,3 +209,26 @@ def test_g7_run_min_curvature_qp_n500(fits, rings):
                                                     g[f"{key}_i_start"], max_iter)
         np.testing.assert_array_equal(ns, g[f"{key}_n_success"])
         assert np.hypot(ocx - g[f"{key}_cx"], ocy - g[f"{key}_cy"]).max() < 1e-6
+
+
+def test_g6_qss_simulator():
+    """The oracle's port of Simulator.run_simulation against the reference's own run (fixture G6)."""
+    from scipy.interpolate import CubicSpline
+    g = golden("G6_simulator.npz")
+    N = len(g["speed"])
+    pts = np.zeros((N, 19))
+    pts[:, [0, 1, 5, 6, 7, 13]] = g["cols_in"]
+    pts[:, 17] = np.arange(N); pts[:, 18] = -1
+    acc = CubicSpline(g["acc_lookup"][:, 0], g["acc_lookup"][:, 1])
+    dcc = CubicSpline(g["dcc_lookup"][:, 0], g["dcc_lookup"][:, 1])
+    out, it = orc.qss_sim(pts, acc.x, acc.c, dcc.x, dcc.c, g["params"])
+    assert it > 10
+    np.testing.assert_array_equal(out[:, 18], g["iter_flag"])
+    np.testing.assert_array_equal(out[:, 4], g["speed"])
+    np.testing.assert_allclose(out[:, 14], g["lon_acc"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out[:, 15], g["lat_acc"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(out[:, 16], g["time"], rtol=0, atol=1e-15)
+    # a zero speed makes the reference raise (np.seterr(all='raise'), simulator.py:164-165)
+    bad = pts.copy(); bad[7, 5] = 0.0          # zero turn radius -> seed speed 0
+    _, it2 = orc.qss_sim(bad, acc.x, acc.c, dcc.x, dcc.c, g["params"])
+    assert it2 == -1
