@@ -90,3 +90,63 @@ def gather_to_root(tensor, rank, world, dist, total=None):
     if rank != 0:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+
+
+# ---------------------------------------------------------------- synthetic oval (BASELINE config 3)
+def oval_points(spacing=10.0, heading0=np.deg2rad(17.0)):
+    """Centre line and half-widths of the synthetic Indy-style oval of SURVEY.md 8(d) config 3 (the
+    reference ships no Indy data): two 1006 m straights, two 201 m short chutes, four 402 m
+    quarter-turns (4023 m in all); half-width 7.6 m on the straights, 9.1 m in the turns.
+    The front straight heads `heading0` off the x axis: the reference's constraints are axis-aligned
+    boxes between the two bound points (optimizer.py:243-248), which collapse to zero width on an
+    exactly axis-parallel straight and leave every QP there feasible or not by rounding noise.
+    Returns (xy [P,2], half_width [P]) sampled every ~`spacing` metres, counter-clockwise."""
+    R = 402.0 / (np.pi / 2.0)
+    segs = [("s", 1006.0), ("t", 402.0), ("s", 201.0), ("t", 402.0),
+            ("s", 1006.0), ("t", 402.0), ("s", 201.0), ("t", 402.0)]
+    pos = np.array([0.0, 0.0]); heading = float(heading0)
+    pts, hw = [], []
+    for kind, length in segs:
+        m = max(2, int(round(length / spacing)))
+        for j in range(m):
+            s = length * j / m
+            if kind == "s":
+                p = pos + s * np.array([np.cos(heading), np.sin(heading)])
+                w = 7.6
+            else:
+                ang = s / R
+                c = pos + R * np.array([-np.sin(heading), np.cos(heading)])      # centre of the left turn
+                p = c + R * np.array([np.sin(heading + ang), -np.cos(heading + ang)])
+                w = 9.1
+            pts.append(p); hw.append(w)
+        if kind == "s":
+            pos = pos + length * np.array([np.cos(heading), np.sin(heading)])
+        else:
+            c = pos + R * np.array([-np.sin(heading), np.cos(heading)])
+            heading += np.pi / 2.0
+            pos = c + R * np.array([np.sin(heading), -np.cos(heading)])
+    return np.array(pts), np.array(hw)
+
+
+def oval_centerline(s=100.0, k=5):
+    xy, _ = oval_points()
+    return BSplineTrajectory(xy, s, k)
+
+
+def oval_half_widths(N):
+    """Half-widths of the oval resampled on N uniform-in-parameter samples (nearest raw point)."""
+    xy, hw = oval_points()
+    idx = np.minimum((np.arange(N) * (len(hw) / N)).astype(int), len(hw) - 1)
+    return hw[idx].copy(), hw[idx].copy()
+
+
+def solve_grouped(groups, i_starts, search=_lib.SEARCH_WINDOWED):
+    """Mixed batches (BASELINE config 3): instances are grouped by track so that every workgroup of
+    one launch sees one knot layout.  groups = [(Track, widths [B_g,N,2]), ...], i_starts = one pinned
+    start-index array per group (control-point counts differ between tracks).
+    Returns a list of (ctrl, xy, n_success, status) per group, in order."""
+    out = []
+    for (trk, widths), ist in zip(groups, i_starts):
+        ctrl, xy, ns, status, _ = ops.solve_batch_host(trk, _lib.BOUNDS_WIDTHS, widths, ist, search=search)
+        out.append((ctrl, xy, ns, status))
+    return out

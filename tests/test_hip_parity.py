@@ -477,3 +477,27 @@ def test_simulator_class_api(rl, fits):
     assert abs(res.total_time - s[0]) < 1e-14 and abs(res.average_speed - s[1]) < 1e-6 * s[1]
     assert abs(res.max_speed - s[2]) < 1e-12 and abs(res.min_speed - s[3]) < 1e-12
     np.testing.assert_array_equal(traj.points, pts)  # the input trajectory is not modified (simulator.py:64)
+
+
+def test_mixed_batch_monza_and_oval(rl, fits, rings):
+    """BASELINE config 3 in small: half Monza, half the synthetic Indy-style oval (a different knot
+    vector and control-point count), grouped by track, each group against the oracle."""
+    N, B, max_iter = 400, 6, 2
+    t, cx, cy, k, length = spline(fits, "c100")
+    w_monza = monza_like_widths(rl, fits, rings, "c100", N, B, seed=1234)
+    oval = rl.batch.oval_centerline(100.0, 5)
+    ot, ocx, ocy, ok_ = oval._tck()
+    assert abs(oval.get_length() - 4023.0) < 5.0 and len(ocx) != len(cx)
+    wl, wr = rl.batch.oval_half_widths(N)
+    w_oval = rl.batch.width_batch(wl, wr, B, seed=5678)
+    ctx = rl.lib.Context.get(0)
+    groups = [(rl.lib.Track(ctx, t, cx, cy, k, N), w_monza), (rl.lib.Track(ctx, ot, ocx, ocy, ok_, N), w_oval)]
+    i_starts = [rl.batch.default_i_start(len(cx), k, max_iter, seed=0),
+                rl.batch.default_i_start(len(ocx), ok_, max_iter, seed=0)]
+    res = rl.batch.solve_grouped(groups, i_starts)
+    for (ctrl, xy, ns, status), (tt, c0x, c0y, kk, ll), w, ist, name in (
+            (res[0], (t, cx, cy, k, length), w_monza, i_starts[0], "monza"),
+            (res[1], (ot, ocx, ocy, ok_, oval.get_length()), w_oval, i_starts[1], "oval")):
+        octrl, oxy, ons = orc.solve_width_batch(tt, c0x, c0y, kk, ll, N, w, ist, nthreads=8)
+        batch_parity(xy, oxy, ns, ons, f"config 3 / {name}")
+        assert np.abs(ctrl - np.stack([c0x, c0y], axis=1)).max() > 0.5   # the lines moved
