@@ -275,6 +275,9 @@ def main():
         cases = [("c100", 200, 3, 1), ("c30", 200, 2, 7)]
         if not args.fast:
             cases.append(("c100", 500, 2, 0))
+            # the benchmark size, and the size of the reference's own test (sample_along(3.0) -> 1929)
+            cases.append(("c100", 2000, 1, 3))
+            cases.append(("c100", 1929, 1, 5))
         kw = {"cases": np.array([f"{a}_N{b}_it{c}_seed{d}" for a, b, c, d in cases])}
         for tag, N, max_iter, seed in cases:
             sp = fits[tag][0].copy()
