@@ -57,6 +57,10 @@ typedef struct rl_stats {
 } rl_stats;
 
 int rl_version(void);
+/* test aid: with RL_DEBUG_DUMP=1 in the environment, rl_mincurv_sweep_joint records, for instance 0
+ * and every window, the QP it assembled and what it decided (48 header doubles + 9 per row, see
+ * tests/test_hip_parity.py::test_joint_window_qps_replayed); this copies the first n doubles out. */
+int rl_debug_read(double* out, long long n);
 const char* rl_last_error(void);
 
 int rl_ctx_create(int device_id, rl_ctx** out);
@@ -111,6 +115,16 @@ int rl_track_constraint(rl_ctx* ctx, const rl_track* trk, const double* points, 
  * n_success[2*max_iter] out (forward/backward successes per iteration, optimizer.py:314,325). */
 int rl_mincurv_sweep(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter,
                      double* cx, double* cy, double* points, int* n_success, rl_stats* stats);
+
+/* ---- a9+a10+a11+a13: TrajectoryOptimizer.run_joint_min_curvature_qp (optimization/optimizer.py:163-220):
+ * the sliding-window variant, span 5 (:167).  Per window: joint_min_curvature_cost (:88-110),
+ * joint_track_constraint (:112-161, rows for ALL samples), the 10-variable QP (casadi.conic/qpOASES,
+ * :188-197) solved exactly as two 5-variable diagonal-Hessian QPs with a dual active-set method,
+ * the five control points + wrap (:199-206), re-sampling and boundary refill (:207-210).
+ * i_start[max_iter] pins np.random.randint of :178 (range [k//2, n-(k-k//2)-5)).
+ * n_success[max_iter]: windows updated per outer iteration.  Degree 5 only. */
+int rl_mincurv_sweep_joint(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter,
+                           double* cx, double* cy, double* points, int* n_success, rl_stats* stats);
 
 /* ---- batched solve: B independent instances of the same sweep, one workgroup each.
  * DEVICE pointers; enqueued on the ctx stream; no synchronisation.

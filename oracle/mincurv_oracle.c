@@ -721,3 +721,212 @@ int orc_qss_sim(double* points, int N, const double* acc_x, const double* acc_c,
   free(nw);
   return err ? -1 : itr;
 }
+
+/* ---------------------------------------------------------------- sliding-window (joint) variant */
+
+/* Strictly convex QP with a DIAGONAL Hessian and two-sided linear rows
+ *     min  sum_j 1/2 h_j x_j^2 + g_j x_j     s.t.  l_i <= a_i . x <= u_i ,  i < M
+ * solved with the dual active-set method of Goldfarb & Idnani (Math. Prog. 27, 1983): start at the
+ * unconstrained minimum, repeatedly pick the most violated row and move, in the primal and in the
+ * dual, until it is satisfied or proven incompatible with the active set.  This is the exact
+ * solution qpOASES (casadi.conic, optimizer.py:188-197) converges to for the window QP, whose
+ * Hessian the reference builds block-diagonal from 2x2 diagonal blocks (optimizer.py:103-108).
+ * nv <= ORC_QP_MAXV.  Returns 0 = solved, 2 = infeasible, 3 = bad data / iteration cap.
+ * lam (optional, [M]) receives the row multipliers (>0 lower bound active, <0 upper). */
+#define ORC_QP_MAXV 8
+
+static int small_spd_solve(int q, double* Mq /*[q][q], destroyed*/, double* b /*[q] in/out*/) {
+  /* Cholesky; q <= ORC_QP_MAXV */
+  for (int c = 0; c < q; ++c) {
+    double d = Mq[c * q + c];
+    for (int k = 0; k < c; ++k) d -= Mq[c * q + k] * Mq[c * q + k];
+    if (!(d > 0.0)) return 1;
+    d = sqrt(d);
+    Mq[c * q + c] = d;
+    for (int r = c + 1; r < q; ++r) {
+      double s = Mq[r * q + c];
+      for (int k = 0; k < c; ++k) s -= Mq[r * q + k] * Mq[c * q + k];
+      Mq[r * q + c] = s / d;
+    }
+  }
+  for (int r = 0; r < q; ++r) {
+    double s = b[r];
+    for (int k = 0; k < r; ++k) s -= Mq[r * q + k] * b[k];
+    b[r] = s / Mq[r * q + r];
+  }
+  for (int r = q - 1; r >= 0; --r) {
+    double s = b[r];
+    for (int k = r + 1; k < q; ++k) s -= Mq[k * q + r] * b[k];
+    b[r] = s / Mq[r * q + r];
+  }
+  return 0;
+}
+
+int orc_qp_diag_rows(int nv, const double* h, const double* g, int M, const double* A,
+                     const double* l, const double* u, double* x, double* lam_out) {
+  if (nv < 1 || nv > ORC_QP_MAXV) return 3;
+  double hinv[ORC_QP_MAXV];
+  for (int j = 0; j < nv; ++j) {
+    if (!(h[j] > 0.0) || !isfinite(h[j]) || !isfinite(g[j])) return 3;
+    hinv[j] = 1.0 / h[j];
+    x[j] = -g[j] * hinv[j];
+  }
+  /* row norms; rows that are identically zero only decide feasibility (0 must lie in [l,u]) */
+  double* nrm = (double*)malloc((size_t)(M > 0 ? M : 1) * sizeof(double));
+  for (int i = 0; i < M; ++i) {
+    double s = 0.0;
+    for (int j = 0; j < nv; ++j) s += A[i * nv + j] * A[i * nv + j];
+    nrm[i] = sqrt(s);
+    if (l[i] != l[i] || u[i] != u[i] || nrm[i] != nrm[i]) { free(nrm); return 3; }
+    if (nrm[i] == 0.0 && (l[i] > 0.0 || u[i] < 0.0)) { free(nrm); return 2; }
+    if (l[i] > u[i]) { free(nrm); return 2; }
+  }
+  int widx[ORC_QP_MAXV], wsgn[ORC_QP_MAXV], q = 0;
+  double wlam[ORC_QP_MAXV];
+  const double tol = 1e-10; /* violation tolerance, in units of x (row normalised) */
+  int status = 3;
+  for (int outer = 0; outer < 200 * nv; ++outer) {
+    /* most violated row (normalised) */
+    int p = -1, psgn = 0;
+    double worst = tol;
+    for (int i = 0; i < M; ++i) {
+      if (nrm[i] == 0.0) continue;
+      double ax = 0.0;
+      for (int j = 0; j < nv; ++j) ax += A[i * nv + j] * x[j];
+      double vl = (l[i] - ax) / nrm[i], vu = (ax - u[i]) / nrm[i];
+      if (vl > worst) { worst = vl; p = i; psgn = +1; }
+      if (vu > worst) { worst = vu; p = i; psgn = -1; }
+    }
+    if (p < 0) { status = 0; break; }
+    double np_[ORC_QP_MAXV];
+    for (int j = 0; j < nv; ++j) np_[j] = psgn * A[p * nv + j];
+    const double beta = psgn > 0 ? l[p] : -u[p]; /* constraint: np.x >= beta */
+    double up = 0.0;                              /* multiplier of p accumulated over partial steps */
+    int done_p = 0;
+    for (int inner = 0; inner < 4 * nv + 8 && !done_p; ++inner) {
+      /* directions: r = (N' H^-1 N)^-1 N' H^-1 np ;  z = H^-1 (np - N r) */
+      double Mq[ORC_QP_MAXV * ORC_QP_MAXV], r[ORC_QP_MAXV], z[ORC_QP_MAXV];
+      for (int a = 0; a < q; ++a) {
+        for (int b = 0; b < q; ++b) {
+          double s = 0.0;
+          for (int j = 0; j < nv; ++j)
+            s += wsgn[a] * A[widx[a] * nv + j] * hinv[j] * wsgn[b] * A[widx[b] * nv + j];
+          Mq[a * q + b] = s;
+        }
+        double s = 0.0;
+        for (int j = 0; j < nv; ++j) s += wsgn[a] * A[widx[a] * nv + j] * hinv[j] * np_[j];
+        r[a] = s;
+      }
+      if (q > 0 && small_spd_solve(q, Mq, r)) { status = 3; done_p = 2; break; }
+      double zn = 0.0, scale = 0.0;
+      for (int j = 0; j < nv; ++j) {
+        double s = np_[j];
+        for (int a = 0; a < q; ++a) s -= wsgn[a] * A[widx[a] * nv + j] * r[a];
+        z[j] = hinv[j] * s;
+        zn += z[j] * np_[j];
+        scale += np_[j] * hinv[j] * np_[j];
+      }
+      const int z_is_zero = (q == nv) || !(zn > 1e-13 * scale);
+      /* step lengths */
+      double t1 = INFINITY; int kdrop = -1;
+      for (int a = 0; a < q; ++a) if (r[a] > 0.0) { double tt = wlam[a] / r[a]; if (tt < t1) { t1 = tt; kdrop = a; } }
+      double cp = -beta;
+      for (int j = 0; j < nv; ++j) cp += np_[j] * x[j]; /* < 0: violated */
+      double t2 = z_is_zero ? INFINITY : -cp / zn;
+      if (t2 < 0.0) t2 = 0.0;
+      double tstep = t1 < t2 ? t1 : t2;
+      if (!(tstep < INFINITY)) { status = 2; done_p = 2; break; } /* infeasible */
+      if (!z_is_zero) for (int j = 0; j < nv; ++j) x[j] += tstep * z[j];
+      for (int a = 0; a < q; ++a) wlam[a] -= tstep * r[a];
+      up += tstep;
+      if (!z_is_zero && t2 <= t1) { /* full step: p becomes active */
+        widx[q] = p; wsgn[q] = psgn; wlam[q] = up; ++q;
+        done_p = 1;
+      } else {                       /* partial / dual step: drop kdrop and try again */
+        for (int a = kdrop; a + 1 < q; ++a) { widx[a] = widx[a + 1]; wsgn[a] = wsgn[a + 1]; wlam[a] = wlam[a + 1]; }
+        --q;
+      }
+    }
+    if (done_p == 2) break;
+    if (!done_p) { status = 3; break; }
+  }
+  if (status == 0 && lam_out) {
+    for (int i = 0; i < M; ++i) lam_out[i] = 0.0;
+    for (int a = 0; a < q; ++a) lam_out[widx[a]] += wsgn[a] * wlam[a];
+  }
+  free(nrm);
+  return status;
+}
+
+/* TrajectoryOptimizer.run_joint_min_curvature_qp -- optimizer.py:163-220 (span = 5, :167), with the
+ * window start indices (np.random.randint, :178) supplied by the caller and without the simulator
+ * call (:208-209), whose output never feeds back into the spline.  The window QP
+ * (joint_min_curvature_cost :88-110, joint_track_constraint :112-161) has a diagonal Hessian and
+ * rows that touch either the five x unknowns or the five y unknowns, so it is solved as two
+ * 5-variable QPs.  A window whose QP is infeasible is skipped (:212-214).
+ * n_success[max_iter]: windows updated per outer iteration. */
+void orc_run_joint_min_curvature_qp(const double* t, int nt, double* cx, double* cy, int k,
+                                    double length, double* points, int N,
+                                    const double* ringL, int nL, const double* ringR, int nR,
+                                    const int* i_start, int max_iter, int* n_success) {
+  (void)length;
+  const int span = 5, n = nt - k - 1;
+  double* u = (double*)malloc((size_t)N * sizeof(double));
+  for (int i = 0; i < N; ++i) u[i] = grid_u(i, N);
+  sample_geometry(t, nt, cx, cy, k, u, N, points);
+  orc_fill_bounds(points, N, ringL, nL, ringR, nR, 100.0); /* :166 */
+  double* Ax = (double*)calloc((size_t)N * span, sizeof(double));
+  double* lx = (double*)malloc((size_t)N * 4 * sizeof(double));
+  double *ux = lx + N, *ly = lx + 2 * N, *uy = lx + 3 * N;
+  double* bj = (double*)malloc((size_t)N * sizeof(double));
+  double* ti = (double*)malloc((size_t)N * sizeof(double));
+  for (int it = 0; it < max_iter; ++it) {
+    const int ignore_front = k / 2, ignore_rear = k - ignore_front;
+    const int i_max = n - ignore_rear - span, i_min = ignore_front; /* :172-177 */
+    const int st = i_start[it];
+    int ok = 0;
+    for (int i = 0; i < i_max - i_min; ++i) { /* :180-183 */
+      int kk = i + st;
+      if (kk >= i_max) kk = kk - i_max + i_min;
+      double hx[5], hy[5], gx[5], gy[5], zx[5], zy[5];
+      for (int j = 0; j < span; ++j) { /* joint_min_curvature_cost, :103-108 */
+        double z0[2] = {cx[kk + j], cy[kk + j]}, H[4], g[2];
+        orc_min_curvature_cost(z0, kk + j, t, nt, cx, cy, k, N, H, g);
+        hx[j] = H[0]; hy[j] = H[3]; gx[j] = g[0]; gy[j] = g[1];
+        zx[j] = z0[0]; zy[j] = z0[1];
+      }
+      /* joint_track_constraint, :129-159: dense rows over ALL samples */
+      memset(Ax, 0, (size_t)N * span * sizeof(double));
+      for (int j = 0; j < span; ++j) {
+        int i0, i1;
+        support_range(t, k, kk + j, N, &i0, &i1);
+        int M = i1 - i0;
+        for (int q = 0; q < M; ++q) ti[q] = grid_u(i0 + q, N);
+        if (M > 0) orc_basis_element(t + kk + j, k, ti, M, 0, bj);
+        for (int q = 0; q < M; ++q) Ax[(size_t)(i0 + q) * span + j] = bj[q];
+      }
+      for (int s = 0; s < N; ++s) {
+        const double* p = points + (size_t)s * ORC_NCOL;
+        double azx = 0.0, azy = 0.0;
+        for (int j = 0; j < span; ++j) { azx += Ax[(size_t)s * span + j] * zx[j]; azy += Ax[(size_t)s * span + j] * zy[j]; }
+        double nzx = p[ORC_X] - azx, nzy = p[ORC_Y] - azy; /* :148 */
+        lx[s] = fmin(p[ORC_LBX], p[ORC_RBX]) - nzx; ux[s] = fmax(p[ORC_LBX], p[ORC_RBX]) - nzx;
+        ly[s] = fmin(p[ORC_LBY], p[ORC_RBY]) - nzy; uy[s] = fmax(p[ORC_LBY], p[ORC_RBY]) - nzy;
+      }
+      double nx_[5], ny_[5];
+      if (orc_qp_diag_rows(span, hx, gx, N, Ax, lx, ux, nx_, NULL) != 0) continue; /* :212-214 */
+      if (orc_qp_diag_rows(span, hy, gy, N, Ax, ly, uy, ny_, NULL) != 0) continue;
+      for (int j = 0; j < span; ++j) { cx[kk + j] = nx_[j]; cy[kk + j] = ny_[j]; } /* :200-201 */
+      cx[0] = cx[n - 5]; cy[0] = cy[n - 5];       /* :202-206 */
+      cx[1] = cx[n - 4]; cy[1] = cy[n - 4];
+      cx[n - 3] = cx[2]; cy[n - 3] = cy[2];
+      cx[n - 2] = cx[3]; cy[n - 2] = cy[3];
+      cx[n - 1] = cx[4]; cy[n - 1] = cy[4];
+      sample_geometry(t, nt, cx, cy, k, u, N, points);                 /* :207 */
+      orc_fill_bounds(points, N, ringL, nL, ringR, nR, 100.0);       /* :210 */
+      ++ok;
+    }
+    n_success[it] = ok;
+  }
+  free(ti); free(bj); free(lx); free(Ax); free(u);
+}

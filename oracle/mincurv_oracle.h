@@ -115,6 +115,21 @@ void orc_solve_width_batch(const double* t, int nt, const double* cx0, const dou
 int orc_qss_sim(double* points, int N, const double* acc_x, const double* acc_c, int acc_m,
                 const double* dcc_x, const double* dcc_c, int dcc_m, const double params[6]);
 
+/* Exact solution of  min sum_j 1/2 h_j x_j^2 + g_j x_j  s.t.  l_i <= a_i.x <= u_i  (A is [M][nv]
+ * row-major, nv <= 8) by the Goldfarb-Idnani dual active-set method: the window QP of
+ * run_joint_min_curvature_qp (optimizer.py:185-197), one call per coordinate.
+ * 0 = solved, 2 = infeasible, 3 = bad data.  lam [M] (optional): row multipliers. */
+int orc_qp_diag_rows(int nv, const double* h, const double* g, int M, const double* A,
+                     const double* l, const double* u, double* x, double* lam);
+
+/* TrajectoryOptimizer.run_joint_min_curvature_qp -- optimizer.py:163-220 (span 5), window start
+ * indices supplied by the caller, simulator call (:208-209) omitted (no feedback into the spline).
+ * n_success[max_iter]: windows updated per outer iteration. */
+void orc_run_joint_min_curvature_qp(const double* t, int nt, double* cx, double* cy, int k,
+                                    double length, double* points, int N,
+                                    const double* ringL, int nL, const double* ringR, int nR,
+                                    const int* i_start, int max_iter, int* n_success);
+
 double orc_last_kappa(void);
 void orc_reset_kappa(void);
 

@@ -19,18 +19,46 @@ _ip = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False):
     src = os.path.join(_HERE, "mincurv_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    so = os.path.join(_HERE, "libmincurv_oracle.so")
+    so2 = os.path.join(_HERE, "libmincurv_oracle_fma.so")
+    if force or not os.path.exists(so) or not os.path.exists(so2) or os.path.getmtime(so) < os.path.getmtime(src) \
+            or os.path.getmtime(so2) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-    return _SO
+    return so
 
 
 _lib = None
 
 
+class _Variant:
+    """Context manager: route the wrappers of this module to the FMA-contracted build of the same
+    oracle source (noise-sensitivity diagnostics in the tests)."""
+
+    def __enter__(self):
+        global _lib
+        build()
+        self.saved = _lib
+        _lib = None
+        self.saved_so = globals()["_SO"]
+        globals()["_SO"] = os.path.join(_HERE, "libmincurv_oracle_fma.so")
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        globals()["_SO"] = self.saved_so
+        return False
+
+
+def fma_variant():
+    return _Variant()
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not os.path.exists(_SO):
+            build()
         _lib = ctypes.CDLL(_SO)
         _lib.orc_arc_gk21.restype = ctypes.c_double
         _lib.orc_arc_gk21.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int,
@@ -176,3 +204,30 @@ def qss_sim(points, acc_x, acc_c, dcc_x, dcc_c, params):
     ax, axp = _d(acc_x); ac, acp = _d(acc_c); dx, dxp = _d(dcc_x); dc, dcp = _d(dcc_c); pr, prp = _d(params)
     it = lib().orc_qss_sim(pts.ctypes.data_as(_dp), len(pts), axp, acp, ac.shape[1], dxp, dcp, dc.shape[1], prp)
     return pts, it
+
+
+def qp_diag_rows(h, g, A, l, u):
+    """Goldfarb-Idnani solve of the diagonal-Hessian QP; returns (status, x, lam)."""
+    h, hp = _d(h); g, gp = _d(g); A, ap = _d(A); l, lp = _d(l); u, up = _d(u)
+    M, nv = A.shape
+    x = np.zeros(nv); lam = np.zeros(M)
+    st = lib().orc_qp_diag_rows(int(nv), hp, gp, int(M), ap, lp, up, x.ctypes.data_as(_dp), lam.ctypes.data_as(_dp))
+    return st, x, lam
+
+
+def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None):
+    """Returns (cx, cy, points[N,19], n_success[max_iter])."""
+    t, tp = _d(t)
+    cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
+    ringL, lp = _d(ringL); ringR, rp = _d(ringR)
+    i_start, ip = _i(i_start)
+    max_iter = len(i_start) if max_iter is None else max_iter
+    pts = np.zeros((N, NCOL))
+    lib().orc_trajectory_init(pts.ctypes.data_as(_dp), N)
+    ns = np.zeros(max_iter, dtype=np.int32)
+    f = lib().orc_run_joint_min_curvature_qp
+    f.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp, ctypes.c_int,
+                  _dp, ctypes.c_int, _dp, ctypes.c_int, _ip, ctypes.c_int, _ip]
+    f(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k), float(length),
+      pts.ctypes.data_as(_dp), int(N), lp, len(ringL), rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
+    return cx, cy, pts, ns

@@ -36,6 +36,7 @@ class RlError(RuntimeError):
 _SIGNATURES = {
     "rl_version": (ctypes.c_int, []),
     "rl_last_error": (ctypes.c_char_p, []),
+    "rl_debug_read": (ctypes.c_int, [_dp, ctypes.c_longlong]),
     "rl_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "rl_ctx_destroy": (None, [_vp]),
     "rl_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
@@ -55,6 +56,8 @@ _SIGNATURES = {
     "rl_track_constraint": (ctypes.c_int, [_vp, _vp, _dp, ctypes.c_int, _dp, _dp, _dp, _ip]),
     "rl_mincurv_sweep": (ctypes.c_int, [_vp, _vp, _ip, ctypes.c_int, _dp, _dp, _dp, _ip,
                                         ctypes.POINTER(Stats)]),
+    "rl_mincurv_sweep_joint": (ctypes.c_int, [_vp, _vp, _ip, ctypes.c_int, _dp, _dp, _dp, _ip,
+                                              ctypes.POINTER(Stats)]),
     "rl_mincurv_solve_batch_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _ip,
                                                   ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp,
                                                   ctypes.POINTER(Stats)]),

@@ -270,6 +270,8 @@ __global__ void k_constraint(TrackDev tr, const double* __restrict__ cx,
 
 // ------------------------------------------------------------------------------------------------
 // a12: the sweep.
+constexpr int kJointRowsPerThread = 3;  // sliding-window variant: union of 5 supports <= 3 * 256 samples
+
 struct SweepArgs {
   TrackDev tr;
   int B;
@@ -289,13 +291,14 @@ struct SweepArgs {
   int* status;          // [B] or null
   double* gscratch;     // per-instance global scratch when rings/sigma do not fit LDS
   size_t gscratch_stride;  // doubles per instance
+  double* dbg;          // optional per-window QP dump of instance 0 (joint variant, tests only)
   int debug;            // timing ablations only (RL_DEBUG_FLAGS): results are WRONG when non-zero
 };
 
 // LDS carve (doubles).  cpad = n rounded up to even so every later array is 16-byte aligned.
 struct SweepLds {
   int cpad, nLp, nRp, ncL, ncR;
-  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, total;
+  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, off_joint, total;
 };
 
 __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds) {
@@ -307,11 +310,12 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   size_t o = 0;
   L.off_cx = o; o += L.cpad;
   L.off_cy = o; o += L.cpad;
-  L.off_red = o; o += 16 * 12 + 4;       // up to 16 waves x 12 partials + verdict
+  L.off_red = o; o += 16 * 24 + 4;       // up to 16 waves x 24 partials + verdict
   L.off_cL = o; o += (size_t)((3 * L.ncL + 1) & ~1);
   L.off_cR = o; o += (size_t)((3 * L.ncR + 1) & ~1);
   L.off_pL = o; o += (size_t)((L.ncL + 1) & ~1);
   L.off_pR = o; o += (size_t)((L.ncR + 1) & ~1);
+  L.off_joint = o; o += 128 + (size_t)((N + 15) / 16) * 2;  // joint variant: QP scratch + 1 byte per sample
   L.off_hint = o; o += (size_t)(((size_t)2 * ((N + 3) & ~3) * sizeof(unsigned short) + 15) / 16) * 2;  // u16 [2][Npad]
   if (rings_in_lds) {
     L.off_sL = o; o += (size_t)((N + 1) & ~1);
@@ -325,7 +329,7 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   return L;
 }
 
-template <int K, int BLOCK, bool RINGS_LDS>
+template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false>
 __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
@@ -431,6 +435,26 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     }
   }
 
+  // ---- joint (sliding-window) variant only: QP scratch and, per sample, whether the point lies
+  // outside its own bound box.  joint_track_constraint (optimizer.py:129-159) has a row for EVERY
+  // sample; rows outside the window's support read 0 in [min(L,R) - p, max(L,R) - p], i.e. they make
+  // the QP infeasible as soon as any sample of the track is outside its box.
+  double* jq = smem + L.off_joint;                                    // [128] doubles
+  unsigned char* outside = reinterpret_cast<unsigned char*>(jq + 128);  // [N]
+  int* n_outside = reinterpret_cast<int*>(jq + 127);
+  auto note_outside = [&](int i, double px, double py, double ndx, double ndy, double sl, double sr) {
+    const double Lx = px + sl * ndx, Ly = py + sl * ndy;
+    const double Rx = px + sr * (-ndx), Ry = py + sr * (-ndy);
+    const bool out = fmin(Lx, Rx) > px || fmax(Lx, Rx) < px || fmin(Ly, Ry) > py || fmax(Ly, Ry) < py;
+    const int was = outside[i];
+    if ((int)out != was) { outside[i] = out ? 1 : 0; atomicAdd(n_outside, out ? 1 : -1); }
+  };
+  if (JOINT) {
+    for (int i = tid; i < N; i += BLOCK) outside[i] = 0;
+    if (tid == 0) *n_outside = 0;
+    __syncthreads();
+  }
+
   // refresh(i0,i1,j0,j1): new p, normal and closest ring crossings for the samples of two ranges
   auto refresh = [&](int i0, int i1, int j0, int j1, int mode) {
     const int m0 = i1 - i0, m1 = j1 - j0, m = m0 + m1;
@@ -457,6 +481,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           sR[i] = hr.best_s;
           hints[i] = (unsigned short)(hl.edge == kNoEdge ? 0xFFFF : hl.edge);
           hints[Npad + i] = (unsigned short)(hr.edge == kNoEdge ? 0xFFFF : hr.edge);
+          if (JOINT) note_outside(i, c.x, c.y, dx, dy, hl.best_s, hr.best_s);
         }
       }
       return;
@@ -483,6 +508,17 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
       (side ? sR : sL)[i] = h.best_s;
       hints[side * Npad + i] = (unsigned short)(h.edge == kNoEdge ? 0xFFFF : h.edge);
     }
+    if (JOINT) {  // per-lane search modes: the box flags need both crossings -> second sweep over the samples
+      __syncthreads();
+      for (int r = tid; r < m; r += BLOCK) {
+        const int i = r < m0 ? i0 + r : j0 + (r - m0);
+        CurvePoint<K, 1> c;
+        eval_sample<K, 1>(tr, cx, cy, i, tr.ell[i], c);
+        double dx, dy, inv_s2;
+        scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);
+        note_outside(i, c.x, c.y, dx, dy, sL[i], sR[i]);
+      }
+    }
   };
 
   // the windowed mode needs rings longer than its window and edge indices that fit 16 bits
@@ -503,6 +539,292 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   const double* __restrict__ D2 = tr.D + (size_t)2 * (K + 1) * N;
   int n_skipped = 0;
 
+  if (JOINT) {
+    // ---- TrajectoryOptimizer.run_joint_min_curvature_qp (optimizer.py:163-220), span 5
+    constexpr int SP = 5;
+    const int j_max = n - ignore_rear - SP;  // :176
+    double* jx = jq;            // [SP] current iterate of the QP being solved
+    double* jh = jq + 8;        // [2][SP] Hessian diagonals (x, y)
+    double* jg = jq + 24;       // [2][SP] gradients
+    double* jz = jq + 40;       // [2][SP] control points of the window at entry
+    double* jcand = jq + 56;    // [8]  candidate row: SP coefficients, bound, sign
+    double* jact = jq + 64;     // [SP][8] active rows: SP coefficients (signed), beta, lambda
+    double* jctl = jq + 112;    // [0] verdict / row id, [1] violation, ...
+    for (int it = 0; it < a.max_iter; ++it) {
+      const int st = a.i_start[it];
+      int ok_count = 0;
+      for (int stp = 0; stp < j_max - i_min; ++stp) {  // :180-183
+        int kk = stp + st;
+        if (kk >= j_max) kk = kk - j_max + i_min;
+        const int u0 = tr.sup[2 * kk], u1 = tr.sup[2 * (kk + SP - 1) + 1];  // union of the supports
+        // ---- cost: the five 2x2 diagonal blocks (joint_min_curvature_cost, :103-108)
+        for (int j = 0; j < SP; ++j) {
+          const int idx = kk + j;
+          const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+          const double zx = cx[idx], zy = cy[idx];
+          double hxx = 0.0, hyy = 0.0, gx = 0.0, gy = 0.0;
+          for (int i = s0 + tid; i < s1; i += BLOCK) {
+            const int l = tr.ell[i];
+            CurvePoint<K, 2> c;
+            eval_sample<K, 2>(tr, cx, cy, i, l, c);
+            const double B2 = D2[(size_t)(idx - l + K) * N + i];
+            double ndx, ndy, inv_s2;
+            scaled_normal(c.dx, c.dy, a.max_dist, ndx, ndy, inv_s2);
+            const double inv_den = inv_s2 * inv_s2 * inv_s2;
+            const double Fx = c.d2x - B2 * zx, Fy = c.d2y - B2 * zy;
+            const double Pxx = c.dy * c.dy * inv_den, Pyy = c.dx * c.dx * inv_den;
+            const double Pxy = -2.0 * c.dx * c.dy * inv_den;
+            hxx += B2 * Pxx * B2; hyy += B2 * Pyy * B2; gx += Fx * Pxx * B2;
+            gy += (Fy * Pxy * B2 + Fy * Pyy * B2) + (B2 * Pxy * Fx + Fy * Pyy * B2);
+          }
+          const double v0 = wave_sum(hxx), v1 = wave_sum(hyy), v2 = wave_sum(gx), v3 = wave_sum(gy);
+          if (lane == 0) { double* r = red + wave * 24 + 4 * j; r[0] = v0; r[1] = v1; r[2] = v2; r[3] = v3; }
+        }
+        __syncthreads();
+        if (tid < SP) {
+          double s0_ = 0, s1_ = 0, s2_ = 0, s3_ = 0;
+          for (int w = 0; w < NW; ++w) { const double* r = red + w * 24 + 4 * tid; s0_ += r[0]; s1_ += r[1]; s2_ += r[2]; s3_ += r[3]; }
+          jh[tid] = 2.0 * s0_; jh[SP + tid] = 2.0 * s1_; jg[tid] = s2_ + s2_; jg[SP + tid] = s3_;
+          jz[tid] = cx[kk + tid]; jz[SP + tid] = cy[kk + tid];
+        }
+        __syncthreads();
+        // ---- rows of the union support, two samples per thread at most (joint_track_constraint)
+        constexpr int RPT = kJointRowsPerThread;
+        double ra[RPT][SP], rlx[RPT], rux[RPT], rly[RPT], ruy[RPT], rn[RPT];
+        int n_out_union = 0;
+        bool rows_fit = (u1 - u0) <= RPT * BLOCK;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+          const int i = u0 + tid + q * BLOCK;
+          rn[q] = -1.0;  // no row
+          if (i < u1) {
+            const int l = tr.ell[i];
+            CurvePoint<K, 1> c;
+            eval_sample<K, 1>(tr, cx, cy, i, l, c);
+            double ndx, ndy, inv_s2;
+            scaled_normal(c.dx, c.dy, a.max_dist, ndx, ndy, inv_s2);
+            const double sl = sL[i], sr = sR[i];
+            const double Lx = c.x + sl * ndx, Ly = c.y + sl * ndy;
+            const double Rx = c.x + sr * (-ndx), Ry = c.y + sr * (-ndy);
+            double azx = 0.0, azy = 0.0, nn = 0.0;
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+              const int aa = kk + j - l + K;
+              const double bj = (aa >= 0 && aa <= K) ? D0[(size_t)aa * N + i] : 0.0;
+              ra[q][j] = bj;
+              azx += bj * jz[j]; azy += bj * jz[SP + j];
+              nn += bj * bj;
+            }
+            const double nzx = c.x - azx, nzy = c.y - azy;  // :148
+            rlx[q] = fmin(Lx, Rx) - nzx; rux[q] = fmax(Lx, Rx) - nzx;
+            rly[q] = fmin(Ly, Ry) - nzy; ruy[q] = fmax(Ly, Ry) - nzy;
+            rn[q] = sqrt(nn);
+            n_out_union += outside[i];
+          }
+        }
+        constexpr int DBG_STRIDE = 48 + 9 * kJointRowsPerThread * 256;
+        double* dbg = (a.dbg && b == 0) ? a.dbg + (size_t)(it * (j_max - i_min) + stp) * DBG_STRIDE : nullptr;
+        if (dbg) {
+#pragma unroll
+          for (int q = 0; q < RPT; ++q) {
+            const int r_ = tid + q * BLOCK;
+            if (rn[q] >= 0.0) {
+              double* o = dbg + 48 + 9 * r_;
+              for (int j = 0; j < SP; ++j) o[j] = ra[q][j];
+              o[5] = rlx[q]; o[6] = rux[q]; o[7] = rly[q]; o[8] = ruy[q];
+            }
+          }
+          if (tid == 0) {
+            dbg[0] = kk; dbg[1] = u0; dbg[2] = u1; dbg[3] = *n_outside;
+            for (int j = 0; j < SP; ++j) { dbg[15 + j] = jh[j]; dbg[20 + j] = jh[SP + j]; dbg[25 + j] = jg[j]; dbg[30 + j] = jg[SP + j]; dbg[35 + j] = jz[j]; dbg[40 + j] = jz[SP + j]; }
+          }
+        }
+        // verdict of the zero rows: samples outside the union (their flags) + zero-norm rows inside
+        {
+          int bad = 0;
+#pragma unroll
+          for (int q = 0; q < RPT; ++q)
+            if (rn[q] == 0.0 && (rlx[q] > 0.0 || rux[q] < 0.0 || rly[q] > 0.0 || ruy[q] < 0.0)) bad = 1;
+#pragma unroll
+          for (int q = 0; q < RPT; ++q)
+            if (rn[q] >= 0.0 && (rlx[q] > rux[q] || rly[q] > ruy[q] || !(rlx[q] == rlx[q]) || !(rux[q] == rux[q]) ||
+                                 !(rly[q] == rly[q]) || !(ruy[q] == ruy[q]))) bad = 1;
+          const double wsum = wave_sum((double)n_out_union);
+          const bool wbad = __any(bad);
+          if (lane == 0) { red[wave * 24] = wsum; red[wave * 24 + 1] = wbad ? 1.0 : 0.0; }
+        }
+        __syncthreads();
+        bool feasible = rows_fit;
+        {
+          double in_union = 0.0, bad = 0.0;
+          for (int w = 0; w < NW; ++w) { in_union += red[w * 24]; bad = fmax(bad, red[w * 24 + 1]); }
+          if (bad != 0.0 || (double)(*n_outside) - in_union > 0.5) feasible = false;
+        }
+        __syncthreads();
+        // ---- two 5-variable QPs (x then y), Goldfarb-Idnani dual active set; thread 0 owns the small
+        // linear algebra, every thread scans its rows for the most violated one
+        double newz[2][SP] = {};
+        for (int coord = 0; coord < 2 && feasible; ++coord) {
+          const double* hh = jh + coord * SP;
+          const double* gg = jg + coord * SP;
+          if (tid == 0) {
+            bool okd = true;
+            for (int j = 0; j < SP; ++j) {
+              if (!(hh[j] > 0.0) || !isfinite(hh[j]) || !isfinite(gg[j])) okd = false;
+              jx[j] = okd ? -gg[j] / hh[j] : 0.0;
+            }
+            jctl[2] = okd ? 0.0 : 3.0;  // status: 0 running, 1 solved, 2 infeasible, 3 bad
+            jctl[3] = 0.0;              // q = active rows
+          }
+          __syncthreads();
+          for (int outer = 0; outer < 200 * SP; ++outer) {
+            if (jctl[2] != 0.0) break;
+            // most violated row, normalised (ties: lowest sample, lower bound first)
+            double worst = 1e-10; int wrow = -1, wsgn = 0;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+              if (rn[q] > 0.0) {
+                double ax = 0.0;
+#pragma unroll
+                for (int j = 0; j < SP; ++j) ax += ra[q][j] * jx[j];
+                const double lo_ = coord ? rly[q] : rlx[q], hi_ = coord ? ruy[q] : rux[q];
+                const double vl = (lo_ - ax) / rn[q], vu = (ax - hi_) / rn[q];
+                if (vl > worst) { worst = vl; wrow = tid + q * BLOCK; wsgn = +1; }
+                if (vu > worst) { worst = vu; wrow = tid + q * BLOCK; wsgn = -1; }
+              }
+            }
+            const double wmax = wave_max(worst);
+            // lowest row index among the lanes that hold the wave maximum
+            const double cand_id = (worst == wmax && wrow >= 0) ? (double)wrow : 1e300;
+            const double wid = wave_min(cand_id);
+            if (lane == 0) { red[wave * 24] = wmax; red[wave * 24 + 1] = wid; }
+            __syncthreads();
+            double bmax = 1e-10, bid = 1e300;
+            for (int w = 0; w < NW; ++w) {
+              const double v = red[w * 24], id = red[w * 24 + 1];
+              if (id < 1e299 && (v > bmax || (v == bmax && id < bid))) { bmax = v; bid = id; }
+            }
+            __syncthreads();
+            if (bid > 1e299) {  // nothing violated: optimal
+              if (tid == 0) jctl[2] = 1.0;
+              __syncthreads();
+              break;
+            }
+            if (wrow >= 0 && (double)wrow == bid && worst == bmax) {  // the owner publishes its row
+              const int q = wrow / BLOCK;
+              for (int j = 0; j < SP; ++j) jcand[j] = wsgn * ra[q][j];
+              jcand[5] = wsgn > 0 ? (coord ? rly[q] : rlx[q]) : -(coord ? ruy[q] : rux[q]);  // np.x >= beta
+            }
+            __syncthreads();
+            if (tid == 0) {
+              int q = (int)jctl[3];
+              double up = 0.0;
+              int done_p = 0;
+              for (int inner = 0; inner < 4 * SP + 8 && !done_p; ++inner) {
+                double Mq[SP * SP], r[SP], z[SP];
+                for (int a_ = 0; a_ < q; ++a_) {
+                  for (int b_ = 0; b_ < q; ++b_) {
+                    double s_ = 0.0;
+                    for (int j = 0; j < SP; ++j) s_ += jact[a_ * 8 + j] / hh[j] * jact[b_ * 8 + j];
+                    Mq[a_ * SP + b_] = s_;
+                  }
+                  double s_ = 0.0;
+                  for (int j = 0; j < SP; ++j) s_ += jact[a_ * 8 + j] / hh[j] * jcand[j];
+                  r[a_] = s_;
+                }
+                bool sing = false;
+                for (int c_ = 0; c_ < q; ++c_) {  // Cholesky + two triangular solves
+                  double d = Mq[c_ * SP + c_];
+                  for (int k_ = 0; k_ < c_; ++k_) d -= Mq[c_ * SP + k_] * Mq[c_ * SP + k_];
+                  if (!(d > 0.0)) { sing = true; break; }
+                  d = sqrt(d);
+                  Mq[c_ * SP + c_] = d;
+                  for (int r_ = c_ + 1; r_ < q; ++r_) {
+                    double s_ = Mq[r_ * SP + c_];
+                    for (int k_ = 0; k_ < c_; ++k_) s_ -= Mq[r_ * SP + k_] * Mq[c_ * SP + k_];
+                    Mq[r_ * SP + c_] = s_ / d;
+                  }
+                }
+                if (sing) { jctl[2] = 3.0; done_p = 2; break; }
+                for (int r_ = 0; r_ < q; ++r_) {
+                  double s_ = r[r_];
+                  for (int k_ = 0; k_ < r_; ++k_) s_ -= Mq[r_ * SP + k_] * r[k_];
+                  r[r_] = s_ / Mq[r_ * SP + r_];
+                }
+                for (int r_ = q - 1; r_ >= 0; --r_) {
+                  double s_ = r[r_];
+                  for (int k_ = r_ + 1; k_ < q; ++k_) s_ -= Mq[k_ * SP + r_] * r[k_];
+                  r[r_] = s_ / Mq[r_ * SP + r_];
+                }
+                double zn = 0.0, scale = 0.0, cp = -jcand[5];
+                for (int j = 0; j < SP; ++j) {
+                  double s_ = jcand[j];
+                  for (int a_ = 0; a_ < q; ++a_) s_ -= jact[a_ * 8 + j] * r[a_];
+                  z[j] = s_ / hh[j];
+                  zn += z[j] * jcand[j];
+                  scale += jcand[j] / hh[j] * jcand[j];
+                  cp += jcand[j] * jx[j];
+                }
+                const bool z0_ = (q == SP) || !(zn > 1e-13 * scale);
+                double t1 = INFINITY; int kdrop = -1;
+                for (int a_ = 0; a_ < q; ++a_)
+                  if (r[a_] > 0.0) { const double tt = jact[a_ * 8 + 6] / r[a_]; if (tt < t1) { t1 = tt; kdrop = a_; } }
+                double t2 = z0_ ? INFINITY : -cp / zn;
+                if (t2 < 0.0) t2 = 0.0;
+                const double ts = t1 < t2 ? t1 : t2;
+                if (!(ts < INFINITY)) { jctl[2] = 2.0; done_p = 2; break; }
+                if (!z0_) for (int j = 0; j < SP; ++j) jx[j] += ts * z[j];
+                for (int a_ = 0; a_ < q; ++a_) jact[a_ * 8 + 6] -= ts * r[a_];
+                up += ts;
+                if (!z0_ && t2 <= t1) {
+                  for (int j = 0; j < 6; ++j) jact[q * 8 + j] = jcand[j];
+                  jact[q * 8 + 6] = up;
+                  ++q;
+                  done_p = 1;
+                } else {
+                  for (int a_ = kdrop; a_ + 1 < q; ++a_)
+                    for (int j = 0; j < 7; ++j) jact[a_ * 8 + j] = jact[(a_ + 1) * 8 + j];
+                  --q;
+                }
+              }
+              if (!done_p && jctl[2] == 0.0) jctl[2] = 3.0;
+              jctl[3] = (double)q;
+            }
+            __syncthreads();
+          }
+          if (jctl[2] != 1.0) feasible = false;
+          for (int j = 0; j < SP; ++j) newz[coord][j] = jx[j];
+          __syncthreads();
+        }
+        if (dbg && tid == 0) {
+          dbg[4] = feasible ? 1.0 : 0.0;
+          for (int j = 0; j < SP; ++j) { dbg[5 + j] = newz[0][j]; dbg[10 + j] = newz[1][j]; }
+        }
+        if (feasible) {
+          if (tid == 0) {
+            for (int j = 0; j < SP; ++j) { cx[kk + j] = newz[0][j]; cy[kk + j] = newz[1][j]; }  // :200-201
+            cx[0] = cx[n - 5];     cy[0] = cy[n - 5];                                              // :202-206
+            cx[1] = cx[n - 4];     cy[1] = cy[n - 4];
+            cx[n - 3] = cx[2];     cy[n - 3] = cy[2];
+            cx[n - 2] = cx[3];     cy[n - 2] = cy[3];
+            cx[n - 1] = cx[4];     cy[n - 1] = cy[4];
+          }
+          __syncthreads();
+          // aliases of the window's control points (periodic copies at the other end of the array)
+          int a0 = 0, a1 = 0;
+          if (kk <= 4) { a0 = tr.sup[2 * (max(kk, 2) + n - 5)]; a1 = tr.sup[2 * (min(kk + SP - 1, 4) + n - 5) + 1]; }
+          else if (kk + SP - 1 >= n - 5) { a0 = tr.sup[2 * (max(kk, n - 5) - (n - 5))]; a1 = tr.sup[2 * (min(kk + SP - 1, n - 4) - (n - 5)) + 1]; }
+          refresh(u0, u1, a0, a1, mode);
+          __syncthreads();
+          ++ok_count;
+        } else {
+          ++n_skipped;
+        }
+      }
+      if (tid == 0 && a.n_success) a.n_success[(size_t)b * 2 * a.max_iter + 2 * it] = ok_count;
+      if (tid == 0 && a.n_success) a.n_success[(size_t)b * 2 * a.max_iter + 2 * it + 1] = 0;
+    }
+  } else
   for (int it = 0; it < a.max_iter; ++it) {
     const int st = a.i_start[it];
     for (int pass = 0; pass < 2; ++pass) {

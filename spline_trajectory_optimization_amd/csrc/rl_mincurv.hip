@@ -19,6 +19,8 @@
 namespace {
 
 thread_local std::string g_err;
+double* g_dbg_buf = nullptr;   // RL_DEBUG_DUMP=1: per-window QP dump of the joint variant (tests)
+size_t g_dbg_len = 0;
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -133,9 +135,9 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B) {
   return p;
 }
 
-template <int K, int BLOCK, bool RL>
+template <int K, int BLOCK, bool RL, bool JOINT = false>
 int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
-  auto kern = rl::k_sweep<K, BLOCK, RL>;
+  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT>;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
@@ -143,7 +145,12 @@ int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
   return RL_OK;
 }
 
-int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a) {
+int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false) {
+  if (joint) {
+    if (k != 5) return fail(RL_ERR_UNSUPPORTED, "the sliding-window variant is built for degree 5 (span 5)");
+    return p.rings_in_lds ? launch_sweep_t<5, 256, true, true>(ctx, a, p.lds_bytes)
+                          : launch_sweep_t<5, 256, false, true>(ctx, a, p.lds_bytes);
+  }
   if (k == 5) {
     return p.rings_in_lds ? launch_sweep_t<5, 256, true>(ctx, a, p.lds_bytes)
                           : launch_sweep_t<5, 256, false>(ctx, a, p.lds_bytes);
@@ -157,9 +164,18 @@ int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepAr
 
 }  // namespace
 
+static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter, double* cx, double* cy,
+                        double* points, int* n_success, rl_stats* stats, bool joint);
+
 extern "C" {
 
 int rl_version(void) { return RL_VERSION; }
+
+int rl_debug_read(double* out, long long n) {
+  if (!g_dbg_buf || !out || n < 0 || (size_t)n > g_dbg_len) return fail(RL_ERR_ARG, "no debug dump of that size");
+  RL_HIP(hipMemcpy(out, g_dbg_buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return RL_OK;
+}
 
 const char* rl_last_error(void) { return g_err.c_str(); }
 
@@ -440,17 +456,33 @@ int rl_track_constraint(rl_ctx* ctx, const rl_track* trk, const double* points, 
 static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const double* in_dev,
                               int B, const int* i_start, int max_iter, int search,
                               double* out_ctrl, double* out_xy, double* out_points, int* n_success,
-                              int* status, rl_stats* stats, SweepPlan* plan_out) {
+                              int* status, rl_stats* stats, SweepPlan* plan_out, bool joint = false) {
   if (!ctx || !trk || !i_start || !out_ctrl) return fail(RL_ERR_ARG, "null argument");
   if (!out_xy && !out_points) return fail(RL_ERR_ARG, "need out_xy or out_points");
   if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
   if (max_iter <= 0 || max_iter > RL_MAX_ITER) return fail(RL_ERR_ARG, "max_iter out of range");
   if (search < RL_SEARCH_BRUTE || search > RL_SEARCH_WINDOWED) return fail(RL_ERR_ARG, "bad search mode");
   const int n = trk->n, N = trk->N, k = trk->k;
-  const int i_min = k / 2, i_max = n - (k - k / 2);
+  const int i_min = k / 2, i_max = n - (k - k / 2) - (joint ? 5 : 0);
+  if (i_max <= i_min) return fail(RL_ERR_ARG, "too few control points");
   for (int j = 0; j < max_iter; ++j)
     if (i_start[j] < i_min || i_start[j] >= i_max)
-      return fail(RL_ERR_ARG, "i_start outside [k//2, n-(k-k//2)) (optimizer.py:301-303)");
+      return fail(RL_ERR_ARG, joint ? "i_start outside [k//2, n-(k-k//2)-span) (optimizer.py:176-178)"
+                                    : "i_start outside [k//2, n-(k-k//2)) (optimizer.py:301-303)");
+  if (joint) {  // the window rows live in registers: 3 per thread
+    int widest = 0;
+    const double step = 1.0 / (double)N;
+    for (int kk = i_min; kk < i_max; ++kk) {
+      const double ts = trk->t_host[kk], te = trk->t_host[kk + 4 + k + 1];
+      int a0 = 0;
+      while (a0 < N && !((double)a0 * step >= ts)) ++a0;
+      int b0 = a0;
+      while (b0 < N && (double)b0 * step < te) ++b0;
+      if (b0 - a0 > widest) widest = b0 - a0;
+    }
+    if (widest > rl::kJointRowsPerThread * 256)
+      return fail(RL_ERR_UNSUPPORTED, "sliding-window variant: a window spans more than 768 samples");
+  }
   rl::SweepArgs a;
   std::memset(&a, 0, sizeof(a));
   a.tr = trk->dev();
@@ -473,6 +505,16 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   a.search = search;
   a.max_dist = 100.0;  // race_track.py:104
   if (const char* dbg = getenv("RL_DEBUG_FLAGS")) a.debug = atoi(dbg);
+  if (joint && getenv("RL_DEBUG_DUMP")) {
+    const size_t need = (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256);
+    if (g_dbg_len < need) {
+      if (g_dbg_buf) (void)hipFree(g_dbg_buf);
+      RL_HIP(hipMalloc(reinterpret_cast<void**>(&g_dbg_buf), need * sizeof(double)));
+      g_dbg_len = need;
+    }
+    RL_HIP(hipMemsetAsync(g_dbg_buf, 0, need * sizeof(double), ctx->stream));
+    a.dbg = g_dbg_buf;
+  }
   a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_points = out_points;
   a.n_success = n_success; a.status = status;
   RL_HIP(hipSetDevice(ctx->device));
@@ -490,7 +532,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     stats->rings_in_lds = p.rings_in_lds ? 1 : 0;
   }
   if (plan_out) *plan_out = p;
-  return launch_sweep(ctx, k, p, a);
+  return launch_sweep(ctx, k, p, a, joint);
 }
 
 int rl_mincurv_solve_batch_dev(rl_ctx* ctx, const rl_track* trk, int bounds_form, const double* in,
@@ -540,35 +582,12 @@ int rl_mincurv_solve_batch_host(rl_ctx* ctx, const rl_track* trk, int bounds_for
 
 int rl_mincurv_sweep(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter,
                      double* cx, double* cy, double* points, int* n_success, rl_stats* stats) {
-  if (!ctx || !trk || !cx || !cy) return fail(RL_ERR_ARG, "null argument");
-  RL_HIP(hipSetDevice(ctx->device));
-  const int n = trk->n, N = trk->N;
-  if (int rc = rl_track_set_control_points(trk, cx, cy)) return rc;
-  DevBuf<double> dctrl, dpts;
-  DevBuf<int> dns, dst;
-  RL_HIP(dctrl.alloc((size_t)n * 2)); RL_HIP(dpts.alloc((size_t)N * RL_NCOL));
-  RL_HIP(dns.alloc((size_t)2 * (max_iter > 0 ? max_iter : 1))); RL_HIP(dst.alloc(1));
-  RL_HIP(hipMemsetAsync(dpts.p, 0, dpts.n * sizeof(double), ctx->stream));
-  RL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-  int rc = solve_batch_common(ctx, trk, RL_BOUNDS_SHARED_RINGS, nullptr, 1, i_start, max_iter,
-                              RL_SEARCH_WINDOWED, dctrl.p, nullptr, dpts.p, dns.p, dst.p, stats, nullptr);
-  if (rc) return rc;
-  RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-  std::vector<double> ctrl((size_t)2 * n);
-  RL_HIP(hipMemcpyAsync(ctrl.data(), dctrl.p, ctrl.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (points) RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (n_success) RL_HIP(hipMemcpyAsync(n_success, dns.p, (size_t)2 * max_iter * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  RL_HIP(hipStreamSynchronize(ctx->stream));
-  for (int j = 0; j < n; ++j) { cx[j] = ctrl[2 * j]; cy[j] = ctrl[2 * j + 1]; }
-  if (points) {
-    for (int i = 0; i < N; ++i) { points[(size_t)i * RL_NCOL + 17] = (double)i; points[(size_t)i * RL_NCOL + 18] = -1.0; }
-  }
-  if (stats) {
-    float ms = 0.f;
-    RL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    stats->kernel_ms = ms;
-  }
-  return RL_OK;
+  return sweep_single(ctx, trk, i_start, max_iter, cx, cy, points, n_success, stats, false);
+}
+
+int rl_mincurv_sweep_joint(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter,
+                           double* cx, double* cy, double* points, int* n_success, rl_stats* stats) {
+  return sweep_single(ctx, trk, i_start, max_iter, cx, cy, points, n_success, stats, true);
 }
 
 int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, const double* acc_c,
@@ -606,3 +625,42 @@ int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, c
 }
 
 }  // extern "C"
+
+static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter, double* cx, double* cy,
+                        double* points, int* n_success, rl_stats* stats, bool joint) {
+  if (!ctx || !trk || !cx || !cy) return fail(RL_ERR_ARG, "null argument");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = trk->n, N = trk->N;
+  if (int rc = rl_track_set_control_points(trk, cx, cy)) return rc;
+  DevBuf<double> dctrl, dpts;
+  DevBuf<int> dns, dst;
+  RL_HIP(dctrl.alloc((size_t)n * 2)); RL_HIP(dpts.alloc((size_t)N * RL_NCOL));
+  RL_HIP(dns.alloc((size_t)2 * (max_iter > 0 ? max_iter : 1))); RL_HIP(dst.alloc(1));
+  RL_HIP(hipMemsetAsync(dpts.p, 0, dpts.n * sizeof(double), ctx->stream));
+  RL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = solve_batch_common(ctx, trk, RL_BOUNDS_SHARED_RINGS, nullptr, 1, i_start, max_iter,
+                              RL_SEARCH_WINDOWED, dctrl.p, nullptr, dpts.p, dns.p, dst.p, stats, nullptr, joint);
+  if (rc) return rc;
+  RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  std::vector<double> ctrl((size_t)2 * n);
+  RL_HIP(hipMemcpyAsync(ctrl.data(), dctrl.p, ctrl.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (points) RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int> ns_host((size_t)2 * (max_iter > 0 ? max_iter : 1));
+  RL_HIP(hipMemcpyAsync(ns_host.data(), dns.p, (size_t)2 * max_iter * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  for (int j = 0; j < n; ++j) { cx[j] = ctrl[2 * j]; cy[j] = ctrl[2 * j + 1]; }
+  if (n_success) {  // sweep: [max_iter][fwd,bwd]; sliding window: [max_iter]
+    if (joint) for (int j = 0; j < max_iter; ++j) n_success[j] = ns_host[2 * j];
+    else for (int j = 0; j < 2 * max_iter; ++j) n_success[j] = ns_host[j];
+  }
+  if (points) {
+    for (int i = 0; i < N; ++i) { points[(size_t)i * RL_NCOL + 17] = (double)i; points[(size_t)i * RL_NCOL + 18] = -1.0; }
+  }
+  if (stats) {
+    float ms = 0.f;
+    RL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->kernel_ms = ms;
+  }
+  return RL_OK;
+}
+

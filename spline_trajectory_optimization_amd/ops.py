@@ -97,6 +97,23 @@ def mincurv_sweep(track, cx, cy, i_start, want_points=True):
     return cx, cy, pts, ns.reshape(max_iter, 2), st
 
 
+def mincurv_sweep_joint(track, cx, cy, i_start, want_points=True):
+    """TrajectoryOptimizer.run_joint_min_curvature_qp (optimization/optimizer.py:163-220) for one
+    instance bounded by the track's shared rings.  Returns (cx, cy, points|None, n_success[max_iter], stats)."""
+    ctx = track.ctx
+    cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
+    i_start, ip = as_i(i_start)
+    max_iter = len(i_start)
+    pts = np.zeros((track.N, _lib.NCOL)) if want_points else None
+    ns = np.zeros(max_iter, dtype=np.int32)
+    st = Stats()
+    check(ctx.lib.rl_mincurv_sweep_joint(ctx.h, track.h, ip, max_iter, cx.ctypes.data_as(_dp),
+                                         cy.ctypes.data_as(_dp),
+                                         pts.ctypes.data_as(_dp) if want_points else None,
+                                         ns.ctypes.data_as(_ip), ctypes.byref(st)))
+    return cx, cy, pts, ns, st
+
+
 def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WINDOWED, B=None):
     """Batched sweep with host (numpy) buffers.  bounds: widths [B,N,2] / points [B,N,4] / None.
     Returns (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2], status [B], stats)."""

@@ -143,7 +143,27 @@ class TrajectoryOptimizer:
         return traj_out_s
 
     def run_joint_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, max_iter=3,
-                                   visualize=False):
-        """optimizer.py:163-220 (sliding window, span 5).  Has no caller in the reference tree;
-        the 10-variable window QP kernel is the next row of the build plan."""
-        raise NotImplementedError("run_joint_min_curvature_qp: window-QP kernel not built yet")
+                                   visualize=False, *, i_start=None):
+        """optimizer.py:163-220 (sliding window, span 5) -> ONE launch of the joint sweep kernel.
+        The per-window simulator call (:208-209) never feeds back into the spline and is not run."""
+        traj_out_s = traj_in_s.copy()
+        n = len(traj_out_s._spl_x.c)
+        k = traj_out_s._spl_x.k
+        span = 5
+        i_min, i_max = k // 2, n - (k - k // 2) - span
+        if i_start is None:
+            i_start = []
+            for _ in range(max_iter):
+                i_start.append(int(np.random.randint(i_min, i_max)))  # optimizer.py:178
+                print(f'Starting from {i_start[-1]}-th control point.')
+        i_start = np.asarray(i_start, dtype=np.int32)
+        assert len(i_start) == max_iter
+        trk = self._device_track(traj_out_s, len(traj_in_d))
+        trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
+        t, cx, cy, _ = traj_out_s._tck()
+        cx, cy, pts, ns, stats = ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=True)
+        traj_out_s._spl_x.c[:] = cx
+        traj_out_s._spl_y.c[:] = cy
+        self.last_n_success = ns
+        self.last_stats = stats
+        return traj_out_s
