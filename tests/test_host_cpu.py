@@ -123,3 +123,29 @@ def test_sharded_solve_and_gather_gloo_world2(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GLOO_OK" in out.stdout
+
+
+def test_ttl_and_csv_formats_roundtrip(tmp_path, built):
+    """Wire formats of the reference (models/trajectory.py:202-209, 312-358): Trajectory CSV and the
+    TTL file (header ttl_num,N,length,origin + 17 columns per row) -- host-side, no GPU involved."""
+    from spline_trajectory_optimization_amd.models.trajectory import Trajectory, load_ttl, save_ttl
+    rng = np.random.default_rng(0)
+    tr = Trajectory(7, ttl_num=3, origin=(45.6, 9.28, 180.0))
+    tr.points[:, :17] = rng.normal(size=(7, 17))
+    tr.points[:, Trajectory.REGION] = [0, 1, 2, 0, 1, 2, 3]
+    p = tmp_path / "a.csv"
+    Trajectory.save(str(p), tr)
+    back = Trajectory.load(str(p))
+    np.testing.assert_allclose(back.points, tr.points, rtol=0, atol=0)
+    q = tmp_path / "a.ttl"
+    save_ttl(str(q), tr)
+    lines = open(q).read().splitlines()
+    assert lines[0].split(",")[:2] == ["3", "7"] and len(lines) == 8 and len(lines[1].split(",")) == 17
+    ttl = load_ttl(str(q))
+    assert ttl.ttl_num == 3 and ttl.origin == (45.6, 9.28, 180.0) and len(ttl) == 7
+    np.testing.assert_allclose(ttl.points[:, :17], tr.points[:, :17], rtol=0, atol=0)
+    assert np.all(ttl.points[:, 17] == np.arange(7)) and np.all(ttl.points[:, 18] == -1)
+    # ring helper: a closed polyline keeps one copy of the closing vertex, like shapely's LinearRing
+    from spline_trajectory_optimization_amd.models.race_track import Ring
+    r = Ring(np.array([[0.0, 0], [1, 0], [1, 1], [0, 0]]))
+    assert r.vertices.shape == (3, 2) and r.coords.shape == (4, 2)

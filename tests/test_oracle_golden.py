@@ -235,3 +235,67 @@ def test_g6_qss_simulator():
     bad = pts.copy(); bad[7, 5] = 0.0          # zero turn radius -> seed speed 0
     _, it2 = orc.qss_sim(bad, acc.x, acc.c, dcc.x, dcc.c, g["params"])
     assert it2 == -1
+
+
+def test_qp_diag_rows_kkt_and_feasibility():
+    """The Goldfarb-Idnani solver behind the window QP of run_joint_min_curvature_qp
+    (optimizer.py:188-197): KKT conditions on random problems, and its infeasibility verdicts against an
+    LP feasibility solve (scipy HiGHS)."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(0)
+    n_inf = 0
+    for trial in range(400):
+        nv = int(rng.integers(1, 6)); M = int(rng.integers(1, 40))
+        h = rng.uniform(0.1, 5, nv); g = rng.normal(0, 3, nv)
+        A = rng.normal(0, 1, (M, nv)) * (rng.random((M, nv)) < 0.6)
+        c = A @ rng.normal(0, 1, nv)
+        w = rng.uniform(0, 1.0, M) * (rng.random(M) < 0.9)
+        l = c - w * rng.random(M); u = c + w * rng.random(M)
+        if trial % 7 == 0:
+            l = l + rng.normal(0, 2, M); u = np.maximum(u, l + rng.random(M) * 0.2)
+        st, x, lam = orc.qp_diag_rows(h, g, A, l, u)
+        res = linprog(np.zeros(nv), A_ub=np.vstack([A, -A]), b_ub=np.concatenate([u, -l]), bounds=[(None, None)] * nv)
+        assert (res.status == 0) == (st == 0), trial
+        if st != 0:
+            assert st == 2
+            n_inf += 1
+            continue
+        Ax = A @ x
+        assert np.all(Ax >= l - 1e-8) and np.all(Ax <= u + 1e-8)
+        assert np.abs(h * x + g - A.T @ lam).max() <= 1e-8 * (1 + np.abs(g).max())      # stationarity
+        assert np.all(np.abs(Ax - l)[lam > 1e-12] < 1e-7) and np.all(np.abs(Ax - u)[lam < -1e-12] < 1e-7)
+    assert n_inf > 10
+
+
+def test_g5_joint_assembly(fits, rings):
+    """joint_min_curvature_cost / joint_track_constraint (optimizer.py:88-161) as the oracle's joint
+    driver assembles them, against the reference's own matrices (fixture G5)."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    N = 500
+    g5 = golden("G5_joint.npz")
+    u = np.linspace(0.0, 1.0, N, endpoint=False)
+    pts = orc.sample_along(t, cx, cy, k, length, u)
+    orc.fill_bounds(pts, rings[0], rings[1], 100.0)
+    for st in g5["starts"]:
+        st = int(st)
+        Hd = []; gg = []
+        A = np.zeros((2 * N, 10)); z = np.zeros(10)
+        for j in range(5):
+            H, g_, M = orc.min_curvature_cost([cx[st + j], cy[st + j]], st + j, t, cx, cy, k, N)
+            Hd += [H[0, 0], H[1, 1]]; gg += list(g_)
+            Aj, _, _ = orc.track_constraint(st + j, t, cx, cy, k, pts)
+            m = len(Aj) // 2
+            mask = (u >= t[st + j]) & (u < t[st + j + k + 1])
+            s0 = int(np.argmax(mask))
+            A[2 * s0:2 * (s0 + m):2, 2 * j] = Aj[0::2, 0]; A[2 * s0 + 1:2 * (s0 + m):2, 2 * j + 1] = Aj[1::2, 1]
+            z[2 * j:2 * j + 2] = (cx[st + j], cy[st + j])
+        np.testing.assert_allclose(Hd, g5[f"s{st}_Hdiag"], rtol=1e-10)
+        assert np.all(np.abs(np.array(gg) - g5[f"s{st}_g"]) <= 1e-8 * np.abs(g5[f"s{st}_g"]).max())
+        ref_A = np.zeros_like(A); ref_A[g5[f"s{st}_Arow"], g5[f"s{st}_Acol"]] = g5[f"s{st}_Aval"]
+        np.testing.assert_allclose(A, ref_A, rtol=0, atol=1e-14)
+        non_z = pts[:, :2] - (A @ z).reshape(-1, 2)
+        lba = np.empty(2 * N); uba = np.empty(2 * N)
+        lba[0::2] = np.minimum(pts[:, 9], pts[:, 11]) - non_z[:, 0]; lba[1::2] = np.minimum(pts[:, 10], pts[:, 12]) - non_z[:, 1]
+        uba[0::2] = np.maximum(pts[:, 9], pts[:, 11]) - non_z[:, 0]; uba[1::2] = np.maximum(pts[:, 10], pts[:, 12]) - non_z[:, 1]
+        np.testing.assert_allclose(lba, g5[f"s{st}_lba"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(uba, g5[f"s{st}_uba"], rtol=0, atol=1e-9)
