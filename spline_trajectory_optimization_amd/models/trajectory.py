@@ -1,29 +1,37 @@
 """Host-side mirror of the reference's `spline_traj_optm.models.trajectory`
-(models/trajectory.py:11-358): same class names, attributes, argument order and return types.
+(models/trajectory.py:11-358): same class names, attributes, argument order and return types, own
+implementation.
 
 What runs where
-  * the spline FIT (scipy FITPACK splprep, trajectory.py:219-222) and the total length
-    (scipy quad, :223) are host-side set-up exactly as in the reference;
-  * evaluation, sampling and boundary filling (`eval`, `sample_along`, `fill_bounds`) are HIP
-    kernels behind the C ABI (include/rl_mincurv.h) -- there is no CPU fallback for them.
+  * the spline FIT (scipy FITPACK `splprep`, reference :219-222) and the total length (scipy `quad`,
+    :223) are host-side set-up, as in the reference;
+  * evaluation, sampling and boundary filling (`eval`, `sample_along`, `fill_bounds`) are HIP kernels
+    behind the C ABI (include/rl_mincurv.h) -- there is no CPU fallback for them.
 """
 import copy
 import pickle
 from dataclasses import dataclass
 
 import numpy as np
-from scipy import interpolate
-from scipy.integrate import quad
-from scipy.interpolate import BSpline
+from scipy import integrate, interpolate
 
 from .. import ops
+
+# Column layout of the waypoint table (reference :26-44).  CURVATURE holds the turn RADIUS
+# 1/|kappa| (reference :281); TIME holds per-segment times (reference :172-180).
+_COLUMNS = ("X", "Y", "Z", "YAW", "SPEED", "CURVATURE", "DIST_TO_SF_BWD", "DIST_TO_SF_FWD", "REGION",
+            "LEFT_BOUND_X", "LEFT_BOUND_Y", "RIGHT_BOUND_X", "RIGHT_BOUND_Y", "BANK", "LON_ACC",
+            "LAT_ACC", "TIME", "IDX", "ITERATION_FLAG")
+_NCOL = len(_COLUMNS)
+# the 17 columns a TTL row carries, in file order (reference :326-346)
+_TTL_COLUMNS = _COLUMNS[:17]
 
 
 @dataclass
 class Region:
     name: str
     code: int
-    vertices: np.ndarray  # n * 2
+    vertices: np.ndarray  # [n,2]
 
 
 @dataclass
@@ -41,34 +49,17 @@ def _ring_coords(poly):
 
 
 class Trajectory:
-    # column layout: models/trajectory.py:26-44
-    X = 0
-    Y = 1
-    Z = 2
-    YAW = 3
-    SPEED = 4
-    CURVATURE = 5
-    DIST_TO_SF_BWD = 6
-    DIST_TO_SF_FWD = 7
-    REGION = 8
-    LEFT_BOUND_X = 9
-    LEFT_BOUND_Y = 10
-    RIGHT_BOUND_X = 11
-    RIGHT_BOUND_Y = 12
-    BANK = 13
-    LON_ACC = 14
-    LAT_ACC = 15
-    TIME = 16
-    IDX = 17
-    ITERATION_FLAG = 18
+    """N x 19 float64 waypoint table; the class attributes X, Y, ... are the column indices."""
 
     def __init__(self, num_point: int, ttl_num: int = 0, origin=None) -> None:
         self.ttl_num = ttl_num
         self.origin = origin
-        self.points = np.zeros((num_point, 19), dtype=np.float64)
-        self.points[:, Trajectory.IDX] = np.arange(0, len(self.points), 1)
-        self.points[:, Trajectory.ITERATION_FLAG] = -1
+        table = np.zeros((num_point, _NCOL), dtype=np.float64)
+        table[:, _COLUMNS.index("IDX")] = np.arange(num_point)
+        table[:, _COLUMNS.index("ITERATION_FLAG")] = -1.0
+        self.points = table
 
+    # -- container protocol: everything is delegated to the table
     def __getitem__(self, key):
         return self.points[key]
 
@@ -76,182 +67,179 @@ class Trajectory:
         self.points[key] = val
 
     def __len__(self):
-        return len(self.points)
+        return self.points.shape[0]
 
     def __iter__(self):
-        for pt in self.points:
-            yield pt
+        return iter(self.points)
 
     def copy(self):
-        new_traj = Trajectory(len(self.points))
-        new_traj.points = self.points.copy()
-        return new_traj
+        # like the reference (:66-69), ttl_num / origin are not carried over
+        twin = Trajectory(len(self))
+        twin.points = np.array(self.points, copy=True)
+        return twin
 
     def inc(self, idx: int):
-        return 0 if idx + 1 == len(self.points) else idx + 1
+        return (idx + 1) % len(self)
 
     def dec(self, idx: int):
-        return len(self.points) - 1 if idx - 1 < 0 else idx - 1
-
-    def fill_bounds(self, left_poly, right_poly, max_dist=100.0):
-        """models/trajectory.py:83-141 -> HIP kernel k_fill_bounds (rl_fill_bounds)."""
-        pts = np.ascontiguousarray(self.points, dtype=np.float64)
-        ops.fill_bounds(pts, _ring_coords(left_poly), _ring_coords(right_poly), max_dist)
-        self.points[:, Trajectory.LEFT_BOUND_X:Trajectory.RIGHT_BOUND_Y + 1] = \
-            pts[:, Trajectory.LEFT_BOUND_X:Trajectory.RIGHT_BOUND_Y + 1]
-
-    def fill_distance(self):
-        # models/trajectory.py:143-156 (chord lengths; plain host bookkeeping)
-        xy = self.points[:, :2]
-        dists = np.linalg.norm(xy - np.roll(xy, -1, axis=0), axis=1)
-        self.points[0, Trajectory.DIST_TO_SF_BWD] = 0.0
-        self.points[1:, Trajectory.DIST_TO_SF_BWD] = dists[:-1]
-        self.points[:, Trajectory.DIST_TO_SF_BWD] = np.cumsum(self.points[:, Trajectory.DIST_TO_SF_BWD])
-        self.points[:, Trajectory.DIST_TO_SF_FWD] = np.sum(dists) - self.points[:, Trajectory.DIST_TO_SF_BWD]
-
-    def fill_time(self):
-        # models/trajectory.py:158-180: stores PER-SEGMENT times (the cumulative sum is commented
-        # out in the reference, :179-180) -- reproduced, not fixed.
-        for pt in self.points:
-            # the reference's guard indexes with a boolean by mistake (:161); the intent is kept
-            if pt[Trajectory.SPEED] == 0.0 and pt[Trajectory.LON_ACC] == 0.0:
-                raise Exception("Zero speed and lon_acc encoutered. Cannot fill time.")
-        self.points[0, Trajectory.TIME] = 0.0
-        n = len(self.points)
-        for i in range(n):
-            nxt = 0 if i + 1 == n else i + 1
-            x = self.distance(self.points[i], self.points[nxt])
-            self.points[nxt, Trajectory.TIME] = x / (
-                0.5 * (self.points[i, Trajectory.SPEED] + self.points[nxt, Trajectory.SPEED]))
-
-    def fill_region(self, regions: list):
-        # models/trajectory.py:182-194 (file/region tooling, needs shapely; out of the hot path)
-        from shapely.geometry import Point, Polygon
-        polygons = [(Polygon(r.vertices.tolist()), r.code) for r in regions]
-        for row in self.points:
-            p = Point([row[Trajectory.X], row[Trajectory.Y]])
-            for polygon, code in polygons:
-                if polygon.contains(p):
-                    row[Trajectory.REGION] = code
-                    break
-
-    def distance(self, pt1, pt2):
-        return np.linalg.norm(pt1[Trajectory.X:Trajectory.Y + 1] - pt2[Trajectory.X:Trajectory.Y + 1])
+        return (idx - 1) % len(self)
 
     def ts(self):
-        return np.linspace(0.0, 1.0, self.__len__(), endpoint=False)
+        """Spline parameter of every waypoint: uniform in u, NOT in arc length (reference :199-200)."""
+        return np.linspace(0.0, 1.0, len(self), endpoint=False)
 
+    def distance(self, pt1, pt2):
+        return float(np.hypot(pt1[Trajectory.X] - pt2[Trajectory.X], pt1[Trajectory.Y] - pt2[Trajectory.Y]))
+
+    # -- derived columns
+    def fill_bounds(self, left_poly, right_poly, max_dist=100.0):
+        """Closest crossing of each waypoint's normal with the two boundary rings (reference :83-141)
+        -> HIP kernel k_fill_bounds through rl_fill_bounds."""
+        table = np.ascontiguousarray(self.points, dtype=np.float64)
+        ops.fill_bounds(table, _ring_coords(left_poly), _ring_coords(right_poly), max_dist)
+        cols = slice(Trajectory.LEFT_BOUND_X, Trajectory.RIGHT_BOUND_Y + 1)
+        self.points[:, cols] = table[:, cols]
+
+    def fill_distance(self):
+        """Chord-length distance from / to the start-finish line (reference :143-156)."""
+        xy = self.points[:, :2]
+        chord = np.linalg.norm(np.roll(xy, -1, axis=0) - xy, axis=1)   # waypoint i -> i+1 (cyclic)
+        behind = np.concatenate(([0.0], np.cumsum(chord[:-1])))
+        self.points[:, Trajectory.DIST_TO_SF_BWD] = behind
+        self.points[:, Trajectory.DIST_TO_SF_FWD] = chord.sum() - behind
+
+    def fill_time(self):
+        """Time of every segment at the mean of its end speeds, stored on the segment's END point
+        (reference :158-180: the running sum is commented out there, so TIME is per segment)."""
+        v = self.points[:, Trajectory.SPEED]
+        if np.any((v == 0.0) & (self.points[:, Trajectory.LON_ACC] == 0.0)):
+            raise Exception("Zero speed and lon_acc encoutered. Cannot fill time.")
+        xy = self.points[:, :2]
+        nxt = np.roll(np.arange(len(self)), -1)
+        seg = np.hypot(*(xy[nxt] - xy).T)
+        self.points[0, Trajectory.TIME] = 0.0
+        self.points[nxt, Trajectory.TIME] = seg / (0.5 * (v + v[nxt]))
+
+    def fill_region(self, regions: list):
+        """Tag waypoints with the code of the first region polygon containing them (reference
+        :182-194; file tooling, needs shapely)."""
+        from shapely.geometry import Point, Polygon
+        shapes = [(Polygon(np.asarray(r.vertices).tolist()), r.code) for r in regions]
+        for row in self.points:
+            here = Point(row[Trajectory.X], row[Trajectory.Y])
+            code = next((c for poly, c in shapes if poly.contains(here)), None)
+            if code is not None:
+                row[Trajectory.REGION] = code
+
+    # -- plain CSV of the whole table (reference :202-209); called on the class, like the reference
     def save(f, traj):
         np.savetxt(f, traj.points, delimiter=',')
 
     def load(f):
-        arr = np.loadtxt(f, np.float64, delimiter=',')
-        traj = Trajectory(len(arr))
-        traj.points = arr
+        table = np.loadtxt(f, np.float64, delimiter=',')
+        traj = Trajectory(len(table))
+        traj.points = table
         return traj
 
 
+for _i, _name in enumerate(_COLUMNS):   # Trajectory.X = 0, Trajectory.Y = 1, ...
+    setattr(Trajectory, _name, _i)
+
+
 class BSplineTrajectory:
+    """Closed parametric B-spline (x(u), y(u)), u in [0,1), fitted with FITPACK.  `_spl_x`/`_spl_y`
+    are scipy BSpline objects sharing one knot vector, as in the reference: the optimiser reaches into
+    their `.t`, `.c` (mutable) and `.k`."""
+
     def __init__(self, coordinates: np.ndarray, s: float, k: int):
-        assert coordinates.shape[0] >= 3 and coordinates.shape[1] == 2 and len(
-            coordinates.shape) == 2, "coordinates should be N * 2"
-        # close the loop (models/trajectory.py:217-218) and fit (host set-up, :219-222)
-        closed = np.vstack([coordinates, coordinates[0, np.newaxis, :]])
-        tck, u = interpolate.splprep([closed[:, 0], closed[:, 1]], s=s, per=True, k=k)
-        self._spl_x = BSpline(tck[0], tck[1][0], tck[2])
-        self._spl_y = BSpline(tck[0], tck[1][1], tck[2])
-        self._length = self.__get_section_length(0.0, 1.0)
+        pts = np.asarray(coordinates)
+        assert pts.ndim == 2 and pts.shape[1] == 2 and pts.shape[0] >= 3, "coordinates should be N * 2"
+        loop = np.vstack([pts, pts[:1]])                       # repeat the first point: closed loop
+        (knots, coefs, degree), _ = interpolate.splprep([loop[:, 0], loop[:, 1]], s=s, per=True, k=k)
+        self._spl_x = interpolate.BSpline(knots, coefs[0], degree)
+        self._spl_y = interpolate.BSpline(knots, coefs[1], degree)
+        self._length = self.eval_sectional_length((0.0, 1.0))
 
-    # -- host set-up helpers (scipy, as in the reference :225-245)
-    def __integrate_length(self, t: float):
-        return np.sqrt(interpolate.splev(t, self._spl_x, der=1) ** 2 +
-                       interpolate.splev(t, self._spl_y, der=1) ** 2)
-
-    def __get_section_length(self, t_min: float, t_max: float):
-        length, err = quad(self.__integrate_length, t_min, t_max, limit=1000)
-        return length
+    # -- host set-up: arc length by adaptive quadrature of |r'(u)| (reference :225-233)
+    def _speed(self, u):
+        return np.hypot(interpolate.splev(u, self._spl_x, der=1), interpolate.splev(u, self._spl_y, der=1))
 
     def eval_sectional_length(self, ts):
-        return self.__get_section_length(ts[0], ts[1])
+        length, _ = integrate.quad(self._speed, ts[0], ts[1], limit=1000)
+        return length
+
+    def get_length(self):
+        return self._length
 
     def _tck(self):
-        return (np.ascontiguousarray(self._spl_x.t, dtype=np.float64),
-                np.ascontiguousarray(self._spl_x.c, dtype=np.float64),
-                np.ascontiguousarray(self._spl_y.c, dtype=np.float64), int(self._spl_x.k))
+        as_c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        return as_c(self._spl_x.t), as_c(self._spl_x.c), as_c(self._spl_y.c), int(self._spl_x.k)
 
     # -- HIP-backed evaluation
     def eval(self, t, der=0):
-        """models/trajectory.py:247-248 -> rl_spline_eval."""
-        t_arr = np.atleast_1d(np.asarray(t, dtype=np.float64))
-        tt, cx, cy, k = self._tck()
+        """(x, y) or their der-th derivatives at t (reference :247-248) -> rl_spline_eval."""
         if der > 2:
             raise ValueError("der > 2 is not on the min-curvature path")
-        out = ops.spline_eval(tt, cx, cy, k, t_arr, der_max=der)
-        x, y = out[2 * der], out[2 * der + 1]
-        if np.ndim(t) == 0:
-            return np.float64(x[0]), np.float64(y[0])
-        return x, y
+        u = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        knots, cx, cy, k = self._tck()
+        rows = ops.spline_eval(knots, cx, cy, k, u, der_max=der)
+        x, y = rows[2 * der], rows[2 * der + 1]
+        return (np.float64(x[0]), np.float64(y[0])) if np.ndim(t) == 0 else (x, y)
 
     def eval_yaw(self, t):
         dx, dy = self.eval(t, 1)
         return np.arctan2(dy, dx)
 
-    def get_length(self):
-        return self._length
-
-    def sample_along(self, interval: float = None, ts=None) -> Trajectory:
-        """models/trajectory.py:268-291 -> rl_sample_along (k_sample_geometry + k_sample_cumsum)."""
+    def sample_along(self, interval: float = None, ts=None) -> "Trajectory":
+        """Fresh Trajectory with X, Y, YAW, turn radius and cumulative arc length at the given
+        parameters, or every ~`interval` metres (reference :268-291) -> rl_sample_along."""
         if interval is not None:
-            total_length = self.get_length()
-            num_sample = int(total_length // interval)
-            ts = np.linspace(0.0, 1.0, num_sample, endpoint=False)
-        ts = np.ascontiguousarray(ts, dtype=np.float64)
-        traj = Trajectory(len(ts))
-        tt, cx, cy, k = self._tck()
-        traj.points = ops.sample_along(tt, cx, cy, k, self._length, ts)
+            ts = np.linspace(0.0, 1.0, int(self._length // interval), endpoint=False)
+        u = np.ascontiguousarray(ts, dtype=np.float64)
+        knots, cx, cy, k = self._tck()
+        traj = Trajectory(len(u))
+        traj.points = ops.sample_along(knots, cx, cy, k, self._length, u)
         return traj
 
     def copy(self):
         return copy.deepcopy(self)
 
     def set_control_point(self, idx, coord):
-        self._spl_x.c[idx] = coord[0]
-        self._spl_y.c[idx] = coord[1]
+        self._spl_x.c[idx], self._spl_y.c[idx] = coord[0], coord[1]
 
     def get_control_point(self, idx):
         return self._spl_x.c[idx], self._spl_y.c[idx]
 
+    # pickle round trip (reference :303-309); called on the class
     def save(f, traj):
-        with open(f, "wb") as output_file:
-            pickle.dump(traj, output_file)
+        with open(f, "wb") as fh:
+            pickle.dump(traj, fh)
 
     def load(f):
-        with open(f, "rb") as input_file:
-            return pickle.load(input_file)
+        with open(f, "rb") as fh:
+            return pickle.load(fh)
 
 
 def save_ttl(ttl_path: str, trajectory: Trajectory):
-    """models/trajectory.py:312-347 (TTL csv: header ttl_num,N,length[,origin] + 17 columns/row)."""
-    with open(ttl_path, "w") as f:
-        header = ",".join([str(trajectory.ttl_num), str(len(trajectory)),
-                           str(trajectory[0, Trajectory.DIST_TO_SF_FWD])])
-        if trajectory.origin is not None:
-            header += "," + ",".join([str(x) for x in trajectory.origin])
-        f.write(header + "\n")
+    """TTL file (reference :312-347): header `ttl_num,N,track_length[,origin...]`, then 17 columns per
+    waypoint with REGION written as an integer."""
+    head = [trajectory.ttl_num, len(trajectory), trajectory[0, Trajectory.DIST_TO_SF_FWD]]
+    if trajectory.origin is not None:
+        head += list(trajectory.origin)
+    region = _TTL_COLUMNS.index("REGION")
+    with open(ttl_path, "w") as out:
+        out.write(",".join(str(h) for h in head) + "\n")
         for row in trajectory.points:
-            vals = [str(row[c]) for c in range(Trajectory.X, Trajectory.REGION)]
-            vals.append(str(int(row[Trajectory.REGION])))
-            vals += [str(row[c]) for c in range(Trajectory.LEFT_BOUND_X, Trajectory.TIME + 1)]
-            f.write(",".join(vals) + "\n")
+            cells = [str(int(v)) if c == region else str(v) for c, v in enumerate(row[:len(_TTL_COLUMNS)])]
+            out.write(",".join(cells) + "\n")
 
 
 def load_ttl(ttl_path: str) -> Trajectory:
-    """models/trajectory.py:350-358."""
-    with open(ttl_path, "r") as f:
-        header = f.readline().split(",")
-        assert len(header) >= 6
-    data = np.loadtxt(ttl_path, dtype=float, delimiter=",", skiprows=1)
-    trajectory = Trajectory(len(data), int(header[0]),
-                            (float(header[3]), float(header[4]), float(header[5])))
-    trajectory.points[:, :data.shape[1]] = data
-    return trajectory
+    """Inverse of save_ttl (reference :350-358); the header must carry the 3-value origin."""
+    with open(ttl_path, "r") as src:
+        head = src.readline().strip().split(",")
+    assert len(head) >= 6
+    body = np.atleast_2d(np.loadtxt(ttl_path, dtype=float, delimiter=",", skiprows=1))
+    traj = Trajectory(len(body), int(head[0]), tuple(float(h) for h in head[3:6]))
+    traj.points[:, :body.shape[1]] = body
+    return traj
