@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-instances", type=int, default=8)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST HOOK: all ranks use cuda:0 and the gloo backend (exercises the N>1 code path "
+                         "on a single-GPU box; the numbers are meaningless)")
     args = ap.parse_args()
 
     import torch
@@ -70,14 +73,19 @@ def main():
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as ge
-    if local_rank == 0:
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         ge.build_hip()          # the .so normally ships prebuilt; never let N ranks race on hipcc
     if world > 1:
         dist.barrier()
