@@ -930,3 +930,267 @@ void orc_run_joint_min_curvature_qp(const double* t, int nt, double* cx, double*
   }
   free(ti); free(bj); free(lx); free(Ax); free(u);
 }
+
+/* ---------------------------------------------------------------- global min-curvature QP (own formulation) */
+
+/* NOT a restatement of reference code: the reference's only global formulation is the Julia notebook
+ * prototype (julia/spline_traj_opt.ipynb cells 6/8/9), which uses the wrong basis in the cost, drops
+ * the linear term and does not converge in its own recorded output.  This is the
+ * build's well-posed counterpart, the CPU twin of the HIP kernel k_global_qp, kept here so that the
+ * GPU result has an independent check:
+ *
+ *   unknowns   a_j, j < n_p = n - k : periodic control point j moves along the fixed unit normal nu_j
+ *              of the centre line at its Greville site:  c_j = c0_j + a_j nu_j
+ *   constraint the lateral offset of every sample from the centre line stays inside the track:
+ *              -(w_R,i - margin) <= n0_i . (r_i(a) - p0_i) <= w_L,i - margin         (linear in a)
+ *   cost       sum_i kappa_i(a)^2, Gauss-Newton: kappa linearised at the current a (full derivative,
+ *              speed term included), a few outer re-linearisations
+ *   QP solve   Mehrotra predictor-corrector interior point, one common primal/dual step; the normal
+ *              matrix P + A' D A is n_p x n_p, symmetric positive definite and cyclic-banded
+ *              (half-bandwidth k) because every row touches the k+1 control points of one knot span.
+ * stats[0] = total interior-point iterations, [1] = initial sum kappa^2, [2] = final sum kappa^2,
+ * [3] = largest bound violation of the final line [m], [4] = last outer step max|delta a| [m]. */
+
+static void spd_factor_dense(int n, double* K) { /* in-place lower Cholesky, row-major */
+  for (int c = 0; c < n; ++c) {
+    double d = K[c * n + c];
+    for (int q = 0; q < c; ++q) d -= K[c * n + q] * K[c * n + q];
+    d = sqrt(d);
+    K[c * n + c] = d;
+    for (int r = c + 1; r < n; ++r) {
+      double s = K[r * n + c];
+      for (int q = 0; q < c; ++q) s -= K[r * n + q] * K[c * n + q];
+      K[r * n + c] = s / d;
+    }
+  }
+}
+static void spd_solve_dense(int n, const double* Lm, double* b) {
+  for (int r = 0; r < n; ++r) {
+    double s = b[r];
+    for (int q = 0; q < r; ++q) s -= Lm[r * n + q] * b[q];
+    b[r] = s / Lm[r * n + r];
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double s = b[r];
+    for (int q = r + 1; q < n; ++q) s -= Lm[q * n + r] * b[q];
+    b[r] = s / Lm[r * n + r];
+  }
+}
+
+int orc_global_mincurv(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
+                       const double* w_left, const double* w_right, double margin, int n_outer,
+                       double* out_cx, double* out_cy, double* out_xy, double* out_a, double* stats) {
+  const int n = nt - k - 1, np_ = n - k, K1 = k + 1;
+  if (np_ < 2 * K1 || k > ORC_MAXK) return -1;
+  int* ell = (int*)malloc((size_t)N * sizeof(int));
+  double* D = (double*)malloc((size_t)3 * K1 * N * sizeof(double));
+  double work[2 * ORC_MAXK + 2];
+  for (int i = 0; i < N; ++i) {
+    const double u = grid_u(i, N);
+    ell[i] = find_interval(t, nt, k, u);
+    for (int m = 0; m < 3; ++m) {
+      deboor_d(t, u, k, ell[i], m, work);
+      for (int a = 0; a < K1; ++a) D[((size_t)m * K1 + a) * N + i] = work[a];
+    }
+  }
+#define DD(m, a, i) D[((size_t)(m) * K1 + (a)) * N + (i)]
+#define JH(i, a) ((ell[i] - k + (a)) >= np_ ? (ell[i] - k + (a)) - np_ : (ell[i] - k + (a)))
+  /* control-point normals at the Greville sites */
+  double* nu = (double*)malloc((size_t)np_ * 2 * sizeof(double));
+  for (int j = 0; j < np_; ++j) {
+    double g = 0.0;
+    for (int q = 1; q <= k; ++q) g += t[j + q];
+    g /= (double)k;
+    g -= floor(g);
+    double dx, dy;
+    orc_bspline_eval(t, nt, cx0, k, &g, 1, 1, &dx);
+    orc_bspline_eval(t, nt, cy0, k, &g, 1, 1, &dy);
+    const double s = sqrt(dx * dx + dy * dy);
+    nu[2 * j] = -dy / s; nu[2 * j + 1] = dx / s;
+  }
+  /* centre line samples, normals, constraint rows and bounds */
+  double* p0 = (double*)malloc((size_t)N * 4 * sizeof(double)); /* p0x p0y n0x n0y */
+  double* A = (double*)malloc((size_t)N * K1 * sizeof(double));
+  double* G = (double*)malloc((size_t)N * K1 * sizeof(double));
+  double* kap = (double*)malloc((size_t)N * sizeof(double));
+  double* lo = (double*)malloc((size_t)N * 10 * sizeof(double));
+  double *hi = lo + N, *sl = lo + 2 * N, *su = lo + 3 * N, *ll = lo + 4 * N, *lu = lo + 5 * N;
+  double *dsl = lo + 6 * N, *dsu = lo + 7 * N, *dll = lo + 8 * N, *dlu = lo + 9 * N;
+  for (int i = 0; i < N; ++i) {
+    double x = 0, y = 0, dx = 0, dy = 0;
+    for (int a = 0; a < K1; ++a) {
+      const int j = ell[i] - k + a;
+      x += cx0[j] * DD(0, a, i); y += cy0[j] * DD(0, a, i);
+      dx += cx0[j] * DD(1, a, i); dy += cy0[j] * DD(1, a, i);
+    }
+    const double s = sqrt(dx * dx + dy * dy);
+    p0[4 * i] = x; p0[4 * i + 1] = y; p0[4 * i + 2] = -dy / s; p0[4 * i + 3] = dx / s;
+    for (int a = 0; a < K1; ++a) {
+      const int j = JH(i, a);
+      A[(size_t)i * K1 + a] = DD(0, a, i) * (p0[4 * i + 2] * nu[2 * j] + p0[4 * i + 3] * nu[2 * j + 1]);
+    }
+    lo[i] = -(w_right[i] - margin);
+    hi[i] = w_left[i] - margin;
+  }
+  double* av = (double*)calloc((size_t)np_, sizeof(double));   /* current a */
+  double* xv = (double*)malloc((size_t)np_ * 6 * sizeof(double));
+  double *rd = xv + np_, *rhs = xv + 2 * np_, *dxa = xv + 3 * np_, *qv = xv + 4 * np_, *dxc = xv + 5 * np_;
+  double* P = (double*)malloc((size_t)np_ * np_ * 2 * sizeof(double));
+  double* Kq = P + (size_t)np_ * np_;
+  double* cx = (double*)malloc((size_t)n * 2 * sizeof(double));
+  double* cy = cx + n;
+  double k2_first = 0.0, k2_last = 0.0, last_step = 0.0;
+  int total_it = 0;
+  for (int outer = 0; outer <= n_outer; ++outer) {
+    /* current control points and the curvature rows at them */
+    for (int j = 0; j < n; ++j) {
+      const int jj = j >= np_ ? j - np_ : j;
+      cx[j] = cx0[jj] + av[jj] * nu[2 * jj];
+      cy[j] = cy0[jj] + av[jj] * nu[2 * jj + 1];
+    }
+    double k2 = 0.0;
+    for (int i = 0; i < N; ++i) {
+      double dx = 0, dy = 0, ddx = 0, ddy = 0;
+      for (int a = 0; a < K1; ++a) {
+        const int j = ell[i] - k + a;
+        dx += cx[j] * DD(1, a, i); dy += cy[j] * DD(1, a, i);
+        ddx += cx[j] * DD(2, a, i); ddy += cy[j] * DD(2, a, i);
+      }
+      const double s2 = dx * dx + dy * dy, inv3 = 1.0 / (s2 * sqrt(s2));
+      const double kp = (dx * ddy - dy * ddx) * inv3;
+      kap[i] = kp;
+      k2 += kp * kp;
+      for (int a = 0; a < K1; ++a) {
+        const int j = JH(i, a);
+        const double nx = nu[2 * j], ny = nu[2 * j + 1], b1 = DD(1, a, i), b2 = DD(2, a, i);
+        G[(size_t)i * K1 + a] = ((b1 * nx) * ddy + dx * (b2 * ny) - (b1 * ny) * ddx - dy * (b2 * nx)) * inv3 -
+                                3.0 * kp * (dx * b1 * nx + dy * b1 * ny) / s2;
+      }
+    }
+    if (outer == 0) k2_first = k2;
+    k2_last = k2;
+    if (outer == n_outer) break;
+    /* QP data: P = sc 2 G'G + eps I,  q = sc 2 G'(kap - G a) */
+    memset(P, 0, (size_t)np_ * np_ * sizeof(double));
+    memset(qv, 0, (size_t)np_ * sizeof(double));
+    for (int i = 0; i < N; ++i) {
+      double ga = 0.0;
+      for (int a = 0; a < K1; ++a) ga += G[(size_t)i * K1 + a] * av[JH(i, a)];
+      for (int a = 0; a < K1; ++a) {
+        const int ja = JH(i, a);
+        qv[ja] += 2.0 * G[(size_t)i * K1 + a] * (kap[i] - ga);
+        for (int b = 0; b < K1; ++b) P[(size_t)ja * np_ + JH(i, b)] += 2.0 * G[(size_t)i * K1 + a] * G[(size_t)i * K1 + b];
+      }
+    }
+    double tr = 0.0;
+    for (int j = 0; j < np_; ++j) tr += P[(size_t)j * np_ + j];
+    const double sc = (double)np_ / tr;
+    for (int j = 0; j < np_ * np_; ++j) P[j] *= sc;
+    for (int j = 0; j < np_; ++j) { P[(size_t)j * np_ + j] += 1e-9; qv[j] *= sc; }
+    /* interior point from x = a */
+    memcpy(xv, av, (size_t)np_ * sizeof(double));
+    for (int i = 0; i < N; ++i) {
+      double ax = 0.0;
+      for (int a = 0; a < K1; ++a) ax += A[(size_t)i * K1 + a] * xv[JH(i, a)];
+      sl[i] = fmax(ax - lo[i], 1e-2); su[i] = fmax(hi[i] - ax, 1e-2); ll[i] = 1.0; lu[i] = 1.0;
+    }
+    double qinf = 0.0;
+    for (int j = 0; j < np_; ++j) qinf = fmax(qinf, fabs(qv[j]));
+    for (int it = 0; it < 80; ++it) {
+      /* residuals */
+      double mu = 0.0, rpmax = 0.0;
+      for (int j = 0; j < np_; ++j) {
+        double s = qv[j];
+        for (int q = 0; q < np_; ++q) s += P[(size_t)j * np_ + q] * xv[q];
+        rd[j] = s;
+      }
+      for (int i = 0; i < N; ++i) {
+        double ax = 0.0;
+        for (int a = 0; a < K1; ++a) ax += A[(size_t)i * K1 + a] * xv[JH(i, a)];
+        const double rpl = ax - lo[i] - sl[i], rpu = hi[i] - ax - su[i];
+        rpmax = fmax(rpmax, fmax(fabs(rpl), fabs(rpu)));
+        mu += sl[i] * ll[i] + su[i] * lu[i];
+        for (int a = 0; a < K1; ++a) rd[JH(i, a)] += A[(size_t)i * K1 + a] * (lu[i] - ll[i]);
+      }
+      mu /= (double)(2 * N);
+      double rdmax = 0.0;
+      for (int j = 0; j < np_; ++j) rdmax = fmax(rdmax, fabs(rd[j]));
+      if (fmax(rdmax / (1.0 + qinf), rpmax) < 1e-9 && mu < 1e-10) break;
+      ++total_it;
+      /* normal matrix */
+      memcpy(Kq, P, (size_t)np_ * np_ * sizeof(double));
+      for (int i = 0; i < N; ++i) {
+        const double dm = ll[i] / sl[i] + lu[i] / su[i];
+        for (int a = 0; a < K1; ++a)
+          for (int b = 0; b < K1; ++b)
+            Kq[(size_t)JH(i, a) * np_ + JH(i, b)] += dm * A[(size_t)i * K1 + a] * A[(size_t)i * K1 + b];
+      }
+      spd_factor_dense(np_, Kq);
+      double alpha = 1.0, sigma = 0.0;
+      for (int pass = 0; pass < 2; ++pass) {
+        /* rhs = -rd + A'[(-rcl - ll rpl)/sl] - A'[(-rcu - lu rpu)/su] */
+        double* dxv = pass == 0 ? dxa : dxc;
+        for (int j = 0; j < np_; ++j) rhs[j] = -rd[j];
+        for (int i = 0; i < N; ++i) {
+          double ax = 0.0;
+          for (int a = 0; a < K1; ++a) ax += A[(size_t)i * K1 + a] * xv[JH(i, a)];
+          const double rpl = ax - lo[i] - sl[i], rpu = hi[i] - ax - su[i];
+          double rcl = sl[i] * ll[i], rcu = su[i] * lu[i];
+          if (pass == 1) { rcl += -sigma * mu + dsl[i] * dll[i]; rcu += -sigma * mu + dsu[i] * dlu[i]; }
+          const double wv = (-rcl - ll[i] * rpl) / sl[i] - (-rcu - lu[i] * rpu) / su[i];
+          for (int a = 0; a < K1; ++a) rhs[JH(i, a)] += A[(size_t)i * K1 + a] * wv;
+        }
+        memcpy(dxv, rhs, (size_t)np_ * sizeof(double));
+        spd_solve_dense(np_, Kq, dxv);
+        double amin = 1.0, mu_aff = 0.0;
+        for (int i = 0; i < N; ++i) {
+          double ax = 0.0, adx = 0.0;
+          for (int a = 0; a < K1; ++a) { ax += A[(size_t)i * K1 + a] * xv[JH(i, a)]; adx += A[(size_t)i * K1 + a] * dxv[JH(i, a)]; }
+          const double rpl = ax - lo[i] - sl[i], rpu = hi[i] - ax - su[i];
+          double rcl = sl[i] * ll[i], rcu = su[i] * lu[i];
+          if (pass == 1) { rcl += -sigma * mu + dsl[i] * dll[i]; rcu += -sigma * mu + dsu[i] * dlu[i]; }
+          const double d_sl = adx + rpl, d_su = -adx + rpu;
+          const double d_ll = (-rcl - ll[i] * d_sl) / sl[i], d_lu = (-rcu - lu[i] * d_su) / su[i];
+          /* step to the boundary */
+          if (d_sl < 0.0) amin = fmin(amin, 0.995 * (-sl[i] / d_sl));
+          if (d_su < 0.0) amin = fmin(amin, 0.995 * (-su[i] / d_su));
+          if (d_ll < 0.0) amin = fmin(amin, 0.995 * (-ll[i] / d_ll));
+          if (d_lu < 0.0) amin = fmin(amin, 0.995 * (-lu[i] / d_lu));
+          /* pass 0: affine deltas (the corrector's second-order term); pass 1: the deltas of the step.
+           * This row's affine values were read a few lines above, so overwriting them here is safe. */
+          dsl[i] = d_sl; dsu[i] = d_su; dll[i] = d_ll; dlu[i] = d_lu;
+        }
+        alpha = amin;
+        if (pass == 0) {
+          for (int i = 0; i < N; ++i)
+            mu_aff += (sl[i] + alpha * dsl[i]) * (ll[i] + alpha * dll[i]) + (su[i] + alpha * dsu[i]) * (lu[i] + alpha * dlu[i]);
+          mu_aff /= (double)(2 * N);
+          const double r = mu_aff / mu;
+          sigma = r * r * r;
+        }
+      }
+      for (int j = 0; j < np_; ++j) xv[j] += alpha * dxc[j];
+      for (int i = 0; i < N; ++i) {
+        sl[i] += alpha * dsl[i]; su[i] += alpha * dsu[i]; ll[i] += alpha * dll[i]; lu[i] += alpha * dlu[i];
+      }
+    }
+    last_step = 0.0;
+    for (int j = 0; j < np_; ++j) { last_step = fmax(last_step, fabs(xv[j] - av[j])); av[j] = xv[j]; }
+  }
+  /* outputs */
+  double viol = 0.0;
+  for (int i = 0; i < N; ++i) {
+    double x = 0, y = 0;
+    for (int a = 0; a < K1; ++a) { const int j = ell[i] - k + a; x += cx[j] * DD(0, a, i); y += cy[j] * DD(0, a, i); }
+    if (out_xy) { out_xy[2 * i] = x; out_xy[2 * i + 1] = y; }
+    const double lat = (x - p0[4 * i]) * p0[4 * i + 2] + (y - p0[4 * i + 1]) * p0[4 * i + 3];
+    viol = fmax(viol, fmax(lo[i] - lat, lat - hi[i]));
+  }
+  for (int j = 0; j < n; ++j) { out_cx[j] = cx[j]; out_cy[j] = cy[j]; }
+  if (out_a) memcpy(out_a, av, (size_t)np_ * sizeof(double));
+  if (stats) { stats[0] = (double)total_it; stats[1] = k2_first; stats[2] = k2_last; stats[3] = viol; stats[4] = last_step; }
+#undef DD
+#undef JH
+  free(cx); free(P); free(xv); free(av); free(lo); free(kap); free(G); free(A); free(p0); free(nu); free(D); free(ell);
+  return 0;
+}

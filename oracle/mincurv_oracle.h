@@ -130,6 +130,14 @@ void orc_run_joint_min_curvature_qp(const double* t, int nt, double* cx, double*
                                     const double* ringL, int nL, const double* ringR, int nR,
                                     const int* i_start, int max_iter, int* n_success);
 
+/* Global min-curvature QP on lateral control-point offsets -- the build's OWN formulation (the
+ * reference has none that works: SURVEY.md App. A.6), CPU twin of the HIP kernel k_global_qp.
+ * See the comment block in mincurv_oracle.c.  w_left / w_right [N]: half-widths per sample;
+ * out_cx/out_cy [n]; out_xy [N,2] (may be NULL); out_a [n-k] (may be NULL); stats[5] (may be NULL). */
+int orc_global_mincurv(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
+                       const double* w_left, const double* w_right, double margin, int n_outer,
+                       double* out_cx, double* out_cy, double* out_xy, double* out_a, double* stats);
+
 double orc_last_kappa(void);
 void orc_reset_kappa(void);
 

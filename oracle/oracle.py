@@ -231,3 +231,18 @@ def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, m
     f(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k), float(length),
       pts.ctypes.data_as(_dp), int(N), lp, len(ringL), rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
     return cx, cy, pts, ns
+
+
+def global_mincurv(t, cx0, cy0, k, N, w_left, w_right, margin=0.0, n_outer=6):
+    """The build's own global min-curvature QP (lateral control-point offsets, interior point);
+    returns (cx, cy, xy [N,2], a [n-k], stats[5])."""
+    t, tp = _d(t); cx0, xp = _d(cx0); cy0, yp = _d(cy0); wl, lp = _d(w_left); wr, rp = _d(w_right)
+    n = len(cx0)
+    cx = np.zeros(n); cy = np.zeros(n); xy = np.zeros((N, 2)); a = np.zeros(n - k); st = np.zeros(5)
+    f = lib().orc_global_mincurv
+    f.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double,
+                  ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
+    rc = f(tp, len(t), xp, yp, int(k), int(N), lp, rp, float(margin), int(n_outer), cx.ctypes.data_as(_dp),
+           cy.ctypes.data_as(_dp), xy.ctypes.data_as(_dp), a.ctypes.data_as(_dp), st.ctypes.data_as(_dp))
+    assert rc == 0
+    return cx, cy, xy, a, st

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "rl_kernels.hpp"
+#include "rl_global.hpp"
 
 namespace {
 
@@ -75,6 +77,11 @@ struct rl_track {
   DevBuf<double> ringL, ringR;  // shared rings as (x,y) pairs
   int nL = 0, nR = 0;
   mutable DevBuf<double> gscratch;  // for the non-LDS-resident sweep variant
+  // tables of the global QP (a15), built on first use and dropped when the centre line changes
+  mutable DevBuf<double> gq_A, gq_nu;
+  mutable DevBuf<int> gq_chunk, gq_span;
+  mutable int gq_nc = 0;
+  mutable bool gq_valid = false;
   rl::TrackDev dev() const {
     rl::TrackDev d;
     d.k = k; d.n = n; d.nt = nt; d.N = N;
@@ -382,6 +389,7 @@ int rl_track_set_control_points(rl_track* trk, const double* cx0, const double* 
     hipLaunchKernelGGL(rl::k_build_tables<5>, grid, block, 0, ctx->stream, trk->t.p, trk->nt, trk->c0.p, N, trk->ell.p, trk->D.p, trk->base.p);
   RL_HIP(hipGetLastError());
   RL_HIP(hipStreamSynchronize(ctx->stream));
+  trk->gq_valid = false;
   return RL_OK;
 }
 
@@ -571,6 +579,141 @@ int rl_mincurv_solve_batch_host(rl_ctx* ctx, const rl_track* trk, int bounds_for
   RL_HIP(hipMemcpyAsync(out_xy, dxy.p, dxy.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (n_success) RL_HIP(hipMemcpyAsync(n_success, dns.p, (size_t)B * 2 * max_iter * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   if (status) RL_HIP(hipMemcpyAsync(status, dst.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  if (stats) {
+    float ms = 0.f;
+    RL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->kernel_ms = ms;
+  }
+  return RL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a15: global min-curvature QP (rl_global.hpp)
+extern "C++" {
+namespace {
+
+int host_find_interval(const std::vector<double>& t, int k, int n, double x) {
+  int lo = k, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (x >= t[mid]) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// Track-level tables: constraint rows, control-point normals, and the partition of the sample
+// grid into chunks of <= kGRows consecutive samples of one knot span.
+int global_tables(const rl_ctx* ctx, const rl_track* trk) {
+  if (trk->gq_valid) return RL_OK;
+  const int k = trk->k, n = trk->n, N = trk->N, np = n - k;
+  if (np < 2 * (k + 1)) return fail(RL_ERR_UNSUPPORTED, "too few control points for the global QP");
+  if (np > rl::kGMaxNp) return fail(RL_ERR_UNSUPPORTED, "global QP: more than 192 free control points");
+  if (N >= (1 << 24)) return fail(RL_ERR_UNSUPPORTED, "global QP: N too large");
+  std::vector<int> rows(np, 0);
+  const double step = 1.0 / (double)N;
+  for (int i = 0; i < N; ++i) ++rows[host_find_interval(trk->t_host, k, n, (double)i * step) - k];
+  std::vector<int> chunk, span(np + 1, 0);
+  int row = 0;
+  for (int s = 0; s < np; ++s) {
+    span[s] = (int)chunk.size() / 2;
+    for (int r = 0; r < rows[s]; r += rl::kGRows) {
+      const int c = std::min(rl::kGRows, rows[s] - r);
+      chunk.push_back((row + r) | (c << 24));
+      chunk.push_back(s);
+    }
+    row += rows[s];
+  }
+  span[np] = (int)chunk.size() / 2;
+  const int nc = span[np];
+  if (nc > 1024) return fail(RL_ERR_UNSUPPORTED, "global QP: N / 8 + n exceeds one workgroup");
+  RL_HIP(trk->gq_A.alloc((size_t)N * (k + 1))); RL_HIP(trk->gq_nu.alloc((size_t)2 * np));
+  RL_HIP(trk->gq_chunk.alloc(chunk.size())); RL_HIP(trk->gq_span.alloc(span.size()));
+  RL_HIP(hipMemcpyAsync(trk->gq_chunk.p, chunk.data(), chunk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(trk->gq_span.p, span.data(), span.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  const rl::TrackDev td = trk->dev();
+  if (k == 3) {
+    hipLaunchKernelGGL(rl::k_global_normals<3>, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, td, np, trk->gq_nu.p);
+    hipLaunchKernelGGL(rl::k_global_rows<3>, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, td, np, trk->gq_nu.p, trk->gq_A.p);
+  } else {
+    hipLaunchKernelGGL(rl::k_global_normals<5>, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, td, np, trk->gq_nu.p);
+    hipLaunchKernelGGL(rl::k_global_rows<5>, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, td, np, trk->gq_nu.p, trk->gq_A.p);
+  }
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipStreamSynchronize(ctx->stream));  // chunk / span are host vectors
+  trk->gq_nc = nc;
+  trk->gq_valid = true;
+  return RL_OK;
+}
+
+template <int K, int MAXB>
+int launch_global_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block, size_t lds) {
+  auto kern = rl::k_global_qp<K, MAXB>;
+  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(B), dim3(block), lds, ctx->stream, a);
+  RL_HIP(hipGetLastError());
+  return RL_OK;
+}
+
+int global_common(rl_ctx* ctx, const rl_track* trk, const double* widths, int B, double margin, int n_outer,
+                  double* out_ctrl, double* out_xy, double* out_a, double* out_stats, rl_stats* stats) {
+  if (!ctx || !trk || !widths || !out_ctrl || !out_stats) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
+  if (n_outer < 0 || n_outer > 64) return fail(RL_ERR_ARG, "n_outer out of range");
+  if (!degree_supported(trk->k)) return fail(RL_ERR_UNSUPPORTED, "spline degree must be 3 or 5");
+  RL_HIP(hipSetDevice(ctx->device));
+  if (int rc = global_tables(ctx, trk)) return rc;
+  rl::GlobalArgs a;
+  a.trk = trk->dev();
+  a.A = trk->gq_A.p; a.nu = trk->gq_nu.p; a.chunk = trk->gq_chunk.p; a.span_ch0 = trk->gq_span.p;
+  a.nc = trk->gq_nc; a.np = trk->n - trk->k;
+  a.widths = widths; a.margin = margin; a.n_outer = n_outer; a.max_ipm = 80;
+  a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_a = out_a; a.out_stats = out_stats;
+  const int block = std::max(64, (a.nc + 63) / 64 * 64);
+  const size_t lds = (size_t)rl::global_layout(trk->k, trk->n, a.np, block).total * sizeof(double);
+  if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "global QP does not fit LDS");
+  if (stats) { stats->lds_bytes = (int)lds; stats->block_threads = block; stats->rings_in_lds = 0; }
+  if (trk->k == 3) {
+    if (block <= 384) return launch_global_t<3, 384>(ctx, a, B, block, lds);
+    if (block <= 640) return launch_global_t<3, 640>(ctx, a, B, block, lds);
+    return launch_global_t<3, 1024>(ctx, a, B, block, lds);
+  }
+  if (block <= 384) return launch_global_t<5, 384>(ctx, a, B, block, lds);
+  if (block <= 640) return launch_global_t<5, 640>(ctx, a, B, block, lds);
+  return launch_global_t<5, 1024>(ctx, a, B, block, lds);
+}
+
+}  // namespace
+}  // extern "C++"
+
+int rl_mincurv_global_batch_dev(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,
+                                double margin, int n_outer, double* out_ctrl, double* out_xy,
+                                double* out_a, double* out_stats, rl_stats* stats) {
+  return global_common(ctx, trk, widths, B, margin, n_outer, out_ctrl, out_xy, out_a, out_stats, stats);
+}
+
+int rl_mincurv_global_batch_host(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,
+                                 double margin, int n_outer, double* out_ctrl, double* out_xy,
+                                 double* out_a, double* out_stats, rl_stats* stats) {
+  if (!ctx || !trk || !widths || !out_ctrl || !out_stats) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = trk->n, N = trk->N, np = n - trk->k;
+  DevBuf<double> dw, dctrl, dxy, da, dst;
+  RL_HIP(dw.alloc((size_t)B * N * 2)); RL_HIP(dctrl.alloc((size_t)B * n * 2));
+  if (out_xy) RL_HIP(dxy.alloc((size_t)B * N * 2));
+  if (out_a) RL_HIP(da.alloc((size_t)B * np));
+  RL_HIP(dst.alloc((size_t)B * 8));
+  RL_HIP(hipMemcpyAsync(dw.p, widths, dw.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = global_tables(ctx, trk)) return rc;  // keeps the table build out of the timed region
+  RL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  if (int rc = global_common(ctx, trk, dw.p, B, margin, n_outer, dctrl.p, dxy.p, da.p, dst.p, stats)) return rc;
+  RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  RL_HIP(hipMemcpyAsync(out_ctrl, dctrl.p, dctrl.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_xy) RL_HIP(hipMemcpyAsync(out_xy, dxy.p, dxy.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_a) RL_HIP(hipMemcpyAsync(out_a, da.p, da.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(out_stats, dst.p, dst.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipStreamSynchronize(ctx->stream));
   if (stats) {
     float ms = 0.f;
