@@ -57,8 +57,7 @@ def fma_variant():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()  # no-op unless a .so is missing or older than the source
         _lib = ctypes.CDLL(_SO)
         _lib.orc_arc_gk21.restype = ctypes.c_double
         _lib.orc_arc_gk21.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int,

@@ -381,8 +381,13 @@ __global__ void __launch_bounds__(MAXB) k_global_qp(GlobalArgs a) {
           for (int al = 0; al < K1; ++al) ax = fma(Ar[al], xJ[al], ax);
           const double2 w = reinterpret_cast<const double2*>(wid)[i];
           const double lo = -(w.y - a.margin), hi = w.x - a.margin;
-          sl[r] = fmax(ax - lo, 1e-2); su[r] = fmax(hi - ax, 1e-2);
-          ll[r] = 1.0; lu[r] = 1.0;
+          if (outer == 0) {
+            sl[r] = fmax(ax - lo, 1e-2); su[r] = fmax(hi - ax, 1e-2);
+            ll[r] = 1.0; lu[r] = 1.0;
+          } else {  // warm start from the previous linearisation's slacks and duals
+            sl[r] = fmax(sl[r], 1e-2); su[r] = fmax(su[r], 1e-2);
+            ll[r] = fmax(ll[r], 1e-2); lu[r] = fmax(lu[r], 1e-2);
+          }
           rpl[r] = ax - lo - sl[r]; rpu[r] = hi - ax - su[r];
         }
       }

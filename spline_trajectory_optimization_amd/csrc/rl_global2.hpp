@@ -1,0 +1,845 @@
+// rl_global2.hpp -- a15, fast path: the global min-curvature QP of rl_global.hpp (same formulation,
+// same CPU twin oracle/mincurv_oracle.c: orc_global_mincurv) as a WAVE-SPECIALISED workgroup.
+//
+//   * waves 0 .. nw-2 ("row waves"): thread = one chunk of <= R consecutive samples of ONE knot span.
+//     The chunk's constraint rows A (instance independent) and its interior-point state (slacks, duals)
+//     stay in registers for the whole solve; bounds lo/hi are in LDS.
+//   * wave nw-1 ("linear-algebra wave"): owns the np x np normal matrix.  The cyclic band
+//     (half-bandwidth K) is FOLDED (unknown order 0, np-1, 1, np-2, ...) into a plain band of
+//     half-bandwidth 2K, stored one matrix row per lane, both triangles, column c in register slot
+//     c mod (4K+1).  L D L' and both triangular solves then run entirely in registers: the pivot
+//     column is broadcast with v_readlane, every update is lane-local, no LDS, no barrier inside.
+//   The two roles are two separate code paths (register allocation = max, not sum) that meet at the
+//   same sequence of workgroup barriers; the barrier protocol is spelled out at k_global_qp2.
+//
+//   * chunk partials -> span sums go through an LDS staging area in rounds (fixed summation order:
+//     run-to-run reproducible, independent of the position in the batch).
+//
+// Shapes the fast path does not cover (more chunks than 7 waves, LDS overflow) use k_global_qp.
+#pragma once
+#include "rl_global.hpp"
+
+namespace rl {
+
+// keeps the scheduler from interleaving the unrolled per-row bodies (register pressure)
+#define RL_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int kG2Round = 11;   // span outputs staged per flush round
+constexpr int kG2Block = 512;  // 7 row waves + 1 linear-algebra wave; 256 VGPRs per lane
+
+struct Global2Layout {  // offsets in doubles
+  int xs, xs2, dxa, dxs, avs, qv, rdP, rd, rhs, cxs, cys, nus, Pc, Ssum, Spart, lohi, red, ctl, sch, total;
+};
+
+__host__ __device__ inline Global2Layout global2_layout(int k, int n, int np, int N, int groups, int nrow) {
+  const int K1 = k + 1, NO = K1 * (K1 + 1) / 2 + 2 * K1, NS = 4 * k + 1;
+  Global2Layout L;
+  int o = 0;
+  auto take = [&](int c) { const int r = o; o += (c + 1) & ~1; return r; };
+  L.xs = take(np); L.xs2 = take(np); L.dxa = take(np); L.dxs = take(np); L.avs = take(np); L.qv = take(np); L.rdP = take(np);
+  L.rd = take(np); L.rhs = take(np);
+  L.cxs = take(n); L.cys = take(n); L.nus = take(2 * np);
+  L.Pc = take(np * K1);
+  L.Ssum = take(np * NO);
+  const int spart = nrow * kG2Round, mf = NS * 64 * groups;  // the folded matrix aliases the staging area
+  L.Spart = take(spart > mf ? spart : mf);
+  L.lohi = take(2 * N);
+  L.red = take(4 * 16);
+  L.ctl = take(8);
+  L.sch = take((np + 2) / 2 + 1);
+  L.total = o;
+  return L;
+}
+
+// 1/x to double precision without the IEEE division sequence (x is a positive, normal number here)
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Folded band in registers.  Matrix row p lives in lane p & 63 of group p >> 6; slot s of row p holds
+// column  col(p, s) = the one column == s (mod NS) in [p - BW, p + BW].  Rows >= np are zero.
+//
+// Every step is templated on the group Q of the pivot column so that all register indices are
+// static; the rows a column touches lie in group Q and, where the window crosses a multiple of 64,
+// in the neighbouring group (same lanes, wrapped).  No branch inside a column step.
+template <int BW, int G>
+struct FoldBand {
+  static constexpr int NS = 2 * BW + 1;
+  double S[G][NS];
+  double dinv[G];
+
+  __device__ __forceinline__ void load(const double* Mf, int lane) {
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      dinv[q] = 0.0;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) S[q][s] = Mf[s * (64 * G) + 64 * q + lane];
+    }
+  }
+
+  // rows (c, c + BW] <-> lanes of group Q (and Q + 1); rows [c - BW, c) <-> group Q (and Q - 1)
+  template <int Q>
+  static __device__ __forceinline__ bool below(int lane, int c, int dq) { return (unsigned)(lane + 64 * (Q + dq) - c - 1) < (unsigned)BW; }
+  template <int Q>
+  static __device__ __forceinline__ bool above(int lane, int c, int dq) { return (unsigned)(c - 1 - (lane + 64 * (Q + dq))) < (unsigned)BW; }
+
+  // One column of L D L'.  Afterwards slot s holds, in the rows below the pivot, L[r][c]; in the rows
+  // above it, the mirrored entry times 1/d_c (what the backward sweep multiplies with); dinv = 1/d.
+  template <int Q>
+  __device__ __forceinline__ void factor_col(int c, int s, int lane) {
+    constexpr bool NEXT = Q + 1 < G, PREV = Q > 0;
+    const int lc = c & 63;
+    const double inv = frcp(lane_bcast(S[Q][s], lc));
+    const bool m0 = below<Q>(lane, c, 0), m1 = NEXT && below<Q>(lane, c, 1);
+    const double uv0 = m0 ? S[Q][s] : 0.0;
+    const double uv1 = m1 ? S[NEXT ? Q + 1 : Q][s] : 0.0;
+    const double uvc = m1 ? uv1 : uv0;  // the pivot column in lane space (the two windows are disjoint)
+    dinv[Q] = lane == lc ? inv : dinv[Q];
+    S[Q][s] = m0 ? uv0 * inv : (above<Q>(lane, c, 0) ? S[Q][s] * inv : S[Q][s]);
+    if (NEXT) S[Q + 1][s] = m1 ? uv1 * inv : S[Q + 1][s];
+    if (PREV) S[Q - 1][s] = above<Q>(lane, c, -1) ? S[Q - 1][s] * inv : S[Q - 1][s];
+    // all broadcasts first (independent v_readlane pairs), then the independent updates: a single
+    // wave issues in order, so interleaving them would expose the readlane -> VALU latency BW times.
+    // (uv * u) * inv rounds identically in both triangles: the matrix stays bitwise symmetric.
+    double u[BW];
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) u[j - 1] = lane_bcast(uvc, (c + j) & 63);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) {
+      S[Q][(s + j) % NS] = fma(-(uv0 * u[j - 1]), inv, S[Q][(s + j) % NS]);
+      if (NEXT) S[Q + 1][(s + j) % NS] = fma(-(uv1 * u[j - 1]), inv, S[Q + 1][(s + j) % NS]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int Q>
+  __device__ __forceinline__ void forward_col(int c, int s, int lane, double (&b)[G]) const {
+    constexpr bool NEXT = Q + 1 < G;
+    const double bc = lane_bcast(b[Q], c & 63);
+    b[Q] = fma(-(below<Q>(lane, c, 0) ? S[Q][s] : 0.0), bc, b[Q]);
+    if (NEXT) b[Q + 1] = fma(-(below<Q>(lane, c, 1) ? S[Q + 1][s] : 0.0), bc, b[Q + 1]);
+  }
+  template <int Q>
+  __device__ __forceinline__ void backward_col(int c, int s, int lane, double (&b)[G]) const {
+    constexpr bool PREV = Q > 0;
+    const double tc = lane_bcast(b[Q], c & 63);
+    b[Q] = fma(-(above<Q>(lane, c, 0) ? S[Q][s] : 0.0), tc, b[Q]);
+    if (PREV) b[Q - 1] = fma(-(above<Q>(lane, c, -1) ? S[Q - 1][s] : 0.0), tc, b[Q - 1]);
+  }
+
+#define RL_FB_DISPATCH(CALL)                                   \
+  if (G == 1) { CALL(0); }                                     \
+  else { const int qc = c >> 6;                                \
+         if (qc == 0) { CALL(0); } else if (qc == 1) { CALL(G > 1 ? 1 : 0); } else { CALL(G > 2 ? 2 : 0); } }
+
+  __device__ __forceinline__ void factor(int np, int lane) {
+    static_assert(G <= 3, "three groups of 64 rows at most");
+    for (int c0 = 0; c0 < np; c0 += NS) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int c = c0 + s;
+        if (c >= np) break;
+#define RL_FB_CALL(Q) factor_col<(Q)>(c, s, lane)
+        RL_FB_DISPATCH(RL_FB_CALL)
+#undef RL_FB_CALL
+      }
+    }
+  }
+
+  // (L D L') x = b, b in registers (row = lane + 64 q), overwritten by x
+  __device__ __forceinline__ void solve(int np, int lane, double (&b)[G]) const {
+    for (int c0 = 0; c0 < np; c0 += NS) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int c = c0 + s;
+        if (c >= np) break;
+#define RL_FB_CALL(Q) forward_col<(Q)>(c, s, lane, b)
+        RL_FB_DISPATCH(RL_FB_CALL)
+#undef RL_FB_CALL
+      }
+    }
+    for (int c0 = ((np - 1) / NS) * NS; c0 >= 0; c0 -= NS) {
+#pragma unroll
+      for (int s = NS - 1; s >= 0; --s) {
+        const int c = c0 + s;
+        if (c < np) {
+#define RL_FB_CALL(Q) backward_col<(Q)>(c, s, lane, b)
+          RL_FB_DISPATCH(RL_FB_CALL)
+#undef RL_FB_CALL
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) b[q] *= dinv[q];
+  }
+#undef RL_FB_DISPATCH
+};
+
+__device__ __forceinline__ int fold_pos(int j, int np) { return j < (np + 1) / 2 ? 2 * j : 2 * (np - 1 - j) + 1; }
+__device__ __forceinline__ int fold_inv(int p, int np) { return (p & 1) ? np - 1 - (p >> 1) : (p >> 1); }
+
+// ------------------------------------------------------------------------------------------------
+// pieces shared by both roles (every thread of the workgroup calls them with its own tid)
+
+// Ssum[sp * NO + out0 + o] = sum over the chunks of span sp, in chunk order, of Spart[ch * GR + o]
+__device__ __forceinline__ void g2_reduce_round(int tid, int nt, int np, const int* sch, const double* Spart,
+                                                double* Ssum, int NO, int out0, int w) {
+  for (int task = tid; task < np * w; task += nt) {
+    const int sp = task / w, o = task - sp * w;
+    double sum = 0.0;
+    int ch = sch[sp];
+    const int ce = sch[sp + 1];
+    for (; ch + 4 <= ce; ch += 4) {  // four loads in flight; the additions keep the chunk order
+      const double v0 = Spart[ch * kG2Round + o], v1 = Spart[(ch + 1) * kG2Round + o];
+      const double v2 = Spart[(ch + 2) * kG2Round + o], v3 = Spart[(ch + 3) * kG2Round + o];
+      sum += v0; sum += v1; sum += v2; sum += v3;
+    }
+    for (; ch < ce; ++ch) sum += Spart[ch * kG2Round + o];
+    Ssum[sp * NO + out0 + o] = sum;
+  }
+}
+
+template <int K>
+__device__ __forceinline__ double g2_band_entry(const double* Pc, const double* Ssum, int np, int j, int d) {
+  constexpr int K1 = K + 1, NO = K1 * (K1 + 1) / 2 + 2 * K1;
+  double sum = Pc[j * K1 + d];
+  for (int al = d; al <= K; ++al) {
+    int sp = j - al;
+    if (sp < 0) sp += np;
+    sum += Ssum[sp * NO + al * (al + 1) / 2 + (al - d)];
+  }
+  return sum;
+}
+
+// normal matrix P + A'DA into the folded slot layout Mf[s][row] (all slots written, zeros included),
+// dual residual rd and the first right-hand side
+template <int K, int G>
+__device__ __forceinline__ void g2_assemble(int tid, int nt, int np, const double* Pc, const double* Ssum,
+                                            const double* rdP, double* Mf, double* rd, double* rhs) {
+  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1, BW = 2 * K, NS = 2 * BW + 1;
+  for (int task = tid; task < NS * 64 * G; task += nt) {
+    const int s = task / (64 * G), p = task - s * (64 * G);
+    int m = (s - p + BW) % NS;
+    if (m < 0) m += NS;
+    const int col = p - BW + m;
+    double v = 0.0;
+    if (p < np && col >= 0 && col < np) {
+      const int j1 = fold_inv(p, np), j2 = fold_inv(col, np);
+      int d = j1 - j2;
+      if (d < 0) d += np;
+      if (d <= K) v = g2_band_entry<K>(Pc, Ssum, np, j1, d);
+      else if (np - d <= K) v = g2_band_entry<K>(Pc, Ssum, np, j2, np - d);
+    }
+    Mf[task] = v;
+  }
+  for (int j = tid; j < np; j += nt) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int al = 0; al <= K; ++al) {
+      int sp = j - al;
+      if (sp < 0) sp += np;
+      s1 += Ssum[sp * NO + NE + al]; s2 += Ssum[sp * NO + NE + K1 + al];
+    }
+    rd[j] = rdP[j] + s2;
+    rhs[j] = s1 - rdP[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Barrier protocol.  Both roles execute exactly this sequence (R = row waves, L = linear-algebra wave):
+//
+//   per outer iteration
+//     [Oa] all: control points from the offsets                                  -> barrier
+//     [Ob] R: curvature rows, Gauss-Newton partials (27 outputs)                 -> flush (3 rounds:
+//          R writes Spart | barrier | all reduce | barrier)    -- the first barrier also publishes
+//          sum kappa^2; every thread leaves the outer loop here when outer == n_outer
+//     [Oc] L: P, q (scaled), x = a.   R: lo/hi, initial slacks and duals         -> barrier
+//     per interior-point iteration
+//       [I1] R: residuals, A'DA / A'e / A'(lu-ll) partials (33 outputs).  L: P x + q   -> flush (3 rounds)
+//       [I2] all: folded normal matrix, rd, rhs                                   -> barrier
+//       [I3] L: convergence test -> ctl[0]; factor; affine solve -> dxs          -> barrier
+//            all: leave the loop when ctl[0] != 0
+//       [I4] R: affine step: ratios, complementarity sums -> red                 -> barrier
+//       [I5] all: alpha_aff, sigma.  R: corrector partials (K+1 outputs) -> Spart -> barrier
+//            all: reduce                                                          -> barrier
+//       [I6] L: second right-hand side; solve -> dxs                             -> barrier
+//       [I7] R: step ratios -> red                                                -> barrier
+//       [I8] all: alpha.  R: update slacks/duals.  L: x += alpha dx              -> barrier
+//     [Od] L: a = x, step size                                                   -> barrier
+template <int K, int R, int G>
+__global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
+  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1, BW = 2 * K, GR = kG2Round;
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int nt = blockDim.x, nrw = (nt >> 6) - 1, nrow = nrw * kWave;
+  const bool la = wave == nrw;
+  const int b = blockIdx.x;
+  const int N = a.trk.N, n = a.trk.n, np = a.np;
+  const Global2Layout L = global2_layout(K, n, np, N, G, nrow);
+  double *xsA = lds + L.xs, *xsB = lds + L.xs2, *dxa = lds + L.dxa, *dxs = lds + L.dxs, *avs = lds + L.avs, *qv = lds + L.qv, *rdP = lds + L.rdP;
+  double *rd = lds + L.rd, *rhs = lds + L.rhs, *cxs = lds + L.cxs, *cys = lds + L.cys, *nus = lds + L.nus;
+  double *Pc = lds + L.Pc, *Ssum = lds + L.Ssum, *Spart = lds + L.Spart, *Mf = lds + L.Spart;
+  double *lohi = lds + L.lohi, *red = lds + L.red, *ctl = lds + L.ctl;
+  int* sch = reinterpret_cast<int*>(lds + L.sch);
+  const double* __restrict__ wid = a.widths + (size_t)b * N * 2;
+
+  for (int j = tid; j < np; j += nt) { nus[2 * j] = a.nu[2 * j]; nus[2 * j + 1] = a.nu[2 * j + 1]; avs[j] = 0.0; }
+  for (int j = tid; j <= np; j += nt) sch[j] = a.span_ch0[j];
+  for (int i = tid; i < N; i += nt) {
+    const double2 w = reinterpret_cast<const double2*>(wid)[i];
+    reinterpret_cast<double2*>(lohi)[i] = make_double2(-(w.y - a.margin), w.x - a.margin);
+  }
+  __syncthreads();
+
+  // block-level combine of the row waves' partials (fixed order)
+  auto red_sum = [&](int kind) { double s = 0.0; for (int w = 0; w < nrw; ++w) s += red[kind * 16 + w]; return s; };
+  auto red_max = [&](int kind) { double s = -INFINITY; for (int w = 0; w < nrw; ++w) s = fmax(s, red[kind * 16 + w]); return s; };
+  double k2_first = 0.0, k2_last = 0.0;
+  int total_it = 0;
+
+  if (!la) {
+    // =================================================================================== row waves
+    const bool has = tid < a.nc;
+    int row0 = 0, cnt = 0, sp0 = 0;
+    if (has) {
+      const int2 c = reinterpret_cast<const int2*>(a.chunk)[tid];
+      row0 = c.x & 0xffffff; cnt = (unsigned)c.x >> 24; sp0 = c.y;
+    }
+    int J[K1];
+#pragma unroll
+    for (int al = 0; al < K1; ++al) { J[al] = sp0 + al; if (J[al] >= np) J[al] -= np; }
+    double Ar[R][K1];
+    const double* __restrict__ D1 = a.trk.D + (size_t)K1 * N;
+    const double* __restrict__ D2 = a.trk.D + (size_t)2 * K1 * N;
+    double sl[R] = {}, su[R] = {}, ll[R] = {}, lu[R] = {};
+#ifdef RL_G2_PROFILE
+    long long rT[6] = {0, 0, 0, 0, 0, 0}, rk = wall_clock64();
+#define G2_LAP(i) { const long long n_ = wall_clock64(); rT[i] += n_ - rk; rk = n_; }
+#else
+#define G2_LAP(i)
+#endif
+
+    for (int outer = 0;; ++outer) {
+      // [Oa]
+      for (int j = tid; j < n; j += nt) {
+        const int jj = j >= np ? j - np : j;
+        cxs[j] = fma(avs[jj], nus[2 * jj], a.trk.c0[jj]);
+        cys[j] = fma(avs[jj], nus[2 * jj + 1], a.trk.c0[n + jj]);
+      }
+      __syncthreads();
+      // [Ob]
+      {
+        double acc[NE + K1];
+#pragma unroll
+        for (int o = 0; o < NE + K1; ++o) acc[o] = 0.0;
+        double k2p = 0.0;
+        if (has) {
+          double cxJ[K1], cyJ[K1];
+#pragma unroll
+          for (int al = 0; al < K1; ++al) { cxJ[al] = cxs[sp0 + al]; cyJ[al] = cys[sp0 + al]; }
+#pragma unroll 1
+          for (int r = 0; r < cnt; ++r) {
+            const int i = row0 + r;
+            double b1[K1], b2[K1], dx = 0, dy = 0, ddx = 0, ddy = 0;
+#pragma unroll
+            for (int al = 0; al < K1; ++al) {
+              b1[al] = D1[(size_t)al * N + i]; b2[al] = D2[(size_t)al * N + i];
+              dx = fma(cxJ[al], b1[al], dx); dy = fma(cyJ[al], b1[al], dy);
+              ddx = fma(cxJ[al], b2[al], ddx); ddy = fma(cyJ[al], b2[al], ddy);
+            }
+            const double s2 = dx * dx + dy * dy, inv3 = 1.0 / (s2 * sqrt(s2));
+            const double kp = (dx * ddy - dy * ddx) * inv3;
+            k2p = fma(kp, kp, k2p);
+            double Gr[K1], ga = 0.0;
+#pragma unroll
+            for (int al = 0; al < K1; ++al) {
+              const double nx = nus[2 * J[al]], ny = nus[2 * J[al] + 1];
+              Gr[al] = ((b1[al] * nx) * ddy + dx * (b2[al] * ny) - (b1[al] * ny) * ddx - dy * (b2[al] * nx)) * inv3 -
+                       3.0 * kp * (dx * b1[al] * nx + dy * b1[al] * ny) / s2;
+              ga = fma(Gr[al], avs[J[al]], ga);
+            }
+            const double res = kp - ga;
+            int e = 0;
+#pragma unroll
+            for (int al = 0; al < K1; ++al) {
+#pragma unroll
+              for (int be = 0; be <= al; ++be) { acc[e] = fma(Gr[al], Gr[be], acc[e]); ++e; }
+              acc[NE + al] = fma(Gr[al], res, acc[NE + al]);
+            }
+          }
+        }
+        k2p = wave_sum(k2p);
+        if (lane == 0) red[wave] = k2p;
+#pragma unroll
+        for (int r0 = 0; r0 < NE + K1; r0 += GR) {
+          const int w = NE + K1 - r0 < GR ? NE + K1 - r0 : GR;
+          if (has) {
+#pragma unroll
+            for (int o = 0; o < GR; ++o)
+              if (r0 + o < NE + K1) Spart[tid * GR + o] = acc[r0 + o];
+          }
+          __syncthreads();
+          if (r0 == 0) {
+            k2_last = red_sum(0);
+            if (outer == 0) k2_first = k2_last;
+            if (outer == a.n_outer) break;
+          }
+          g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+          __syncthreads();
+        }
+        if (outer == a.n_outer) break;
+      }
+      // [Oc]  the chunk's constraint rows are (re)loaded here, after the register-hungry curvature
+      // pass, so that they are not live across it; the laundered pointer keeps the loads in the loop
+      {
+        const double* Ap = a.A;
+        asm volatile("" : "+s"(Ap));
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int al = 0; al < K1; ++al) Ar[r][al] = r < cnt ? Ap[(size_t)(row0 + r) * K1 + al] : 0.0;
+      }
+      if (has) {
+        double xJ[K1];
+#pragma unroll
+        for (int al = 0; al < K1; ++al) xJ[al] = avs[J[al]];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { RL_ROW_FENCE();
+          double ax = 0.0;
+#pragma unroll
+          for (int al = 0; al < K1; ++al) ax = fma(Ar[r][al], xJ[al], ax);
+          const double2 lh = r < cnt ? reinterpret_cast<const double2*>(lohi)[row0 + r] : make_double2(-1.0, 1.0);
+          if (outer == 0) {
+            sl[r] = fmax(ax - lh.x, 1e-2); su[r] = fmax(lh.y - ax, 1e-2);
+            ll[r] = 1.0; lu[r] = 1.0;
+          } else {  // warm start from the previous linearisation's slacks and duals
+            sl[r] = fmax(sl[r], 1e-2); su[r] = fmax(su[r], 1e-2);
+            ll[r] = fmax(ll[r], 1e-2); lu[r] = fmax(lu[r], 1e-2);
+          }
+        }
+      }
+      __syncthreads();
+      const double *xc = xsA, *xn = xsB;  // x is double buffered: [I8] reads it while the LA wave writes the next one
+      for (int it = 0; it < a.max_ipm; ++it) {
+        G2_LAP(5);
+        // [I1]  three sweeps over the rows, one per flush round: only GR accumulators are live at a time
+        {
+          double dmv[R], ev[R], dlv[R];
+#pragma unroll
+          for (int r0 = 0; r0 < NO; r0 += GR) {
+            const int w = NO - r0 < GR ? NO - r0 : GR;
+            double acc[GR];
+#pragma unroll
+            for (int o = 0; o < GR; ++o) acc[o] = 0.0;
+            if (r0 == 0) {
+              double mu = 0.0, rpmax = 0.0;
+              if (has) {
+                double xJ[K1];
+#pragma unroll
+                for (int al = 0; al < K1; ++al) xJ[al] = xc[J[al]];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { RL_ROW_FENCE();
+                  dmv[r] = 0.0; ev[r] = 0.0; dlv[r] = 0.0;
+                  if (r < cnt) {
+                    double ax = 0.0;
+#pragma unroll
+                    for (int al = 0; al < K1; ++al) ax = fma(Ar[r][al], xJ[al], ax);
+                    const double2 lh = reinterpret_cast<const double2*>(lohi)[row0 + r];
+                    const double rpl = ax - lh.x - sl[r], rpu = lh.y - ax - su[r];
+                    const double ql = ll[r] * frcp(sl[r]), qu = lu[r] * frcp(su[r]);
+                    dmv[r] = ql + qu; ev[r] = qu * rpu - ql * rpl; dlv[r] = lu[r] - ll[r];
+                    mu += sl[r] * ll[r] + su[r] * lu[r];
+                    rpmax = fmax(rpmax, fmax(fabs(rpl), fabs(rpu)));
+                  }
+                }
+              }
+              mu = wave_sum(mu); rpmax = wave_max(rpmax);
+              if (lane == 0) { red[wave] = mu; red[32 + wave] = rpmax; }
+            }
+            if (has) {
+#pragma unroll
+              for (int r = 0; r < R; ++r) { RL_ROW_FENCE();
+                // rows beyond cnt have A = 0 and dm = e = dl = 0: they add nothing
+                int o = 0;
+#pragma unroll
+                for (int al = 0; al < K1; ++al) {
+                  const double wa = dmv[r] * Ar[r][al];
+#pragma unroll
+                  for (int be = 0; be <= al; ++be) {
+                    if (o >= r0 && o < r0 + GR) acc[o - r0] = fma(wa, Ar[r][be], acc[o - r0]);
+                    ++o;
+                  }
+                  if (NE + al >= r0 && NE + al < r0 + GR) acc[NE + al - r0] = fma(Ar[r][al], ev[r], acc[NE + al - r0]);
+                  if (NE + K1 + al >= r0 && NE + K1 + al < r0 + GR)
+                    acc[NE + K1 + al - r0] = fma(Ar[r][al], dlv[r], acc[NE + K1 + al - r0]);
+                }
+              }
+#pragma unroll
+              for (int o = 0; o < GR; ++o)
+                if (r0 + o < NO) Spart[tid * GR + o] = acc[o];
+            }
+            __syncthreads();
+            g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+            __syncthreads();
+          }
+        }
+        G2_LAP(0);
+        // [I2]
+        const double mu_sum = red_sum(0);
+        g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        __syncthreads();
+        // [I3]
+        __syncthreads();
+        G2_LAP(1);
+        if (ctl[0] != 0.0) break;
+        ++total_it;
+        // [I4]..[I8]  Nothing but the slacks and duals is carried across a barrier: every pass rebuilds
+        // the row quantities it needs from x, the affine direction dxa and the final direction dxs.
+        struct RowAff { double rpl, rpu, isl, isu, d_sl, d_su, d_ll, d_lu; };
+        auto row_affine = [&](int r, const double (&xJ)[K1], const double (&aJ)[K1]) {
+          RowAff f;
+          double ax = 0.0, adx = 0.0;
+#pragma unroll
+          for (int al = 0; al < K1; ++al) { ax = fma(Ar[r][al], xJ[al], ax); adx = fma(Ar[r][al], aJ[al], adx); }
+          const double2 lh = reinterpret_cast<const double2*>(lohi)[row0 + r];
+          f.rpl = ax - lh.x - sl[r]; f.rpu = lh.y - ax - su[r];
+          f.isl = frcp(sl[r]); f.isu = frcp(su[r]);
+          f.d_sl = adx + f.rpl; f.d_su = f.rpu - adx;
+          f.d_ll = (-(sl[r] * ll[r]) - ll[r] * f.d_sl) * f.isl;
+          f.d_lu = (-(su[r] * lu[r]) - lu[r] * f.d_su) * f.isu;
+          return f;
+        };
+        {
+          double c1 = 0.0, c2 = 0.0, rmax = 0.0;
+          if (has) {
+            double xJ[K1], aJ[K1];
+#pragma unroll
+            for (int al = 0; al < K1; ++al) { xJ[al] = xc[J[al]]; aJ[al] = dxa[J[al]]; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              if (r < cnt) {
+                const RowAff f = row_affine(r, xJ, aJ);
+                rmax = fmax(rmax, fmax(fmax(-f.d_sl * f.isl, -f.d_su * f.isu),
+                                       fmax(-f.d_ll * __builtin_amdgcn_rcp(ll[r]), -f.d_lu * __builtin_amdgcn_rcp(lu[r]))));
+                c1 += sl[r] * f.d_ll + ll[r] * f.d_sl + su[r] * f.d_lu + lu[r] * f.d_su;
+                c2 += f.d_sl * f.d_ll + f.d_su * f.d_lu;
+              }
+            }
+          }
+          c1 = wave_sum(c1); c2 = wave_sum(c2); rmax = wave_max(rmax);
+          if (lane == 0) { red[wave] = c1; red[16 + wave] = c2; red[32 + wave] = rmax; }
+        }
+        __syncthreads();
+        G2_LAP(2);
+        // [I5]
+        double smu;
+        {
+          const double c1 = red_sum(0), c2 = red_sum(1), rmax = red_max(2);
+          const double aaff = rmax > 0.995 ? 0.995 / rmax : 1.0;
+          const double mu = mu_sum / (double)(2 * N);
+          const double mu_aff = (mu_sum + aaff * c1 + aaff * aaff * c2) / (double)(2 * N);
+          const double ratio = mu_aff / mu;
+          smu = ratio * ratio * ratio * mu;
+        }
+        {
+          double acc[K1];
+#pragma unroll
+          for (int al = 0; al < K1; ++al) acc[al] = 0.0;
+          if (has) {
+            double xJ[K1], aJ[K1];
+#pragma unroll
+            for (int al = 0; al < K1; ++al) { xJ[al] = xc[J[al]]; aJ[al] = dxa[J[al]]; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              if (r < cnt) {
+                const RowAff f = row_affine(r, xJ, aJ);
+                const double rcl = sl[r] * ll[r] - smu + f.d_sl * f.d_ll, rcu = su[r] * lu[r] - smu + f.d_su * f.d_lu;
+                const double wv = (-rcl - ll[r] * f.rpl) * f.isl - (-rcu - lu[r] * f.rpu) * f.isu;
+#pragma unroll
+                for (int al = 0; al < K1; ++al) acc[al] = fma(Ar[r][al], wv, acc[al]);
+              }
+            }
+#pragma unroll
+            for (int al = 0; al < K1; ++al) Spart[tid * GR + al] = acc[al];
+          }
+        }
+        __syncthreads();
+        g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, NE, K1);
+        __syncthreads();
+        G2_LAP(3);
+        // [I6]
+        __syncthreads();
+        G2_LAP(4);
+        // [I7], [I8]
+        auto row_final = [&](int r, const double (&xJ)[K1], const double (&aJ)[K1], const double (&dJ)[K1],
+                             double& d_sl, double& d_su, double& d_ll, double& d_lu, double& isl, double& isu) {
+          const RowAff f = row_affine(r, xJ, aJ);
+          double adx = 0.0;
+#pragma unroll
+          for (int al = 0; al < K1; ++al) adx = fma(Ar[r][al], dJ[al], adx);
+          const double rcl = sl[r] * ll[r] - smu + f.d_sl * f.d_ll, rcu = su[r] * lu[r] - smu + f.d_su * f.d_lu;
+          d_sl = adx + f.rpl; d_su = f.rpu - adx;
+          d_ll = (-rcl - ll[r] * d_sl) * f.isl; d_lu = (-rcu - lu[r] * d_su) * f.isu;
+          isl = f.isl; isu = f.isu;
+        };
+        {
+          double rmax = 0.0;
+          if (has) {
+            double xJ[K1], aJ[K1], dJ[K1];
+#pragma unroll
+            for (int al = 0; al < K1; ++al) { xJ[al] = xc[J[al]]; aJ[al] = dxa[J[al]]; dJ[al] = dxs[J[al]]; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              if (r < cnt) {
+                double d_sl, d_su, d_ll, d_lu, isl, isu;
+                row_final(r, xJ, aJ, dJ, d_sl, d_su, d_ll, d_lu, isl, isu);
+                rmax = fmax(rmax, fmax(fmax(-d_sl * isl, -d_su * isu),
+                                       fmax(-d_ll * __builtin_amdgcn_rcp(ll[r]), -d_lu * __builtin_amdgcn_rcp(lu[r]))));
+              }
+            }
+          }
+          rmax = wave_max(rmax);
+          if (lane == 0) red[32 + wave] = rmax;
+        }
+        __syncthreads();
+        {
+          const double rmax = red_max(2);
+          const double alpha = rmax > 0.995 ? 0.995 / rmax : 1.0;
+          if (has) {
+            double xJ[K1], aJ[K1], dJ[K1];
+#pragma unroll
+            for (int al = 0; al < K1; ++al) { xJ[al] = xc[J[al]]; aJ[al] = dxa[J[al]]; dJ[al] = dxs[J[al]]; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              if (r < cnt) {
+                double d_sl, d_su, d_ll, d_lu, isl, isu;
+                row_final(r, xJ, aJ, dJ, d_sl, d_su, d_ll, d_lu, isl, isu);
+                sl[r] = fma(alpha, d_sl, sl[r]); su[r] = fma(alpha, d_su, su[r]);
+                ll[r] = fma(alpha, d_ll, ll[r]); lu[r] = fma(alpha, d_lu, lu[r]);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        { const double* t_ = xc; xc = xn; xn = t_; }
+      }
+      // [Od]
+      __syncthreads();
+    }
+#ifdef RL_G2_PROFILE
+    if (tid == 0) for (int i = 0; i < 6; ++i) ctl[1 + i] = (double)rT[i];
+#endif
+    // ---- outputs of the row waves: line samples and the largest bound violation
+    {
+      const double* __restrict__ D0 = a.trk.D;
+      double viol = -INFINITY;
+      if (has) {
+        for (int r = 0; r < cnt; ++r) {
+          const int i = row0 + r;
+          double x = 0.0, y = 0.0;
+#pragma unroll
+          for (int al = 0; al < K1; ++al) {
+            const double h = D0[(size_t)al * N + i];
+            x = fma(cxs[sp0 + al], h, x); y = fma(cys[sp0 + al], h, y);
+          }
+          if (a.out_xy) reinterpret_cast<double2*>(a.out_xy)[(size_t)b * N + i] = make_double2(x, y);
+          const double lat = (x - a.trk.base[i]) * a.trk.base[(size_t)2 * N + i] +
+                             (y - a.trk.base[(size_t)N + i]) * a.trk.base[(size_t)3 * N + i];
+          const double2 lh = reinterpret_cast<const double2*>(lohi)[i];
+          viol = fmax(viol, fmax(lh.x - lat, lat - lh.y));
+        }
+      }
+      viol = wave_max(viol);
+      if (lane == 0) red[32 + wave] = viol;
+    }
+    __syncthreads();
+  } else {
+    // ========================================================================= linear-algebra wave
+    FoldBand<BW, G> fb;
+    double last_step = 0.0;
+#ifdef RL_G2_PROFILE
+    long long tF = 0, tS = 0, tA = 0, tk = 0;
+#define G2_TIC() tk = wall_clock64()
+#define G2_TOC(acc) acc += wall_clock64() - tk
+#else
+#define G2_TIC()
+#define G2_TOC(acc)
+#endif
+    for (int outer = 0;; ++outer) {
+      // [Oa]
+      for (int j = tid; j < n; j += nt) {
+        const int jj = j >= np ? j - np : j;
+        cxs[j] = fma(avs[jj], nus[2 * jj], a.trk.c0[jj]);
+        cys[j] = fma(avs[jj], nus[2 * jj + 1], a.trk.c0[n + jj]);
+      }
+      __syncthreads();
+      // [Ob]
+      bool done = false;
+#pragma unroll
+      for (int r0 = 0; r0 < NE + K1; r0 += GR) {
+        const int w = NE + K1 - r0 < GR ? NE + K1 - r0 : GR;
+        __syncthreads();
+        if (r0 == 0) {
+          k2_last = red_sum(0);
+          if (outer == 0) k2_first = k2_last;
+          if (outer == a.n_outer) { done = true; break; }
+        }
+        g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+        __syncthreads();
+      }
+      if (done) break;
+      // [Oc]  P = sc 2 G'G + eps I (cyclic band: Pc[j][d] = P[j][j-d]),  q = sc 2 G'(kappa - G a)
+      double qinf = 0.0;
+      {
+        double tr = 0.0;
+        for (int task = lane; task < np * K1; task += kWave) {
+          const int j = task / K1, d = task - j * K1;
+          double sum = 0.0;
+          for (int al = d; al <= K; ++al) {
+            int sp = j - al;
+            if (sp < 0) sp += np;
+            sum += Ssum[sp * NO + al * (al + 1) / 2 + (al - d)];
+          }
+          Pc[task] = 2.0 * sum;
+          if (d == 0) tr += 2.0 * sum;
+        }
+        tr = wave_sum(tr);
+        const double sc = (double)np / tr;
+        for (int task = lane; task < np * K1; task += kWave) {
+          const int d = task % K1;
+          Pc[task] = Pc[task] * sc + (d == 0 ? 1e-9 : 0.0);
+        }
+        for (int j = lane; j < np; j += kWave) {
+          double sum = 0.0;
+          for (int al = 0; al <= K; ++al) {
+            int sp = j - al;
+            if (sp < 0) sp += np;
+            sum += Ssum[sp * NO + NE + al];
+          }
+          const double q = 2.0 * sum * sc;
+          qv[j] = q;
+          xsA[j] = avs[j];
+          qinf = fmax(qinf, fabs(q));
+        }
+        qinf = wave_max(qinf);
+      }
+      __syncthreads();
+      double *xc = xsA, *xn = xsB;
+      for (int it = 0; it < a.max_ipm; ++it) {
+        // [I1]  rdP = P x + q
+        for (int j = lane; j < np; j += kWave) {
+          double s = qv[j];
+#pragma unroll
+          for (int d = 0; d <= K; ++d) {
+            int jm = j - d; if (jm < 0) jm += np;
+            s = fma(Pc[j * K1 + d], xc[jm], s);
+            if (d > 0) { int jp = j + d; if (jp >= np) jp -= np; s = fma(Pc[jp * K1 + d], xc[jp], s); }
+          }
+          rdP[j] = s;
+        }
+#pragma unroll
+        for (int r0 = 0; r0 < NO; r0 += GR) {
+          const int w = NO - r0 < GR ? NO - r0 : GR;
+          __syncthreads();
+          g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+          __syncthreads();
+        }
+        // [I2]
+        const double mu_sum = red_sum(0), rpmax = red_max(2);
+        g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        __syncthreads();
+        // [I3]
+        bool conv;
+        {
+          double rdmax = 0.0;
+          for (int j = lane; j < np; j += kWave) rdmax = fmax(rdmax, fabs(rd[j]));
+          rdmax = wave_max(rdmax);
+          const double mu = mu_sum / (double)(2 * N);
+          conv = fmax(rdmax / (1.0 + qinf), rpmax) < 1e-9 && mu < 1e-10;
+          if (lane == 0) ctl[0] = conv ? 1.0 : 0.0;
+        }
+        double bx[G];
+        if (!conv) {
+          G2_TIC();
+          fb.load(Mf, lane);
+          fb.factor(np, lane);
+          G2_TOC(tF);
+          G2_TIC();
+#pragma unroll
+          for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; bx[q] = p < np ? rhs[fold_inv(p, np)] : 0.0; }
+          fb.solve(np, lane, bx);
+          G2_TOC(tS);
+#pragma unroll
+          for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; if (p < np) dxa[fold_inv(p, np)] = bx[q]; }
+        }
+        __syncthreads();
+        if (conv) break;
+        ++total_it;
+        // [I4]
+        __syncthreads();
+        // [I5]
+        __syncthreads();
+        g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, NE, K1);
+        __syncthreads();
+        // [I6]
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const int p = lane + 64 * q;
+          double v = 0.0;
+          if (p < np) {
+            const int j = fold_inv(p, np);
+            for (int al = 0; al <= K; ++al) {
+              int sp = j - al;
+              if (sp < 0) sp += np;
+              v += Ssum[sp * NO + NE + al];
+            }
+            v -= rd[j];
+          }
+          bx[q] = v;
+        }
+        G2_TIC();
+        fb.solve(np, lane, bx);
+        G2_TOC(tS);
+#pragma unroll
+        for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; if (p < np) dxs[fold_inv(p, np)] = bx[q]; }
+        __syncthreads();
+        // [I7]
+        __syncthreads();
+        // [I8]
+        {
+          const double rmax = red_max(2);
+          const double alpha = rmax > 0.995 ? 0.995 / rmax : 1.0;
+          for (int j = lane; j < np; j += kWave) xn[j] = fma(alpha, dxs[j], xc[j]);
+        }
+        __syncthreads();
+        { double* t_ = xc; xc = xn; xn = t_; }
+      }
+      // [Od]
+      {
+        double stepmax = 0.0;
+        for (int j = lane; j < np; j += kWave) { stepmax = fmax(stepmax, fabs(xc[j] - avs[j])); avs[j] = xc[j]; }
+        last_step = wave_max(stepmax);
+      }
+      __syncthreads();
+    }
+    // ---- outputs of the linear-algebra wave: control points, offsets, statistics
+    for (int j = lane; j < n; j += kWave)
+      reinterpret_cast<double2*>(a.out_ctrl)[(size_t)b * n + j] = make_double2(cxs[j], cys[j]);
+    if (a.out_a)
+      for (int j = lane; j < np; j += kWave) a.out_a[(size_t)b * np + j] = avs[j];
+    __syncthreads();
+    if (lane == 0) {
+      double* st = a.out_stats + (size_t)b * 8;
+      st[0] = (double)total_it; st[1] = k2_first; st[2] = k2_last; st[3] = red_max(2); st[4] = last_step;
+      st[5] = 0.0; st[6] = 0.0; st[7] = 0.0;
+#ifdef RL_G2_PROFILE
+      st[5] = (double)tF; st[6] = (double)tS; st[7] = ctl[6]; st[1] = ctl[1]; st[2] = ctl[2]; st[3] = ctl[3]; st[4] = ctl[4] + 1e-3 * ctl[5];
+#endif
+    }
+  }
+}
+
+}  // namespace rl

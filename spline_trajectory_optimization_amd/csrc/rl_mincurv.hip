@@ -17,6 +17,7 @@
 
 #include "rl_kernels.hpp"
 #include "rl_global.hpp"
+#include "rl_global2.hpp"
 
 namespace {
 
@@ -66,6 +67,7 @@ struct rl_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int max_lds = 65536;
   int num_cu = 0;
+  bool force_global_v1 = false;  // test hook: RL_GLOBAL_V1=1 keeps the generic kernel
 };
 
 struct rl_track {
@@ -79,8 +81,9 @@ struct rl_track {
   mutable DevBuf<double> gscratch;  // for the non-LDS-resident sweep variant
   // tables of the global QP (a15), built on first use and dropped when the centre line changes
   mutable DevBuf<double> gq_A, gq_nu;
-  mutable DevBuf<int> gq_chunk, gq_span;
-  mutable int gq_nc = 0;
+  mutable DevBuf<int> gq_chunk, gq_span;    // chunks of <= rl::kGRows rows (k_global_qp)
+  mutable DevBuf<int> gq2_chunk, gq2_span;  // chunks of <= gq2_rows rows (k_global_qp2), if they fit
+  mutable int gq_nc = 0, gq2_nc = 0, gq2_rows = 0;  // gq2_rows = 0: the fast path does not fit
   mutable bool gq_valid = false;
   rl::TrackDev dev() const {
     rl::TrackDev d;
@@ -206,6 +209,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
       c->max_lds = optin;
   }
   c->num_cu = prop.multiProcessorCount;
+  if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return fail(RL_ERR_HIP, "hipEventCreate failed");
@@ -613,20 +617,32 @@ int global_tables(const rl_ctx* ctx, const rl_track* trk) {
   std::vector<int> rows(np, 0);
   const double step = 1.0 / (double)N;
   for (int i = 0; i < N; ++i) ++rows[host_find_interval(trk->t_host, k, n, (double)i * step) - k];
-  std::vector<int> chunk, span(np + 1, 0);
-  int row = 0;
-  for (int s = 0; s < np; ++s) {
-    span[s] = (int)chunk.size() / 2;
-    for (int r = 0; r < rows[s]; r += rl::kGRows) {
-      const int c = std::min(rl::kGRows, rows[s] - r);
-      chunk.push_back((row + r) | (c << 24));
-      chunk.push_back(s);
+  auto partition = [&](int R, std::vector<int>& chunk, std::vector<int>& span) {
+    chunk.clear(); span.assign(np + 1, 0);
+    int row = 0;
+    for (int s = 0; s < np; ++s) {
+      span[s] = (int)chunk.size() / 2;
+      for (int r = 0; r < rows[s]; r += R) {
+        const int c = std::min(R, rows[s] - r);
+        chunk.push_back((row + r) | (c << 24));
+        chunk.push_back(s);
+      }
+      row += rows[s];
     }
-    row += rows[s];
+    span[np] = (int)chunk.size() / 2;
+    return span[np];
+  };
+  std::vector<int> chunk, span, chunk2, span2;
+  const int nc = partition(rl::kGRows, chunk, span);
+  int rows2 = 0, nc2 = 0;
+  for (int R : {5, 6}) {  // fewest rows per thread whose chunks fit the row waves of k_global_qp2
+    nc2 = partition(R, chunk2, span2);
+    if (nc2 <= rl::kG2Block - 64) { rows2 = R; break; }
   }
-  span[np] = (int)chunk.size() / 2;
-  const int nc = span[np];
   if (nc > 1024) return fail(RL_ERR_UNSUPPORTED, "global QP: N / 8 + n exceeds one workgroup");
+  RL_HIP(trk->gq2_chunk.alloc(chunk2.size())); RL_HIP(trk->gq2_span.alloc(span2.size()));
+  RL_HIP(hipMemcpyAsync(trk->gq2_chunk.p, chunk2.data(), chunk2.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(trk->gq2_span.p, span2.data(), span2.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   RL_HIP(trk->gq_A.alloc((size_t)N * (k + 1))); RL_HIP(trk->gq_nu.alloc((size_t)2 * np));
   RL_HIP(trk->gq_chunk.alloc(chunk.size())); RL_HIP(trk->gq_span.alloc(span.size()));
   RL_HIP(hipMemcpyAsync(trk->gq_chunk.p, chunk.data(), chunk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -642,6 +658,8 @@ int global_tables(const rl_ctx* ctx, const rl_track* trk) {
   RL_HIP(hipGetLastError());
   RL_HIP(hipStreamSynchronize(ctx->stream));  // chunk / span are host vectors
   trk->gq_nc = nc;
+  trk->gq2_nc = nc2;
+  trk->gq2_rows = rows2;
   trk->gq_valid = true;
   return RL_OK;
 }
@@ -649,6 +667,16 @@ int global_tables(const rl_ctx* ctx, const rl_track* trk) {
 template <int K, int MAXB>
 int launch_global_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block, size_t lds) {
   auto kern = rl::k_global_qp<K, MAXB>;
+  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(B), dim3(block), lds, ctx->stream, a);
+  RL_HIP(hipGetLastError());
+  return RL_OK;
+}
+
+template <int K, int R, int G>
+int launch_global2_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block, size_t lds) {
+  auto kern = rl::k_global_qp2<K, R, G>;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B), dim3(block), lds, ctx->stream, a);
@@ -670,6 +698,27 @@ int global_common(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,
   a.nc = trk->gq_nc; a.np = trk->n - trk->k;
   a.widths = widths; a.margin = margin; a.n_outer = n_outer; a.max_ipm = 80;
   a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_a = out_a; a.out_stats = out_stats;
+  // fast path: wave-specialised kernel (rl_global2.hpp) when the chunks fit 7 row waves and the LDS
+  if (!ctx->force_global_v1 && trk->gq2_rows != 0 && a.np <= 192) {
+    const int groups = a.np <= 64 ? 1 : 3;
+    const int block2 = ((trk->gq2_nc + 63) / 64 + 1) * 64;
+    const size_t lds2 = (size_t)rl::global2_layout(trk->k, trk->n, a.np, trk->N, groups, block2 - 64).total * sizeof(double);
+    if (lds2 <= (size_t)ctx->max_lds) {
+      a.chunk = trk->gq2_chunk.p; a.span_ch0 = trk->gq2_span.p; a.nc = trk->gq2_nc;
+      if (stats) { stats->lds_bytes = (int)lds2; stats->block_threads = block2; stats->rings_in_lds = 0; }
+      const int sel = (trk->k == 3 ? 0 : 4) + (trk->gq2_rows == 5 ? 0 : 2) + (groups == 1 ? 0 : 1);
+      switch (sel) {
+        case 0: return launch_global2_t<3, 5, 1>(ctx, a, B, block2, lds2);
+        case 1: return launch_global2_t<3, 5, 3>(ctx, a, B, block2, lds2);
+        case 2: return launch_global2_t<3, 6, 1>(ctx, a, B, block2, lds2);
+        case 3: return launch_global2_t<3, 6, 3>(ctx, a, B, block2, lds2);
+        case 4: return launch_global2_t<5, 5, 1>(ctx, a, B, block2, lds2);
+        case 5: return launch_global2_t<5, 5, 3>(ctx, a, B, block2, lds2);
+        case 6: return launch_global2_t<5, 6, 1>(ctx, a, B, block2, lds2);
+        default: return launch_global2_t<5, 6, 3>(ctx, a, B, block2, lds2);
+      }
+    }
+  }
   const int block = std::max(64, (a.nc + 63) / 64 * 64);
   const size_t lds = (size_t)rl::global_layout(trk->k, trk->n, a.np, block).total * sizeof(double);
   if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "global QP does not fit LDS");
