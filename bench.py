@@ -48,6 +48,49 @@ def cpu_baseline(t, cx, cy, k, length, widths, i_start, budget_instances):
                       f"max_iter={MAX_ITER}), one per thread, {dt:.1f} s wall"}, xy
 
 
+GLOBAL_MARGIN, GLOBAL_OUTER = 0.25, 6
+
+
+def global_qp_leg(trk, d_widths, widths, t, cx, cy, k, args, torch, with_cpu):
+    """Secondary measurement, outside the timed region of the headline metric: the same batch through
+    the global banded QP (own formulation; rl_mincurv_global_batch_dev).  One
+    launch = B instances x GLOBAL_OUTER Gauss-Newton linearisations, each one inequality-constrained
+    QP (2N bound rows, n-k unknowns) solved by the interior-point kernel."""
+    from spline_trajectory_optimization_amd import ops
+    out = ops.global_batch_torch(trk, d_widths, GLOBAL_MARGIN, GLOBAL_OUTER)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        ops.global_batch_torch(trk, d_widths, GLOBAL_MARGIN, GLOBAL_OUTER, out=out)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    st = out["stats"].cpu().numpy()
+    B = widths.shape[0]
+    assert np.isfinite(st).all() and (st[:, 3] <= 1e-8).all(), "global QP: a line left its bounds"
+    leg = {"kernel_ms": ms, "instances_per_s": B / ms * 1e3, "qp_solves_per_s": B * GLOBAL_OUTER / ms * 1e3,
+           "linearisations": GLOBAL_OUTER, "ipm_iterations_mean": float(st[:, 0].mean()),
+           "sum_kappa2_before_after": [float(st[:, 1].mean()), float(st[:, 2].mean())],
+           "max_bound_violation_m": float(st[:, 3].max()), "block_threads": int(out["rl_stats"].block_threads),
+           "lds_bytes_per_workgroup": int(out["rl_stats"].lds_bytes),
+           "hbm_GBps_algorithmic": BYTES_PER_SOLVE * B / (ms * 1e-3) / 1e9}
+    if with_cpu:
+        from oracle import oracle as orc
+        ninst = 4
+        t0 = time.perf_counter()
+        dev_m = 0.0
+        xy = out["xy"][:ninst].cpu().numpy()
+        for b in range(ninst):
+            r = orc.global_mincurv(t, cx, cy, k, N_WAYPOINTS, widths[b, :, 0], widths[b, :, 1], GLOBAL_MARGIN, GLOBAL_OUTER)
+            dev_m = max(dev_m, float(np.abs(r[2] - xy[b]).max()))
+        dt = time.perf_counter() - t0
+        assert dev_m < 1e-6, f"global QP deviates from its CPU twin: {dev_m}"
+        leg["cpu_twin"] = {"instances_per_s": ninst / dt, "cores": 1, "sample": f"{ninst} instances, {dt:.2f} s",
+                           "gpu_vs_twin_dev_m": dev_m}
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-global", action="store_true", help="skip the secondary global-QP measurement")
     ap.add_argument("--cpu-instances", type=int, default=8)
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST HOOK: all ranks use cuda:0 and the gloo backend (exercises the N>1 code path "
@@ -183,6 +227,9 @@ def main():
                          "kernel": "k_sweep", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B},
         }
+        if world == 1 and not args.no_global:
+            res["config"]["global_qp"] = global_qp_leg(trk, d_widths, widths, t, cx, cy, k, args, torch,
+                                                      with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             ninst = min(args.cpu_instances, B)
             cb, oxy = cpu_baseline(t, cx, cy, k, line.get_length(), widths, i_start, ninst)
