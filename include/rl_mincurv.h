@@ -154,7 +154,8 @@ int rl_mincurv_solve_batch_host(rl_ctx* ctx, const rl_track* trk, int bounds_for
  *   widths     [B,N,2] (w_left, w_right) as for RL_BOUNDS_WIDTHS      margin  [m] kept to both edges
  *   out_ctrl   [B,n,2]   out_xy [B,N,2] (may be NULL)   out_a [B,n-k] (may be NULL)
  *   out_stats  [B,8]: interior-point iterations, sum kappa^2 before / after, largest bound
- *              violation of the result [m], last outer step max|delta a| [m], 3 reserved
+ *              violation of the result [m], last outer step max|delta a| [m], number of samples
+ *              of the result within 1e-6 m of a bound (the active set), 2 reserved
  * CPU twin for tests: oracle/mincurv_oracle.c: orc_global_mincurv.  *_dev takes device pointers and
  * enqueues on the context's stream; *_host copies in/out, synchronises and fills stats->kernel_ms. */
 int rl_mincurv_global_batch_dev(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,

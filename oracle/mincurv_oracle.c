@@ -949,7 +949,8 @@ void orc_run_joint_min_curvature_qp(const double* t, int nt, double* cx, double*
  *              matrix P + A' D A is n_p x n_p, symmetric positive definite and cyclic-banded
  *              (half-bandwidth k) because every row touches the k+1 control points of one knot span.
  * stats[0] = total interior-point iterations, [1] = initial sum kappa^2, [2] = final sum kappa^2,
- * [3] = largest bound violation of the final line [m], [4] = last outer step max|delta a| [m]. */
+ * [3] = largest bound violation of the final line [m], [4] = last outer step max|delta a| [m],
+ * [5] = number of samples of the final line within 1e-6 m of a bound (the active set). */
 
 static void spd_factor_dense(int n, double* K) { /* in-place lower Cholesky, row-major */
   for (int c = 0; c < n; ++c) {
@@ -1183,16 +1184,18 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
   }
   /* outputs */
   double viol = 0.0;
+  int n_active = 0;
   for (int i = 0; i < N; ++i) {
     double x = 0, y = 0;
     for (int a = 0; a < K1; ++a) { const int j = ell[i] - k + a; x += cx[j] * DD(0, a, i); y += cy[j] * DD(0, a, i); }
     if (out_xy) { out_xy[2 * i] = x; out_xy[2 * i + 1] = y; }
     const double lat = (x - p0[4 * i]) * p0[4 * i + 2] + (y - p0[4 * i + 1]) * p0[4 * i + 3];
     viol = fmax(viol, fmax(lo[i] - lat, lat - hi[i]));
+    if (lat - lo[i] < 1e-6 || hi[i] - lat < 1e-6) ++n_active;
   }
   for (int j = 0; j < n; ++j) { out_cx[j] = cx[j]; out_cy[j] = cy[j]; }
   if (out_a) memcpy(out_a, av, (size_t)np_ * sizeof(double));
-  if (stats) { stats[0] = (double)total_it; stats[1] = k2_first; stats[2] = k2_last; stats[3] = viol; stats[4] = last_step; }
+  if (stats) { stats[0] = (double)total_it; stats[1] = k2_first; stats[2] = k2_last; stats[3] = viol; stats[4] = last_step; stats[5] = (double)n_active; }
 #undef DD
 #undef JH
   free(cx); free(P); free(xv); free(av); free(lo); free(kap); free(G); free(A); free(p0); free(nu); free(D); free(ell);

@@ -234,10 +234,11 @@ def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, m
 
 def global_mincurv(t, cx0, cy0, k, N, w_left, w_right, margin=0.0, n_outer=6):
     """The build's own global min-curvature QP (lateral control-point offsets, interior point);
-    returns (cx, cy, xy [N,2], a [n-k], stats[5])."""
+    returns (cx, cy, xy [N,2], a [n-k], stats[6]: ipm iterations, sum kappa^2 before/after,
+    bound violation, last step, active rows)."""
     t, tp = _d(t); cx0, xp = _d(cx0); cy0, yp = _d(cy0); wl, lp = _d(w_left); wr, rp = _d(w_right)
     n = len(cx0)
-    cx = np.zeros(n); cy = np.zeros(n); xy = np.zeros((N, 2)); a = np.zeros(n - k); st = np.zeros(5)
+    cx = np.zeros(n); cy = np.zeros(n); xy = np.zeros((N, 2)); a = np.zeros(n - k); st = np.zeros(6)
     f = lib().orc_global_mincurv
     f.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double,
                   ctypes.c_int, _dp, _dp, _dp, _dp, _dp]

@@ -19,6 +19,39 @@ def load_track_csv(path):
     return np.loadtxt(path, dtype=np.float64, delimiter=",", skiprows=1, usecols=(0, 1))
 
 
+def load_track_rows(path):
+    """All numeric columns of a track CSV: 3 columns x,y,z or 4 columns x,y,z,bank (README.md:28-35;
+    the reference itself only ever reads columns 0-1, race_track.py:23-25)."""
+    rows = np.loadtxt(path, dtype=np.float64, delimiter=",", skiprows=1, ndmin=2)
+    assert rows.shape[1] in (2, 3, 4), rows.shape
+    return rows
+
+
+def save_track_rows(path, rows):
+    rows = np.asarray(rows, dtype=np.float64)
+    header = ",".join(["x", "y", "z", "bank"][:rows.shape[1]])
+    np.savetxt(path, rows, delimiter=",", header=header, comments="", fmt="%.17g")
+
+
+def bank_on_samples(raw_xy, raw_bank, points):
+    """BASELINE config 4: bank angle [rad] of the raw 4-column track rows carried onto the samples of
+    a trajectory table -- for every sample the two nearest consecutive raw points, linear in the
+    projection onto their segment.  Returns float64 [N] (what goes into Trajectory.BANK, column 13;
+    only the simulator reads it, simulator.py:51-58)."""
+    raw_xy = np.asarray(raw_xy, dtype=np.float64); raw_bank = np.asarray(raw_bank, dtype=np.float64)
+    p = np.asarray(points)[:, :2]
+    d2 = ((p[:, None, :] - raw_xy[None, :, :]) ** 2).sum(axis=2)
+    j = d2.argmin(axis=1)
+    P = len(raw_xy)
+    jn, jp = (j + 1) % P, (j - 1) % P
+    use_next = d2[np.arange(len(p)), jn] <= d2[np.arange(len(p)), jp]
+    j0 = np.where(use_next, j, jp); j1 = np.where(use_next, jn, j)
+    seg = raw_xy[j1] - raw_xy[j0]
+    tpar = ((p - raw_xy[j0]) * seg).sum(axis=1) / np.maximum((seg * seg).sum(axis=1), 1e-300)
+    tpar = np.clip(tpar, 0.0, 1.0)
+    return raw_bank[j0] * (1.0 - tpar) + raw_bank[j1] * tpar
+
+
 def load_monza():
     return (load_track_csv(os.path.join(MONZA_DIR, "MONZA_UNOPTIMIZED_LINE_enu.csv")),
             load_track_csv(os.path.join(MONZA_DIR, "MONZA_LEFT_BOUNDARY_enu.csv")),
@@ -126,6 +159,14 @@ def oval_points(spacing=10.0, heading0=np.deg2rad(17.0)):
             heading += np.pi / 2.0
             pos = c + R * np.array([np.sin(heading), -np.cos(heading)])
     return np.array(pts), np.array(hw)
+
+
+def oval_track_rows(bank_turn_deg=9.2, spacing=10.0):
+    """The oval as 4-column track rows x,y,z,bank (BASELINE config 4): turns banked `bank_turn_deg`
+    (Indianapolis: 9.2 degrees), straights flat, z = 0."""
+    xy, hw = oval_points(spacing)
+    bank = np.where(hw > 8.0, np.deg2rad(bank_turn_deg), 0.0)
+    return np.column_stack([xy, np.zeros(len(xy)), bank])
 
 
 def oval_centerline(s=100.0, k=5):

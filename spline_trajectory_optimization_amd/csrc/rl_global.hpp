@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(MAXB) k_global_qp(GlobalArgs a) {
     reinterpret_cast<double2*>(a.out_ctrl)[(size_t)b * n + j] = make_double2(cxs[j], cys[j]);
   if (a.out_a)
     for (int j = tid; j < np; j += nt) a.out_a[(size_t)b * np + j] = avs[j];
-  double viol = -INFINITY;
+  double viol = -INFINITY, nact = 0.0;
   if (has) {
     for (int r = 0; r < cnt; ++r) {
       const int i = row0 + r;
@@ -608,14 +608,15 @@ __global__ void __launch_bounds__(MAXB) k_global_qp(GlobalArgs a) {
                          (y - a.trk.base[(size_t)N + i]) * a.trk.base[(size_t)3 * N + i];
       const double2 w = reinterpret_cast<const double2*>(wid)[i];
       viol = fmax(viol, fmax(-(w.y - a.margin) - lat, lat - (w.x - a.margin)));
+      if (lat + (w.y - a.margin) < 1e-6 || (w.x - a.margin) - lat < 1e-6) nact += 1.0;
     }
   }
-  double z0 = 0.0, z1 = 0.0;
-  reduce3(z0, viol, z1);
+  double z1 = 0.0;
+  reduce3(nact, viol, z1);
   if (tid == 0) {
     double* st = a.out_stats + (size_t)b * 8;
     st[0] = (double)total_it; st[1] = k2_first; st[2] = k2_last; st[3] = viol; st[4] = last_step;
-    st[5] = 0.0; st[6] = 0.0; st[7] = 0.0;
+    st[5] = nact; st[6] = 0.0; st[7] = 0.0;
   }
 }
 

@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
     // ---- outputs of the row waves: line samples and the largest bound violation
     {
       const double* __restrict__ D0 = a.trk.D;
-      double viol = -INFINITY;
+      double viol = -INFINITY, nact = 0.0;
       if (has) {
         for (int r = 0; r < cnt; ++r) {
           const int i = row0 + r;
@@ -650,10 +650,11 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
                              (y - a.trk.base[(size_t)N + i]) * a.trk.base[(size_t)3 * N + i];
           const double2 lh = reinterpret_cast<const double2*>(lohi)[i];
           viol = fmax(viol, fmax(lh.x - lat, lat - lh.y));
+          if (lat - lh.x < 1e-6 || lh.y - lat < 1e-6) nact += 1.0;
         }
       }
-      viol = wave_max(viol);
-      if (lane == 0) red[32 + wave] = viol;
+      viol = wave_max(viol); nact = wave_sum(nact);
+      if (lane == 0) { red[32 + wave] = viol; red[wave] = nact; }
     }
     __syncthreads();
   } else {
@@ -834,7 +835,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
     if (lane == 0) {
       double* st = a.out_stats + (size_t)b * 8;
       st[0] = (double)total_it; st[1] = k2_first; st[2] = k2_last; st[3] = red_max(2); st[4] = last_step;
-      st[5] = 0.0; st[6] = 0.0; st[7] = 0.0;
+      st[5] = red_sum(0); st[6] = 0.0; st[7] = 0.0;
 #ifdef RL_G2_PROFILE
       st[5] = (double)tF; st[6] = (double)tS; st[7] = ctl[6]; st[1] = ctl[1]; st[2] = ctl[2]; st[3] = ctl[3]; st[4] = ctl[4] + 1e-3 * ctl[5];
 #endif

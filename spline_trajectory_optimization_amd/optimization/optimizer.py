@@ -11,6 +11,9 @@ Differences from the reference, all additive and keyword-only:
     into the returned spline (they only rewrite SPEED/ACC/TIME columns of a table that is
     discarded); they are skipped unless `simulate=True`.
   * the matplotlib visualiser (optimizer.py:261, 331-340) is not constructed.
+  * `run_global_min_curvature_qp` is NEW (no reference counterpart that works: the Julia notebook
+    prototype): the whole line as ONE banded QP per linearisation, solved by the
+    interior-point kernel (include/rl_mincurv.h: rl_mincurv_global_batch_*).
 """
 import numpy as np
 
@@ -165,5 +168,25 @@ class TrajectoryOptimizer:
         traj_out_s._spl_x.c[:] = cx
         traj_out_s._spl_y.c[:] = cy
         self.last_n_success = ns
+        self.last_stats = stats
+        return traj_out_s
+
+    def run_global_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, margin=0.0,
+                                    n_outer=6):
+        """NEW, additive: global min-curvature QP.  The control points of
+        `traj_in_s` slide along the normals of that line; every sample of the result stays within the
+        half-widths |p - L|, |p - R| that `traj_in_d`'s bound columns give it, minus `margin` metres.
+        Returns the optimised BSplineTrajectory; `last_global_stats` = [interior-point iterations,
+        sum kappa^2 before, after, largest bound violation [m], last Gauss-Newton step [m],
+        samples on a bound (active set), 0, 0]."""
+        from .. import batch
+        traj_out_s = traj_in_s.copy()
+        trk = self._device_track(traj_out_s, len(traj_in_d))
+        wl, wr = batch.half_widths_from_bounds(traj_in_d.points)
+        ctrl, xy, a, st, stats = ops.global_batch_host(trk, np.stack([wl, wr], axis=1)[None], margin, n_outer,
+                                                       want_xy=False)
+        traj_out_s._spl_x.c[:] = ctrl[0, :, 0]
+        traj_out_s._spl_y.c[:] = ctrl[0, :, 1]
+        self.last_global_stats = st[0]
         self.last_stats = stats
         return traj_out_s
