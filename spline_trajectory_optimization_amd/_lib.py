@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "librl_mincurv.so")
+LIB_PATH = os.environ.get("RL_LIB_PATH") or os.path.join(_PKG, "librl_mincurv.so")  # RL_LIB_PATH: dev hook for A/B builds
 
 NCOL = 19
 MAX_ITER = 32
