@@ -24,7 +24,9 @@ namespace rl {
 // keeps the scheduler from interleaving the unrolled per-row bodies (register pressure)
 #define RL_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-constexpr int kG2Round = 11;   // span outputs staged per flush round
+// span outputs staged per flush round: 17 (two rounds for the 33 outputs) where the LDS allows it,
+// 12 with three groups of matrix rows (the folded matrix is three times as large there)
+__host__ __device__ constexpr int g2_round(int groups) { return groups == 1 ? 17 : 12; }
 constexpr int kG2Block = 512;  // 7 row waves + 1 linear-algebra wave; 256 VGPRs per lane
 
 struct Global2Layout {  // offsets in doubles
@@ -41,7 +43,7 @@ __host__ __device__ inline Global2Layout global2_layout(int k, int n, int np, in
   L.cxs = take(n); L.cys = take(n); L.nus = take(2 * np);
   L.Pc = take(np * K1);
   L.Ssum = take(np * NO);
-  const int spart = nrow * kG2Round, mf = NS * 64 * groups;  // the folded matrix aliases the staging area
+  const int spart = nrow * g2_round(groups), mf = NS * 64 * groups;  // the folded matrix aliases the staging area
   L.Spart = take(spart > mf ? spart : mf);
   L.lohi = take(2 * N);
   L.red = take(4 * 16);
@@ -186,6 +188,7 @@ __device__ __forceinline__ int fold_inv(int p, int np) { return (p & 1) ? np - 1
 // pieces shared by both roles (every thread of the workgroup calls them with its own tid)
 
 // Ssum[sp * NO + out0 + o] = sum over the chunks of span sp, in chunk order, of Spart[ch * GR + o]
+template <int GR>
 __device__ __forceinline__ void g2_reduce_round(int tid, int nt, int np, const int* sch, const double* Spart,
                                                 double* Ssum, int NO, int out0, int w) {
   for (int task = tid; task < np * w; task += nt) {
@@ -194,11 +197,11 @@ __device__ __forceinline__ void g2_reduce_round(int tid, int nt, int np, const i
     int ch = sch[sp];
     const int ce = sch[sp + 1];
     for (; ch + 4 <= ce; ch += 4) {  // four loads in flight; the additions keep the chunk order
-      const double v0 = Spart[ch * kG2Round + o], v1 = Spart[(ch + 1) * kG2Round + o];
-      const double v2 = Spart[(ch + 2) * kG2Round + o], v3 = Spart[(ch + 3) * kG2Round + o];
+      const double v0 = Spart[ch * GR + o], v1 = Spart[(ch + 1) * GR + o];
+      const double v2 = Spart[(ch + 2) * GR + o], v3 = Spart[(ch + 3) * GR + o];
       sum += v0; sum += v1; sum += v2; sum += v3;
     }
-    for (; ch < ce; ++ch) sum += Spart[ch * kG2Round + o];
+    for (; ch < ce; ++ch) sum += Spart[ch * GR + o];
     Ssum[sp * NO + out0 + o] = sum;
   }
 }
@@ -262,16 +265,16 @@ __device__ __forceinline__ void g2_assemble(int tid, int nt, int np, const doubl
 //       [I2] all: folded normal matrix, rd, rhs                                   -> barrier
 //       [I3] L: convergence test -> ctl[0]; factor; affine solve -> dxs          -> barrier
 //            all: leave the loop when ctl[0] != 0
-//       [I4] R: affine step: ratios, complementarity sums -> red                 -> barrier
-//       [I5] all: alpha_aff, sigma.  R: corrector partials (K+1 outputs) -> Spart -> barrier
-//            all: reduce                                                          -> barrier
-//       [I6] L: second right-hand side; solve -> dxs                             -> barrier
+//       [I4] R: affine step: ratios, complementarity sums -> red; corrector partials A'w0 and
+//            A'(1/sl - 1/su) (2(K+1) outputs) -> Spart                            -> barrier
+//       [I5] all: reduce                                                          -> barrier
+//       [I6] L: alpha_aff, sigma -> ctl[1]; second right-hand side; solve -> dxs -> barrier
 //       [I7] R: step ratios -> red                                                -> barrier
 //       [I8] all: alpha.  R: update slacks/duals.  L: x += alpha dx              -> barrier
 //     [Od] L: a = x, step size                                                   -> barrier
 template <int K, int R, int G>
 __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
-  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1, BW = 2 * K, GR = kG2Round;
+  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1, BW = 2 * K, GR = g2_round(G);
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int nt = blockDim.x, nrw = (nt >> 6) - 1, nrow = nrw * kWave;
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
             if (outer == 0) k2_first = k2_last;
             if (outer == a.n_outer) break;
           }
-          g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+          g2_reduce_round<GR>(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
           __syncthreads();
         }
         if (outer == a.n_outer) break;
@@ -482,7 +485,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
                 if (r0 + o < NO) Spart[tid * GR + o] = acc[o];
             }
             __syncthreads();
-            g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+            g2_reduce_round<GR>(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
             __syncthreads();
           }
         }
@@ -512,8 +515,16 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
           f.d_lu = (-(su[r] * lu[r]) - lu[r] * f.d_su) * f.isu;
           return f;
         };
+        // [I4]+[I5]  one pass: step-length / complementarity statistics of the affine direction AND the
+        // corrector partials.  The corrector weight is affine in sigma*mu,
+        //   w = w0 + smu (1/sl - 1/su),   w0 = (-(sl ll + dsl dll) - ll rpl)/sl - (-(su lu + dsu dlu) - lu rpu)/su,
+        // so A'w0 and A'(1/sl - 1/su) are accumulated side by side (2 (K+1) outputs) and the LA wave, which
+        // computes sigma from the statistics, combines them.
         {
           double c1 = 0.0, c2 = 0.0, rmax = 0.0;
+          double acc[2 * K1];
+#pragma unroll
+          for (int o = 0; o < 2 * K1; ++o) acc[o] = 0.0;
           if (has) {
             double xJ[K1], aJ[K1];
 #pragma unroll
@@ -526,53 +537,30 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
                                        fmax(-f.d_ll * __builtin_amdgcn_rcp(ll[r]), -f.d_lu * __builtin_amdgcn_rcp(lu[r]))));
                 c1 += sl[r] * f.d_ll + ll[r] * f.d_sl + su[r] * f.d_lu + lu[r] * f.d_su;
                 c2 += f.d_sl * f.d_ll + f.d_su * f.d_lu;
+                const double w0 = (-(sl[r] * ll[r] + f.d_sl * f.d_ll) - ll[r] * f.rpl) * f.isl -
+                                  (-(su[r] * lu[r] + f.d_su * f.d_lu) - lu[r] * f.rpu) * f.isu;
+                const double w1 = f.isl - f.isu;
+#pragma unroll
+                for (int al = 0; al < K1; ++al) {
+                  acc[al] = fma(Ar[r][al], w0, acc[al]);
+                  acc[K1 + al] = fma(Ar[r][al], w1, acc[K1 + al]);
+                }
               }
             }
+#pragma unroll
+            for (int o = 0; o < 2 * K1; ++o) Spart[tid * GR + o] = acc[o];
           }
           c1 = wave_sum(c1); c2 = wave_sum(c2); rmax = wave_max(rmax);
           if (lane == 0) { red[wave] = c1; red[16 + wave] = c2; red[32 + wave] = rmax; }
         }
         __syncthreads();
-        G2_LAP(2);
-        // [I5]
-        double smu;
-        {
-          const double c1 = red_sum(0), c2 = red_sum(1), rmax = red_max(2);
-          const double aaff = rmax > 0.995 ? 0.995 / rmax : 1.0;
-          const double mu = mu_sum / (double)(2 * N);
-          const double mu_aff = (mu_sum + aaff * c1 + aaff * aaff * c2) / (double)(2 * N);
-          const double ratio = mu_aff / mu;
-          smu = ratio * ratio * ratio * mu;
-        }
-        {
-          double acc[K1];
-#pragma unroll
-          for (int al = 0; al < K1; ++al) acc[al] = 0.0;
-          if (has) {
-            double xJ[K1], aJ[K1];
-#pragma unroll
-            for (int al = 0; al < K1; ++al) { xJ[al] = xc[J[al]]; aJ[al] = dxa[J[al]]; }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              if (r < cnt) {
-                const RowAff f = row_affine(r, xJ, aJ);
-                const double rcl = sl[r] * ll[r] - smu + f.d_sl * f.d_ll, rcu = su[r] * lu[r] - smu + f.d_su * f.d_lu;
-                const double wv = (-rcl - ll[r] * f.rpl) * f.isl - (-rcu - lu[r] * f.rpu) * f.isu;
-#pragma unroll
-                for (int al = 0; al < K1; ++al) acc[al] = fma(Ar[r][al], wv, acc[al]);
-              }
-            }
-#pragma unroll
-            for (int al = 0; al < K1; ++al) Spart[tid * GR + al] = acc[al];
-          }
-        }
-        __syncthreads();
-        g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, NE, K1);
+        g2_reduce_round<GR>(tid, nt, np, sch, Spart, Ssum, NO, NE, 2 * K1);
         __syncthreads();
         G2_LAP(3);
         // [I6]
         __syncthreads();
         G2_LAP(4);
+        const double smu = ctl[1];
         // [I7], [I8]
         auto row_final = [&](int r, const double (&xJ)[K1], const double (&aJ)[K1], const double (&dJ)[K1],
                              double& d_sl, double& d_su, double& d_ll, double& d_lu, double& isl, double& isu) {
@@ -688,7 +676,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
           if (outer == 0) k2_first = k2_last;
           if (outer == a.n_outer) { done = true; break; }
         }
-        g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+        g2_reduce_round<GR>(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
         __syncthreads();
       }
       if (done) break;
@@ -745,7 +733,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         for (int r0 = 0; r0 < NO; r0 += GR) {
           const int w = NO - r0 < GR ? NO - r0 : GR;
           __syncthreads();
-          g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
+          g2_reduce_round<GR>(tid, nt, np, sch, Spart, Ssum, NO, r0, w);
           __syncthreads();
         }
         // [I2]
@@ -779,25 +767,35 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         __syncthreads();
         if (conv) break;
         ++total_it;
-        // [I4]
+        // [I4]+[I5]
         __syncthreads();
-        // [I5]
+        g2_reduce_round<GR>(tid, nt, np, sch, Spart, Ssum, NO, NE, 2 * K1);
         __syncthreads();
-        g2_reduce_round(tid, nt, np, sch, Spart, Ssum, NO, NE, K1);
-        __syncthreads();
-        // [I6]
+        // [I6]  sigma from the affine statistics, second right-hand side, solve
+        double smu;
+        {
+          const double c1 = red_sum(0), c2 = red_sum(1), rmax = red_max(2);
+          const double aaff = rmax > 0.995 ? 0.995 / rmax : 1.0;
+          const double mu = mu_sum / (double)(2 * N);
+          const double mu_aff = (mu_sum + aaff * c1 + aaff * aaff * c2) / (double)(2 * N);
+          const double ratio = mu_aff / mu;
+          smu = ratio * ratio * ratio * mu;
+          if (lane == 0) ctl[1] = smu;
+        }
 #pragma unroll
         for (int q = 0; q < G; ++q) {
           const int p = lane + 64 * q;
           double v = 0.0;
           if (p < np) {
             const int j = fold_inv(p, np);
+            double v1 = 0.0;
             for (int al = 0; al <= K; ++al) {
               int sp = j - al;
               if (sp < 0) sp += np;
               v += Ssum[sp * NO + NE + al];
+              v1 += Ssum[sp * NO + NE + K1 + al];
             }
-            v -= rd[j];
+            v = fma(smu, v1, v) - rd[j];
           }
           bx[q] = v;
         }
