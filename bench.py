@@ -10,7 +10,9 @@ One "solve" = the reference's complete TrajectoryOptimizer.run_min_curvature_qp 
 (optimizer.py:256-341, max_iter=5 -> 5 x (forward + backward) sweeps over the 61 free control
 points = 610 control-point QPs, each followed by re-sampling and boundary re-intersection), sweep
 order pinned.  One "step" = one launch of the sweep kernel over the rank's whole batch, inputs
-already resident in HBM; for N>1 ranks the step ends with the single gather of the results to rank 0.
+already resident in HBM; for N>1 ranks every step is followed by the single gather of the results to
+rank 0, issued asynchronously (double-buffered outputs) so that it overlaps the next step's launch; the
+timed region ends only after the last gather has completed.
 
 Prints ONE JSON line (rank 0).  See the repo instructions for the field contract.
 """
@@ -157,13 +159,39 @@ def main():
     torch.cuda.synchronize()
     stats = out["stats"]
 
-    def step():
-        ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search, out=out)
-        if world > 1:
-            batch.gather_to_root(out["xy"], rank, world, dist)
+    # N > 1: the gather of step s runs on the process group's stream while step s+1 computes into the
+    # other output set (double buffering); a buffer is reused only after its gather has completed.
+    outs = [out, None]
+    gathered = None
+    if world > 1:
+        outs[1] = {kk: (vv.clone() if hasattr(vv, "clone") else vv) for kk, vv in out.items()}
+        if rank == 0:
+            gathered = [torch.empty((world * B,) + tuple(out["xy"].shape[1:]), dtype=torch.float64, device=dev)
+                        for _ in range(2)]
+    works = [None, None]
 
-    for _ in range(args.warmup):
-        step()
+    def step(s, events=None):
+        slot = s & 1 if world > 1 else 0
+        if works[slot] is not None:
+            works[slot].wait()          # stream-level wait: the buffer's previous gather is done
+        if events is not None:
+            events[0].record()
+        ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search, out=outs[slot])
+        if events is not None:
+            events[1].record()          # kernel-only span on the launch stream (torch's current stream)
+        if world > 1:
+            works[slot] = batch.gather_to_root(outs[slot]["xy"], rank, world, dist,
+                                               out=gathered[slot] if rank == 0 else None, async_op=True)
+
+    def drain():
+        for q in range(2):
+            if works[q] is not None:
+                works[q].wait()
+                works[q] = None
+
+    for w_ in range(args.warmup):
+        step(w_)
+    drain()
     # ---- timed region: barrier + sync on both sides, exactly K steps
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
@@ -171,11 +199,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        ev[s][0].record()
-        ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search, out=out)
-        ev[s][1].record()  # kernel-only span on the launch stream (torch's current stream)
-        if world > 1:
-            batch.gather_to_root(out["xy"], rank, world, dist)
+        step(s, ev[s])
+    drain()                     # every gather has landed on rank 0 before the clock stops
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -187,9 +212,12 @@ def main():
         elapsed = float(tmax.item())
 
     # sanity outside the timed region: results are finite and the bookkeeping is consistent
-    status = out["status"].cpu().numpy()
-    ns = out["n_success"].cpu().numpy()
-    xy = out["xy"].cpu().numpy()
+    last = outs[(args.steps - 1) & 1] if world > 1 else out
+    status = last["status"].cpu().numpy()
+    ns = last["n_success"].cpu().numpy()
+    xy = last["xy"].cpu().numpy()
+    if world > 1 and rank == 0:  # rank 0's own shard came back through the collective unchanged
+        assert torch.equal(gathered[(args.steps - 1) & 1][:B], last["xy"])
     if os.environ.get('RL_DEBUG_FLAGS', '0') == '0':
         assert np.isfinite(xy).all()
     assert os.environ.get('RL_DEBUG_FLAGS', '0') != '0' or np.array_equal(status, 2 * MAX_ITER * (n - 5) - ns.reshape(B, -1).sum(axis=1))
@@ -219,7 +247,7 @@ def main():
                 "spline": f"s={SPLINE_S:g} k={SPLINE_K} n={n}", "batch_per_gpu": B,
                 "control_point_qps_per_s": value * qp_per_solve, "search": args.search,
                 "parallelism": f"{world} rank(s) x independent instances"
-                               + (", 1 RCCL gather to rank 0 per step" if world > 1 else ""),
+                               + (", 1 RCCL gather to rank 0 per step (overlapped with the next step)" if world > 1 else ""),
                 "lds_bytes_per_workgroup": int(stats.lds_bytes), "block_threads": int(stats.block_threads),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -101,14 +101,18 @@ def shard_range(B, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_to_root(tensor, rank, world, dist, total=None):
+def gather_to_root(tensor, rank, world, dist, total=None, out=None, async_op=False):
     """The single collective of the path: every rank's result shard to rank 0 (RCCL `gather` over
     xGMI; gloo in the CPU tests).  `total` = global instance count when the shards come from
     shard_range(total, r, world) (they may then differ by one instance and are padded to the
-    largest); None = every rank holds the same number of instances (weak scaling)."""
+    largest); None = every rank holds the same number of instances (weak scaling).
+    `out` (rank 0, equal shards only): preallocated [world * B, ...] tensor the shards land in directly,
+    no concatenation.  `async_op=True` returns the collective's work handle instead of the result: the
+    gather then runs on the process group's own stream, ordered after what is already enqueued on the
+    current stream, and overlaps with whatever the caller enqueues next (bench.py: the next launch)."""
     import torch
     if world == 1:
-        return tensor
+        return None if async_op else tensor
     if total is None:
         counts = [tensor.shape[0]] * world
     else:
@@ -118,10 +122,20 @@ def gather_to_root(tensor, rank, world, dist, total=None):
     if tensor.shape[0] < mx:
         pad = torch.cat([tensor, tensor.new_zeros((mx - tensor.shape[0],) + tuple(tensor.shape[1:]))])
     pad = pad.contiguous()
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-    dist.gather(pad, bufs, dst=0)
+    bufs = None
+    if rank == 0:
+        if out is not None:
+            assert total is None and out.shape[0] == world * mx and out.is_contiguous()
+            bufs = list(out.view((world, mx) + tuple(tensor.shape[1:])).unbind(0))
+        else:
+            bufs = [torch.empty_like(pad) for _ in range(world)]
+    work = dist.gather(pad, bufs, dst=0, async_op=async_op)
+    if async_op:
+        return work
     if rank != 0:
         return None
+    if out is not None:
+        return out
     return torch.cat([b[:c] for b, c in zip(bufs, counts)])
 
 

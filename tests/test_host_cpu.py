@@ -109,6 +109,23 @@ if rank == 0:
     print("GLOO_OK")
 else:
     assert full is None
+# the weak-scaling form bench.py uses: equal shards, preallocated destination, asynchronous, double buffered
+mine = [torch.full((3, N, 2), float(10 * s_ + rank), dtype=torch.float64) for s_ in range(4)]
+dst = [torch.zeros((world * 3, N, 2), dtype=torch.float64) for _ in range(2)] if rank == 0 else [None, None]
+works = [None, None]
+for s_ in range(4):
+    q = s_ & 1
+    if works[q] is not None:
+        works[q].wait()
+        if rank == 0:
+            assert all(float(dst[q][3 * r_, 0, 0]) == 10 * (s_ - 2) + r_ for r_ in range(world))
+    works[q] = batch.gather_to_root(mine[s_], rank, world, dist, out=dst[q], async_op=True)
+for q in range(2):
+    works[q].wait()
+if rank == 0:
+    assert all(float(dst[1][3 * r_, 5, 1]) == 30 + r_ for r_ in range(world))
+    assert all(float(dst[0][3 * r_ + 2, 5, 1]) == 20 + r_ for r_ in range(world))
+    print("ASYNC_OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -122,7 +139,7 @@ def test_sharded_solve_and_gather_gloo_world2(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "GLOO_OK" in out.stdout
+    assert "GLOO_OK" in out.stdout and "ASYNC_OK" in out.stdout
 
 
 def test_ttl_and_csv_formats_roundtrip(tmp_path, built):
