@@ -251,6 +251,42 @@ __device__ __forceinline__ void g2_assemble(int tid, int nt, int np, const doubl
   }
 }
 
+// The chunk's constraint rows: register resident (AREG, R <= 6: 12 R VGPRs), or, for long chunks
+// (N up to ~4400 with R = 10), re-read from the L2-resident table in every pass.
+template <int K1, int R, bool AREG>
+struct ChunkRows;
+template <int K1, int R>
+struct ChunkRows<K1, R, true> {
+  double a[R][K1];
+  __device__ __forceinline__ void load(const double* A, int row0, int cnt) {
+    const double* Ap = A;
+    asm volatile("" : "+s"(Ap));  // keeps the loads where they are (after the register-hungry curvature pass)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int al = 0; al < K1; ++al) a[r][al] = r < cnt ? Ap[(size_t)(row0 + r) * K1 + al] : 0.0;
+  }
+  __device__ __forceinline__ void get(int r, double (&o)[K1]) const {
+#pragma unroll
+    for (int al = 0; al < K1; ++al) o[al] = a[r][al];
+  }
+};
+template <int K1, int R>
+struct ChunkRows<K1, R, false> {
+  const double* p;
+  int cnt;
+  __device__ __forceinline__ void load(const double* A, int row0, int cnt_) { p = A + (size_t)row0 * K1; cnt = cnt_; }
+  __device__ __forceinline__ void get(int r, double (&o)[K1]) const {
+    static_assert(K1 % 2 == 0, "rows are read as double2");
+    const double2* q = reinterpret_cast<const double2*>(p + (size_t)r * K1);
+#pragma unroll
+    for (int al = 0; al < K1; al += 2) {
+      const double2 v = r < cnt ? q[al / 2] : make_double2(0.0, 0.0);
+      o[al] = v.x; o[al + 1] = v.y;
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Barrier protocol.  Both roles execute exactly this sequence (R = row waves, L = linear-algebra wave):
 //
@@ -272,7 +308,7 @@ __device__ __forceinline__ void g2_assemble(int tid, int nt, int np, const doubl
 //       [I7] R: step ratios -> red                                                -> barrier
 //       [I8] all: alpha.  R: update slacks/duals.  L: x += alpha dx              -> barrier
 //     [Od] L: a = x, step size                                                   -> barrier
-template <int K, int R, int G>
+template <int K, int R, int G, bool AREG>
 __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
   constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1, BW = 2 * K, GR = g2_round(G);
   extern __shared__ double lds[];
@@ -314,7 +350,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
     int J[K1];
 #pragma unroll
     for (int al = 0; al < K1; ++al) { J[al] = sp0 + al; if (J[al] >= np) J[al] -= np; }
-    double Ar[R][K1];
+    ChunkRows<K1, R, AREG> rows;
     const double* __restrict__ D1 = a.trk.D + (size_t)K1 * N;
     const double* __restrict__ D2 = a.trk.D + (size_t)2 * K1 * N;
     double sl[R] = {}, su[R] = {}, ll[R] = {}, lu[R] = {};
@@ -397,23 +433,17 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
       }
       // [Oc]  the chunk's constraint rows are (re)loaded here, after the register-hungry curvature
       // pass, so that they are not live across it; the laundered pointer keeps the loads in the loop
-      {
-        const double* Ap = a.A;
-        asm volatile("" : "+s"(Ap));
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int al = 0; al < K1; ++al) Ar[r][al] = r < cnt ? Ap[(size_t)(row0 + r) * K1 + al] : 0.0;
-      }
+      rows.load(a.A, row0, cnt);
       if (has) {
         double xJ[K1];
 #pragma unroll
         for (int al = 0; al < K1; ++al) xJ[al] = avs[J[al]];
 #pragma unroll
         for (int r = 0; r < R; ++r) { RL_ROW_FENCE();
-          double ax = 0.0;
+          double Av[K1], ax = 0.0;
+          rows.get(r, Av);
 #pragma unroll
-          for (int al = 0; al < K1; ++al) ax = fma(Ar[r][al], xJ[al], ax);
+          for (int al = 0; al < K1; ++al) ax = fma(Av[al], xJ[al], ax);
           const double2 lh = r < cnt ? reinterpret_cast<const double2*>(lohi)[row0 + r] : make_double2(-1.0, 1.0);
           if (outer == 0) {
             sl[r] = fmax(ax - lh.x, 1e-2); su[r] = fmax(lh.y - ax, 1e-2);
@@ -447,9 +477,10 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
                 for (int r = 0; r < R; ++r) { RL_ROW_FENCE();
                   dmv[r] = 0.0; ev[r] = 0.0; dlv[r] = 0.0;
                   if (r < cnt) {
-                    double ax = 0.0;
+                    double Av[K1], ax = 0.0;
+                    rows.get(r, Av);
 #pragma unroll
-                    for (int al = 0; al < K1; ++al) ax = fma(Ar[r][al], xJ[al], ax);
+                    for (int al = 0; al < K1; ++al) ax = fma(Av[al], xJ[al], ax);
                     const double2 lh = reinterpret_cast<const double2*>(lohi)[row0 + r];
                     const double rpl = ax - lh.x - sl[r], rpu = lh.y - ax - su[r];
                     const double ql = ll[r] * frcp(sl[r]), qu = lu[r] * frcp(su[r]);
@@ -466,18 +497,20 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
 #pragma unroll
               for (int r = 0; r < R; ++r) { RL_ROW_FENCE();
                 // rows beyond cnt have A = 0 and dm = e = dl = 0: they add nothing
+                double Av[K1];
+                rows.get(r, Av);
                 int o = 0;
 #pragma unroll
                 for (int al = 0; al < K1; ++al) {
-                  const double wa = dmv[r] * Ar[r][al];
+                  const double wa = dmv[r] * Av[al];
 #pragma unroll
                   for (int be = 0; be <= al; ++be) {
-                    if (o >= r0 && o < r0 + GR) acc[o - r0] = fma(wa, Ar[r][be], acc[o - r0]);
+                    if (o >= r0 && o < r0 + GR) acc[o - r0] = fma(wa, Av[be], acc[o - r0]);
                     ++o;
                   }
-                  if (NE + al >= r0 && NE + al < r0 + GR) acc[NE + al - r0] = fma(Ar[r][al], ev[r], acc[NE + al - r0]);
+                  if (NE + al >= r0 && NE + al < r0 + GR) acc[NE + al - r0] = fma(Av[al], ev[r], acc[NE + al - r0]);
                   if (NE + K1 + al >= r0 && NE + K1 + al < r0 + GR)
-                    acc[NE + K1 + al - r0] = fma(Ar[r][al], dlv[r], acc[NE + K1 + al - r0]);
+                    acc[NE + K1 + al - r0] = fma(Av[al], dlv[r], acc[NE + K1 + al - r0]);
                 }
               }
 #pragma unroll
@@ -502,11 +535,11 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         // [I4]..[I8]  Nothing but the slacks and duals is carried across a barrier: every pass rebuilds
         // the row quantities it needs from x, the affine direction dxa and the final direction dxs.
         struct RowAff { double rpl, rpu, isl, isu, d_sl, d_su, d_ll, d_lu; };
-        auto row_affine = [&](int r, const double (&xJ)[K1], const double (&aJ)[K1]) {
+        auto row_affine = [&](int r, const double (&Av)[K1], const double (&xJ)[K1], const double (&aJ)[K1]) {
           RowAff f;
           double ax = 0.0, adx = 0.0;
 #pragma unroll
-          for (int al = 0; al < K1; ++al) { ax = fma(Ar[r][al], xJ[al], ax); adx = fma(Ar[r][al], aJ[al], adx); }
+          for (int al = 0; al < K1; ++al) { ax = fma(Av[al], xJ[al], ax); adx = fma(Av[al], aJ[al], adx); }
           const double2 lh = reinterpret_cast<const double2*>(lohi)[row0 + r];
           f.rpl = ax - lh.x - sl[r]; f.rpu = lh.y - ax - su[r];
           f.isl = frcp(sl[r]); f.isu = frcp(su[r]);
@@ -532,7 +565,9 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               if (r < cnt) {
-                const RowAff f = row_affine(r, xJ, aJ);
+                double Av[K1];
+                rows.get(r, Av);
+                const RowAff f = row_affine(r, Av, xJ, aJ);
                 rmax = fmax(rmax, fmax(fmax(-f.d_sl * f.isl, -f.d_su * f.isu),
                                        fmax(-f.d_ll * __builtin_amdgcn_rcp(ll[r]), -f.d_lu * __builtin_amdgcn_rcp(lu[r]))));
                 c1 += sl[r] * f.d_ll + ll[r] * f.d_sl + su[r] * f.d_lu + lu[r] * f.d_su;
@@ -542,8 +577,8 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
                 const double w1 = f.isl - f.isu;
 #pragma unroll
                 for (int al = 0; al < K1; ++al) {
-                  acc[al] = fma(Ar[r][al], w0, acc[al]);
-                  acc[K1 + al] = fma(Ar[r][al], w1, acc[K1 + al]);
+                  acc[al] = fma(Av[al], w0, acc[al]);
+                  acc[K1 + al] = fma(Av[al], w1, acc[K1 + al]);
                 }
               }
             }
@@ -564,10 +599,12 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         // [I7], [I8]
         auto row_final = [&](int r, const double (&xJ)[K1], const double (&aJ)[K1], const double (&dJ)[K1],
                              double& d_sl, double& d_su, double& d_ll, double& d_lu, double& isl, double& isu) {
-          const RowAff f = row_affine(r, xJ, aJ);
+          double Av[K1];
+          rows.get(r, Av);
+          const RowAff f = row_affine(r, Av, xJ, aJ);
           double adx = 0.0;
 #pragma unroll
-          for (int al = 0; al < K1; ++al) adx = fma(Ar[r][al], dJ[al], adx);
+          for (int al = 0; al < K1; ++al) adx = fma(Av[al], dJ[al], adx);
           const double rcl = sl[r] * ll[r] - smu + f.d_sl * f.d_ll, rcu = su[r] * lu[r] - smu + f.d_su * f.d_lu;
           d_sl = adx + f.rpl; d_su = f.rpu - adx;
           d_ll = (-rcl - ll[r] * d_sl) * f.isl; d_lu = (-rcu - lu[r] * d_su) * f.isu;

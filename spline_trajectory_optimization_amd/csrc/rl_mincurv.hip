@@ -635,7 +635,7 @@ int global_tables(const rl_ctx* ctx, const rl_track* trk) {
   std::vector<int> chunk, span, chunk2, span2;
   const int nc = partition(rl::kGRows, chunk, span);
   int rows2 = 0, nc2 = 0;
-  for (int R : {5, 6}) {  // fewest rows per thread whose chunks fit the row waves of k_global_qp2
+  for (int R : {5, 6, 10}) {  // fewest rows per thread whose chunks fit the row waves of k_global_qp2
     nc2 = partition(R, chunk2, span2);
     if (nc2 <= rl::kG2Block - 64) { rows2 = R; break; }
   }
@@ -674,9 +674,9 @@ int launch_global_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block
   return RL_OK;
 }
 
-template <int K, int R, int G>
+template <int K, int R, int G, bool AREG>
 int launch_global2_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block, size_t lds) {
-  auto kern = rl::k_global_qp2<K, R, G>;
+  auto kern = rl::k_global_qp2<K, R, G, AREG>;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B), dim3(block), lds, ctx->stream, a);
@@ -704,18 +704,21 @@ int global_common(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,
     const int block2 = ((trk->gq2_nc + 63) / 64 + 1) * 64;
     const size_t lds2 = (size_t)rl::global2_layout(trk->k, trk->n, a.np, trk->N, groups, block2 - 64).total * sizeof(double);
     if (lds2 <= (size_t)ctx->max_lds) {
-      a.chunk = trk->gq2_chunk.p; a.span_ch0 = trk->gq2_span.p; a.nc = trk->gq2_nc;
-      if (stats) { stats->lds_bytes = (int)lds2; stats->block_threads = block2; stats->rings_in_lds = 0; }
-      const int sel = (trk->k == 3 ? 0 : 4) + (trk->gq2_rows == 5 ? 0 : 2) + (groups == 1 ? 0 : 1);
-      switch (sel) {
-        case 0: return launch_global2_t<3, 5, 1>(ctx, a, B, block2, lds2);
-        case 1: return launch_global2_t<3, 5, 3>(ctx, a, B, block2, lds2);
-        case 2: return launch_global2_t<3, 6, 1>(ctx, a, B, block2, lds2);
-        case 3: return launch_global2_t<3, 6, 3>(ctx, a, B, block2, lds2);
-        case 4: return launch_global2_t<5, 5, 1>(ctx, a, B, block2, lds2);
-        case 5: return launch_global2_t<5, 5, 3>(ctx, a, B, block2, lds2);
-        case 6: return launch_global2_t<5, 6, 1>(ctx, a, B, block2, lds2);
-        default: return launch_global2_t<5, 6, 3>(ctx, a, B, block2, lds2);
+      // R = 5, 6: constraint rows register resident; R = 10 (N up to ~4400): re-read from L2, one group only
+      const int R = trk->gq2_rows;
+      if (R != 10 || groups == 1) {
+        a.chunk = trk->gq2_chunk.p; a.span_ch0 = trk->gq2_span.p; a.nc = trk->gq2_nc;
+        if (stats) { stats->lds_bytes = (int)lds2; stats->block_threads = block2; stats->rings_in_lds = 0; }
+#define RL_G2_LAUNCH(KK, RR, GG, AR) return launch_global2_t<KK, RR, GG, AR>(ctx, a, B, block2, lds2)
+        if (trk->k == 3) {
+          if (R == 5) { if (groups == 1) RL_G2_LAUNCH(3, 5, 1, true); RL_G2_LAUNCH(3, 5, 3, true); }
+          if (R == 6) { if (groups == 1) RL_G2_LAUNCH(3, 6, 1, true); RL_G2_LAUNCH(3, 6, 3, true); }
+          RL_G2_LAUNCH(3, 10, 1, false);
+        }
+        if (R == 5) { if (groups == 1) RL_G2_LAUNCH(5, 5, 1, true); RL_G2_LAUNCH(5, 5, 3, true); }
+        if (R == 6) { if (groups == 1) RL_G2_LAUNCH(5, 6, 1, true); RL_G2_LAUNCH(5, 6, 3, true); }
+        RL_G2_LAUNCH(5, 10, 1, false);
+#undef RL_G2_LAUNCH
       }
     }
   }
