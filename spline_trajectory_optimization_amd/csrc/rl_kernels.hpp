@@ -988,8 +988,9 @@ struct QssArgs {
   const double* acc_x; const double* acc_c; int acc_m;   // CubicSpline pieces of Vehicle.acc_intp
   const double* dcc_x; const double* dcc_c; int dcc_m;   //                     Vehicle.dcc_intp
   double max_lon_acc, max_lon_dcc, max_left_acc, max_right_acc, max_speed, max_jerk;
-  int* flags;            // [B][cap][5] scratch: entry idx, turn idx, exit idx, entry stop, exit stop
+  int* flags;            // [B][5][cap] scratch, one array per field: entry idx, turn idx, exit idx, entry stop, exit stop
   int* fresh;            // [B][cap] scratch: fronts spawned during one global iteration
+  double* cst;           // [B][3][N] scratch: segment length |p_i - p_{i-1}|, turn radius, 9.81 sin(bank)
   int cap;
   int* iters;            // [B] out: global iterations, -1 where the reference would have raised
 };
@@ -1025,113 +1026,200 @@ __device__ __forceinline__ double qss_lat_acc(double v, double r, double bank) {
   return v * v / r + 9.81 * sin(bank);  // simulator.py:51-52
 }
 
+// One wave per instance.  The speed profile (speed, longitudinal acceleration, owner) lives in LDS,
+// the per-point constants in an L2-resident scratch, the vehicle lookup tables in LDS.
+//
+// The reference steps the fronts of a sub-pass strictly in list order, each seeing the writes of the
+// fronts before it.  Here the list is taken 64 fronts at a time, one front per lane, by SPECULATION
+// WITH PREFIX COMMIT: every pending lane computes its step from the current profile; lanes that
+// would write stamp their target point with their lane number (LDS atomic min); a lane is
+// conflicted when an EARLIER lane writes its source or its target point; all lanes before the
+// first conflicted one are exactly what the sequential order would have produced (their inputs
+// were untouched), so they commit together; the rest is re-speculated on the new profile.  The
+// first lane of a round is never conflicted, so every round commits at least one front; fronts that
+// stop without writing (the common case) never conflict, and chains of actual writes degrade to the
+// sequential order.  Spawned fronts are appended in list order (ballot prefix) and finished fronts
+// compacted away by all lanes at the end of each global iteration.
 __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
 #pragma clang fp contract(off)  // decisions below compare freshly computed speeds: keep the reference's roundings
-  const int b = blockIdx.x, N = a.N, lane = threadIdx.x;
+  extern __shared__ double qss_lds[];
+  const int b = blockIdx.x, N = a.N, lane = threadIdx.x, cap = a.cap;
   double* P = a.points + (size_t)b * N * 19;
-  int* fl = a.flags + (size_t)b * a.cap * 5;
-  int* nw = a.fresh + (size_t)b * a.cap;
+  double* V = qss_lds;             // [N] SPEED
+  double* A = qss_lds + N;         // [N] LON_ACC
+  double* tab = qss_lds + 2 * N;   // acc_x [m+1], acc_c [4m], dcc_x [m'+1], dcc_c [4m']
+  double* t_ax = tab; double* t_ac = t_ax + a.acc_m + 1;
+  double* t_dx = t_ac + 4 * a.acc_m; double* t_dc = t_dx + a.dcc_m + 1;
+  int* OWN = reinterpret_cast<int*>(t_dc + 4 * a.dcc_m);  // [N] ITERATION_FLAG
+  int* STAMP = OWN + N;                                    // [N] lowest lane writing this point in the current round
+  int* fE = a.flags + (size_t)b * 5 * cap;
+  int* fT = fE + cap; int* fX = fT + cap; int* sE = fX + cap; int* sX = sE + cap;
+  int* nw = a.fresh + (size_t)b * cap;
+  double* SEG = a.cst + (size_t)b * 3 * N;
+  double* RAD = SEG + N;
+  double* GS = RAD + N;
+  constexpr int kFree = 0x7fffffff;
   const double lat0 = qss_acc_circle_lon(a, 0.0);
+  for (int i = lane; i <= a.acc_m; i += 64) t_ax[i] = a.acc_x[i];
+  for (int i = lane; i < 4 * a.acc_m; i += 64) t_ac[i] = a.acc_c[i];
+  for (int i = lane; i <= a.dcc_m; i += 64) t_dx[i] = a.dcc_x[i];
+  for (int i = lane; i < 4 * a.dcc_m; i += 64) t_dc[i] = a.dcc_c[i];
   for (int i = lane; i < N; i += 64) {  // simulator.py:133-147
-    double* p = P + (size_t)i * 19;
+    const double* p = P + (size_t)i * 19;
+    const double* q = P + (size_t)(i == 0 ? N - 1 : i - 1) * 19;
+    const double ddx = p[0] - q[0], ddy = p[1] - q[1];
+    SEG[i] = sqrt(ddx * ddx + ddy * ddy);
+    RAD[i] = p[5];
+    GS[i] = 9.81 * sin(p[13]);
     const double v = qss_calc_v(lat0, p[5], p[13]);
-    p[4] = v < a.max_speed ? v : a.max_speed;
-    p[14] = 0.0;
-    p[15] = qss_lat_acc(p[4], p[5], p[13]);
-    p[18] = (double)i;
-    int* F = fl + 5 * i;
-    F[0] = i; F[1] = i; F[2] = i; F[3] = 0; F[4] = 0;
+    V[i] = v < a.max_speed ? v : a.max_speed;
+    A[i] = 0.0;
+    OWN[i] = i;
+    STAMP[i] = kFree;
+    fE[i] = i; fT[i] = i; fX[i] = i; sE[i] = 0; sX[i] = 0;
   }
   __syncthreads();
-  __shared__ int s_err, s_itr;
-  if (lane == 0) {
-    int nf = N, itr = 0, err = 0;
-    while (!err) {
-      int nnew = 0;
-      for (int side = 0; side < 2 && !err; ++side) {  // 0: enter (:154-254), 1: exit (:257-348)
-        for (int f = 0; f < nf; ++f) {
-          int* F = fl + 5 * f;
-          if (F[3 + side] == 1) continue;
-          const int li = F[2 * side];
-          const int ni = side == 0 ? (li - 1 < 0 ? N - 1 : li - 1) : (li + 1 == N ? 0 : li + 1);
-          F[2 * side] = ni;
-          const double* pl = P + (size_t)li * 19;
-          double* pn = P + (size_t)ni * 19;
-          const double ddx = pl[0] - pn[0], ddy = pl[1] - pn[1];
-          const double dd = sqrt(ddx * ddx + ddy * ddy);
-          const double lv = pl[4], la = pl[14];
-          if (lv == 0.0) { err = 1; break; }
-          const double dt = dd / lv;
-          const double max_dacc = dt * a.max_jerk;
-          double max_acc = la + max_dacc, min_acc = la - max_dacc;
-          const double vmax_acc = ppoly_eval(a.acc_x, a.acc_c, a.acc_m, lv);
-          const double vmax_dcc = ppoly_eval(a.dcc_x, a.dcc_c, a.dcc_m, lv);
-          max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
-          min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
-          double min_state, max_state;
-          if (side == 0) {  // v0^2 = v^2 - 2 a x
-            const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
-            min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-          } else {          // v^2 = 2 a x + v0^2
-            const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
-            max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-          }
-          const double max_curve = qss_calc_v(qss_acc_circle_lon(a, la), pn[5], pn[13]);
-          double greedy = max_state < max_curve ? max_state : max_curve;
-          if (a.max_speed < greedy) greedy = a.max_speed;
-          if (greedy != greedy) { err = 1; break; }
-          if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve &&
-              greedy <= a.max_speed) {
-            if (pn[18] != -1.0 && pn[4] < greedy) {
-              F[3 + side] = 1;  // a slower profile already owns this point: stop
-            } else {
-              if (!(min_acc <= pn[14] && pn[14] <= max_acc)) F[3 + side] = -1;  // merge mode
-              pn[4] = greedy;
-              pn[14] = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
-              pn[15] = qss_lat_acc(greedy, pn[5], pn[13]);
-              pn[18] = (double)F[1];
+  int nf = N, itr = 0, err = 0;
+  while (true) {
+    int nnew = 0;
+    for (int side = 0; side < 2 && !err; ++side) {  // 0: enter (:154-254), 1: exit (:257-348)
+      int* pos = side == 0 ? fE : fX;
+      int* stp = side == 0 ? sE : sX;
+      for (int base = 0; base < nf && !err; base += 64) {
+        const int f = base + lane;
+        const bool in = f < nf;
+        int my_stop = in ? stp[f] : 1;
+        int li = in ? pos[f] : 0;
+        const int turn = in ? fT[f] : 0;
+        const bool active = my_stop != 1;
+        int ni = side == 0 ? (li - 1 < 0 ? N - 1 : li - 1) : (li + 1 == N ? 0 : li + 1);
+        double dd = 0.0, rn = 0.0, gsn = 0.0;
+        if (active) { dd = SEG[side == 0 ? li : ni]; rn = RAD[ni]; gsn = GS[ni]; }
+        unsigned long long pending = __ballot(active);
+        while (pending != 0ull && !err) {
+          const bool mine = (pending >> lane) & 1ull;
+          int new_stop = 0, e = 0, spawned = 0, wr = 0, nown = 0;
+          double nv = 0.0, na = 0.0;
+          if (mine) {
+            const double lv = V[li], la = A[li];
+            if (lv == 0.0) { e = 1; }
+            else {
+              const double dt = dd / lv;
+              const double max_dacc = dt * a.max_jerk;
+              double max_acc = la + max_dacc, min_acc = la - max_dacc;
+              const double vmax_acc = ppoly_eval(t_ax, t_ac, a.acc_m, lv);
+              const double vmax_dcc = ppoly_eval(t_dx, t_dc, a.dcc_m, lv);
+              max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
+              min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
+              double min_state, max_state;
+              if (side == 0) {  // v0^2 = v^2 - 2 a x
+                const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
+                min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+              } else {          // v^2 = 2 a x + v0^2
+                const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
+                max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+              }
+              const double max_curve = sqrt(fabs(fabs(qss_acc_circle_lon(a, la)) - gsn) * rn);  // calc_v, :54-55
+              double greedy = max_state < max_curve ? max_state : max_curve;
+              if (a.max_speed < greedy) greedy = a.max_speed;
+              if (greedy != greedy) { e = 1; }
+              else if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve &&
+                       greedy <= a.max_speed) {
+                const double pv = V[ni], pa = A[ni];
+                if (OWN[ni] != -1 && pv < greedy) {
+                  new_stop = 1;  // a slower profile already owns this point: stop
+                } else {
+                  if (!(min_acc <= pa && pa <= max_acc)) new_stop = -1;  // merge mode
+                  wr = 1; nv = greedy; nown = turn;
+                  na = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
+                }
+              } else {
+                new_stop = 1;
+                if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
+                  spawned = 1; wr = 1;
+                  const double v = sqrt(fabs(fabs(lat0) - gsn) * rn);
+                  nv = v < a.max_speed ? v : a.max_speed;
+                  na = 0.0; nown = ni;
+                }
+              }
             }
-          } else {
-            F[3 + side] = 1;
-            if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
-              if (nf + nnew < a.cap) nw[nnew++] = ni;
-              const double v = qss_calc_v(lat0, pn[5], pn[13]);
-              pn[4] = v < a.max_speed ? v : a.max_speed;
-              pn[14] = 0.0;
-              pn[15] = qss_lat_acc(pn[4], pn[5], pn[13]);
-              pn[18] = (double)ni;
-            }
+            if (wr) atomicMin(&STAMP[ni], lane);
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          bool confl = false;
+          if (mine) { const int s1 = STAMP[li], s2 = STAMP[ni]; confl = (s1 < s2 ? s1 : s2) < lane; }
+          const unsigned long long cm = __ballot(confl);
+          const int qstar = cm != 0ull ? __ffsll((long long)cm) - 1 : 64;
+          const bool commit = mine && lane < qstar;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (mine && wr) STAMP[ni] = kFree;
+          if (commit) {
+            if (wr) { V[ni] = nv; A[ni] = na; OWN[ni] = nown; }
+            li = ni;
+            ni = side == 0 ? (li - 1 < 0 ? N - 1 : li - 1) : (li + 1 == N ? 0 : li + 1);  // unused: one step per sub-pass
+            if (new_stop != 0) my_stop = new_stop;
+          }
+          if (__any(commit && e)) err = 1;
+          const unsigned long long sm = __ballot(commit && spawned);
+          if (commit && spawned) {
+            const int idx = nnew + __popcll(sm & ((1ull << lane) - 1ull));
+            if (nf + idx < cap) nw[idx] = li;
+          }
+          nnew += __popcll(sm);
+          if (nf + nnew > cap) nnew = cap - nf;
+          pending &= ~__ballot(commit);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        if (in && active) { pos[f] = li; stp[f] = my_stop; }
       }
-      if (err) break;
-      for (int q = 0; q < nnew; ++q) {  // :351-352
-        int* F = fl + 5 * (nf + q);
-        F[0] = F[1] = F[2] = nw[q]; F[3] = F[4] = 0;
-      }
-      nf += nnew;
-      int keep = 0;                      // :355-356
-      for (int f = 0; f < nf; ++f) {
-        const int* F = fl + 5 * f;
-        if (F[3] != 1 || F[4] != 1) {
-          if (keep != f) { int* G = fl + 5 * keep; G[0] = F[0]; G[1] = F[1]; G[2] = F[2]; G[3] = F[3]; G[4] = F[4]; }
-          ++keep;
-        }
-      }
-      nf = keep;
-      if (nf == 0) break;
-      ++itr;
     }
-    s_err = err; s_itr = itr;
-    a.iters[b] = err ? -1 : itr;
+    if (err) break;
+    __syncthreads();
+    for (int q = lane; q < nnew; q += 64) {  // :351-352
+      const int idx = nw[q];
+      fE[nf + q] = idx; fT[nf + q] = idx; fX[nf + q] = idx; sE[nf + q] = 0; sX[nf + q] = 0;
+    }
+    nf += nnew;
+    __syncthreads();
+    int keep = 0;                            // :355-356, order preserving
+    for (int base = 0; base < nf; base += 64) {
+      const int f = base + lane;
+      const bool in = f < nf;
+      int e0 = 0, e1 = 0, e2 = 0, e3 = 1, e4 = 1;
+      if (in) { e0 = fE[f]; e1 = fT[f]; e2 = fX[f]; e3 = sE[f]; e4 = sX[f]; }
+      const bool kp = in && (e3 != 1 || e4 != 1);
+      const unsigned long long km = __ballot(kp);
+      const int off = __popcll(km & ((1ull << lane) - 1ull));
+      __syncthreads();  // every lane has read its entry before any lane overwrites an earlier slot
+      if (kp) { const int d = keep + off; fE[d] = e0; fT[d] = e1; fX[d] = e2; sE[d] = e3; sX[d] = e4; }
+      keep += __popcll(km);
+    }
+    nf = keep;
+    __syncthreads();
+    if (nf == 0) break;
+    ++itr;
   }
+  if (lane == 0) a.iters[b] = err ? -1 : itr;
   __syncthreads();
-  if (s_err) return;
+  // results back into the table; LAT_ACC follows from the final speed (every speed write of the
+  // reference is paired with calc_lat_acc of that speed, simulator.py:51-52)
+  for (int i = lane; i < N; i += 64) {
+    double* p = P + (size_t)i * 19;
+    const double v = V[i];
+    p[4] = v; p[14] = A[i];
+    p[15] = v * v / RAD[i] + GS[i];
+    p[18] = (double)OWN[i];
+  }
+  if (err) return;
   // Trajectory.fill_time (models/trajectory.py:158-180): per-segment times, written to the NEXT point
   for (int i = lane; i < N; i += 64) {
     const int nx = i + 1 == N ? 0 : i + 1;
-    const double ddx = P[(size_t)i * 19] - P[(size_t)nx * 19], ddy = P[(size_t)i * 19 + 1] - P[(size_t)nx * 19 + 1];
-    P[(size_t)nx * 19 + 16] = sqrt(ddx * ddx + ddy * ddy) / (0.5 * (P[(size_t)i * 19 + 4] + P[(size_t)nx * 19 + 4]));
+    P[(size_t)nx * 19 + 16] = SEG[nx] / (0.5 * (V[i] + V[nx]));
   }
 }
 

@@ -795,10 +795,14 @@ int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, c
   const int cap = 4 * N + 16;
   DevBuf<double> dpts, dax, dac, ddx, ddc;
   DevBuf<int> dfl, dnw, dit;
+  DevBuf<double> dcst;
   RL_HIP(dpts.alloc((size_t)B * N * RL_NCOL));
   RL_HIP(dax.alloc(acc_m + 1)); RL_HIP(dac.alloc((size_t)4 * acc_m));
   RL_HIP(ddx.alloc(dcc_m + 1)); RL_HIP(ddc.alloc((size_t)4 * dcc_m));
   RL_HIP(dfl.alloc((size_t)B * cap * 5)); RL_HIP(dnw.alloc((size_t)B * cap)); RL_HIP(dit.alloc(B));
+  RL_HIP(dcst.alloc((size_t)B * 3 * N));
+  const size_t lds = ((size_t)2 * N + 5 * (acc_m + dcc_m) + 2 + N + 1) * sizeof(double);  // speed, lon acc, tables, owner + stamp
+  if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "qss: trajectory too long for the LDS-resident profile");
   RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   RL_HIP(hipMemcpyAsync(dax.p, acc_x, dax.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   RL_HIP(hipMemcpyAsync(dac.p, acc_c, dac.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -810,8 +814,9 @@ int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, c
   a.dcc_x = ddx.p; a.dcc_c = ddc.p; a.dcc_m = dcc_m;
   a.max_lon_acc = params[0]; a.max_lon_dcc = params[1]; a.max_left_acc = params[2];
   a.max_right_acc = params[3]; a.max_speed = params[4]; a.max_jerk = params[5];
-  a.flags = dfl.p; a.fresh = dnw.p; a.cap = cap; a.iters = dit.p;
-  hipLaunchKernelGGL(rl::k_qss_sim, dim3(B), dim3(64), 0, ctx->stream, a);
+  a.flags = dfl.p; a.fresh = dnw.p; a.cst = dcst.p; a.cap = cap; a.iters = dit.p;
+  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_sim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(rl::k_qss_sim, dim3(B), dim3(64), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
   RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipMemcpyAsync(iters, dit.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
