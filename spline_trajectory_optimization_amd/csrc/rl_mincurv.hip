@@ -18,6 +18,7 @@
 #include "rl_kernels.hpp"
 #include "rl_global.hpp"
 #include "rl_global2.hpp"
+#include "rl_dtrack.hpp"
 
 namespace {
 
@@ -821,6 +822,45 @@ int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, c
   RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipMemcpyAsync(iters, dit.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+int rl_dt_eval_nodes(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
+                     const double* left, const double* right, double margin, double track_length,
+                     const double* X, const double* U, const double* T, double* eq, double* ineq,
+                     double* cost) {
+  static_assert((int)RL_DT_NPARAM == (int)rl::DT_NPARAM, "parameter tables out of step");
+  if (!ctx || !model || !s || !kappa || !left || !right || !X || !U || !T || !eq || !ineq || !cost)
+    return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0 || N < 2 || !(track_length > 0.0)) return fail(RL_ERR_ARG, "bad sizes");
+  RL_HIP(hipSetDevice(ctx->device));
+  const size_t bn = (size_t)B * N;
+  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, deq, dg, dc;
+  RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(N)); RL_HIP(dr.alloc(N));
+  RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn));
+  RL_HIP(deq.alloc(bn * rl::kDtNeq)); RL_HIP(dg.alloc(bn * rl::kDtNineq)); RL_HIP(dc.alloc(bn));
+  auto up = [&](DevBuf<double>& d, const double* h) {
+    return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  };
+  RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
+  RL_HIP(up(dX, X)); RL_HIP(up(dU, U)); RL_HIP(up(dT, T));
+  rl::DtArgs a;
+  for (int i = 0; i < rl::DT_NPARAM; ++i) a.p[i] = model[i];
+  a.B = B; a.N = N; a.s = ds.p; a.kappa = dk.p; a.left = dl.p; a.right = dr.p; a.margin = margin;
+  a.track_length = track_length; a.X = dX.p; a.U = dU.p; a.T = dT.p;
+  a.eq = deq.p; a.ineq = dg.p; a.cost_part = dc.p;
+  hipLaunchKernelGGL(rl::k_dt_eval_nodes, dim3((N + 127) / 128, B), dim3(128), 0, ctx->stream, a);
+  RL_HIP(hipGetLastError());
+  std::vector<double> part(bn);
+  RL_HIP(hipMemcpyAsync(eq, deq.p, deq.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(ineq, dg.p, dg.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(part.data(), dc.p, bn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < B; ++b) {  // the objective is a plain sum over the nodes, in node order
+    double c = 0.0;
+    for (int j = 0; j < N; ++j) c += part[(size_t)b * N + j];
+    cost[b] = c;
+  }
   return RL_OK;
 }
 

@@ -230,3 +230,25 @@ def qss_sim(points, acc_x, acc_c, dcc_x, dcc_c, params, device=None):
     check(ctx.lib.rl_qss_sim(ctx.h, pts.ctypes.data_as(_dp), B, N, axp, acp, ac.shape[1], dxp, dcp,
                              dc.shape[1], prp, it.ctypes.data_as(_ip)))
     return (pts[0] if single else pts), it
+
+
+DT_PARAMS = ["kd_f", "kb_f", "mass", "Jzz", "lf", "lr", "twf", "twr", "delta_max", "fr", "hcog", "kroll_f",
+             "cl_f", "cl_r", "rho", "A", "cd", "mu", "Bf", "Cf", "Br", "Cr", "Pmax", "Fd_max", "Fb_max",
+             "Td", "Tb", "Tdelta"]  # include/rl_mincurv.h: rl_dt_param
+
+
+def dt_eval_nodes(model, s, kappa, left, right, margin, track_length, X, U, T, device=None):
+    """Function evaluation of the min-time double-track NLP (include/rl_mincurv.h: rl_dt_eval_nodes;
+    models/double_track.py:10-204, min_time_optimizer.py:93-163) for B candidates x N nodes, physical
+    units.  `model` = the reference's model dict.  Returns (eq [B,N,8], ineq [B,N,14], cost [B])."""
+    ctx = Context.get(device)
+    mv, mp = as_d([float(model[k]) for k in DT_PARAMS])
+    X, Xp = as_d(X); U, Up = as_d(U); T, Tp = as_d(T)
+    B, N = T.shape
+    assert X.shape == (B, N, 6) and U.shape == (B, N, 4)
+    s, sp = as_d(s); kappa, kp = as_d(kappa); left, lp = as_d(left); right, rp = as_d(right)
+    assert len(s) == len(kappa) == len(left) == len(right) == N
+    eq = np.empty((B, N, 8)); g = np.empty((B, N, 14)); cost = np.empty(B)
+    check(ctx.lib.rl_dt_eval_nodes(ctx.h, mp, B, N, sp, kp, lp, rp, float(margin), float(track_length), Xp, Up, Tp,
+                                   eq.ctypes.data_as(_dp), g.ctypes.data_as(_dp), cost.ctypes.data_as(_dp)))
+    return eq, g, cost

@@ -1,0 +1,114 @@
+"""First slice of BASELINE config 5: function evaluation of the min-time double-track
+NLP (include/rl_mincurv.h: rl_dt_eval_nodes).
+
+PARITY UNPINNED against the reference: models/double_track.py and min_time_optimizer.py build CasADi
+expressions, CasADi is not importable here and the reference ships no numbers for them.  What is
+checked:
+  * CPU: the numpy checker (oracle/double_track.py) against the physics it states -- straight-line
+    equilibrium, left/right mirror symmetry, Hermite-Simpson collocation order (the defect of an
+    accurately integrated trajectory shrinks like h^5), the alignment helpers across the start line;
+  * GPU: the HIP kernel against that checker on random states to 1e-10 relative."""
+import numpy as np
+import pytest
+
+from oracle import double_track as dt
+
+MODEL = {  # the numbers of the reference's own model self-test (models/double_track.py:207-251)
+    "kd_f": 0.0, "kb_f": 0.7, "mass": 1200.0, "Jzz": 1260, "lf": 1.5, "lr": 1.4, "twf": 1.6, "twr": 1.5,
+    "delta_max": 0.4, "fr": 0.01, "hcog": 0.4, "kroll_f": 0.5, "cl_f": 2.4, "cl_r": 3.0, "rho": 1.2041,
+    "A": 1.0, "cd": 1.4, "mu": 1.5, "Bf": 9.62, "Cf": 2.59, "Br": 8.62, "Cr": 2.65, "Pmax": 270000.0,
+    "Fd_max": 7100.0, "Fb_max": -20000.0, "Td": 1.0, "Tb": 1.0, "Tdelta": 1.0,
+}
+
+
+def random_problem(B, N, seed=0):
+    rng = np.random.default_rng(seed)
+    L = 3.0 * N
+    s = np.arange(N) * 3.0
+    kappa = 0.01 * np.sin(2 * np.pi * s / L * 3)
+    left = 5.0 + rng.uniform(0, 1, N); right = -5.0 - rng.uniform(0, 1, N)
+    X = np.empty((B, N, 6))
+    X[..., 0] = s[None] + rng.normal(0, 0.05, (B, N))
+    X[..., 1] = rng.uniform(-3, 3, (B, N)); X[..., 2] = rng.normal(0, 0.05, (B, N))
+    X[..., 3] = rng.normal(0, 0.1, (B, N)); X[..., 4] = rng.normal(0, 0.03, (B, N))
+    X[..., 5] = rng.uniform(15, 80, (B, N))
+    U = np.empty((B, N, 4))
+    U[..., 0] = rng.uniform(-15000, 6000, (B, N)); U[..., 1] = rng.normal(0, 1, (B, N))
+    U[..., 2] = rng.normal(0, 0.05, (B, N)); U[..., 3] = rng.normal(0, 300, (B, N))
+    T = 3.0 / X[..., 5] * rng.uniform(0.9, 1.1, (B, N))
+    return s, kappa, left, right, L, X, U, T
+
+
+def test_straight_line_equilibrium_and_mirror_symmetry():
+    # coasting straight: no yaw / slip dynamics, all four tyres share the lateral force 0
+    x = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 50.0]); u = np.array([0.0, 0.0, 0.0, 0.0])
+    f, (Fx, Fy, Fz) = dt.dynamics(MODEL, x, u, 0.0)
+    assert f[0] == pytest.approx(50.0) and abs(f[1]) < 1e-12 and abs(f[2]) < 1e-12 and abs(f[3]) < 1e-9 and abs(f[4]) < 1e-12
+    assert f[5] < 0.0                                       # drag + rolling resistance decelerate
+    assert np.all(np.abs(Fy) < 1e-9) and Fz[0] == Fz[1] and Fz[2] == Fz[3]
+    # mirror: (n, xi, omega, beta, delta, gamma, kappa) -> minus; s_dot, v_dot even, the others odd
+    xl = np.array([3.0, 1.2, 0.05, 0.2, 0.03, 45.0]); ul = np.array([3000.0, 0.0, 0.06, 250.0])
+    xr = xl * np.array([1, -1, -1, -1, -1, 1]); ur = ul * np.array([1, 1, -1, -1])
+    fl, (Fxl, Fyl, Fzl) = dt.dynamics(MODEL, xl, ul, 0.008)
+    fr_, (Fxr, Fyr, Fzr) = dt.dynamics(MODEL, xr, ur, -0.008)
+    np.testing.assert_allclose(fr_, fl * np.array([1, -1, -1, -1, -1, 1]), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Fzr[[1, 0, 3, 2]], Fzl, rtol=1e-13)     # left and right wheels swap
+    np.testing.assert_allclose(Fyr[[1, 0, 3, 2]], -Fyl, rtol=1e-12, atol=1e-9)
+
+
+def test_hermite_simpson_defect_has_the_collocation_order():
+    """Integrate the model accurately over one interval (RK4, 2000 substeps, controls held) and feed
+    (x0, x1) to the node evaluation: the Hermite-Simpson defect must fall like h^5."""
+    x0 = np.array([10.0, 0.5, 0.02, 0.05, 0.01, 40.0]); u = np.array([2500.0, 0.0, 0.04, 120.0]); k = 0.004
+    f = lambda x: dt.dynamics(MODEL, x, u, k)[0]
+    errs = []
+    for h in (0.04, 0.02, 0.01):  # the lateral dynamics have a time constant of ~0.1 s at this speed
+        x, n = x0.copy(), 2000
+        for _ in range(n):
+            dtau = h / n
+            k1 = f(x); k2 = f(x + 0.5 * dtau * k1); k3 = f(x + 0.5 * dtau * k2); k4 = f(x + dtau * k3)
+            x = x + dtau / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        N = 4
+        X = np.tile(x0, (1, N, 1)); X[0, 1] = x; U = np.tile(u, (1, N, 1)); T = np.full((1, N), h)
+        s = X[0, :, 0].copy()
+        eq, g, cost = dt.eval_nodes(MODEL, s, np.full(N, k), np.full(N, 6.0), np.full(N, -6.0), 1.0, 1e4, X, U, T)
+        errs.append(np.abs(eq[0, 0, :6]).max())
+    assert errs[0] < 1e-3
+    assert errs[0] / errs[1] > 20 and errs[1] / errs[2] > 20            # ~2^5 per halving
+
+
+def test_alignment_across_the_start_line():
+    """Node N-1 -> node 0: the abscissa wraps by the track length and the yaw by 2 pi (utils.py:10-18)."""
+    N, L = 8, 80.0
+    s = np.arange(N) * 10.0
+    X = np.zeros((1, N, 6)); X[0, :, 0] = s; X[0, :, 5] = 40.0; X[0, :, 2] = 0.1
+    X[0, 0, 2] = 0.1 - 2 * np.pi                                          # same heading, other branch
+    U = np.zeros((1, N, 4)); T = np.full((1, N), 0.25)
+    eq, g, cost = dt.eval_nodes(MODEL, s, np.zeros(N), np.full(N, 6.0), np.full(N, -6.0), 1.0, L, X, U, T)
+    assert np.abs(eq[0, N - 1, 2]) < 1e-3                                 # no 2 pi jump in the yaw defect
+    assert np.abs(eq[0, N - 1, 0]) < 0.1 and np.abs(eq[0, 3, 0]) < 0.1   # nor a track length in s
+    assert np.allclose(eq[0, :, 7], 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(1, 16), (7, 501), (64, 1930)])
+def test_dt_eval_nodes_vs_numpy(B, N):
+    from spline_trajectory_optimization_amd import ops
+    s, kappa, left, right, L, X, U, T = random_problem(B, N, seed=B)
+    eq, g, cost = ops.dt_eval_nodes(MODEL, s, kappa, left, right, 1.2, L, X, U, T)
+    oeq, og, ocost = dt.eval_nodes(MODEL, s, kappa, left, right, 1.2, L, X, U, T)
+    scale = lambda r: np.maximum(1.0, np.abs(r))
+    assert (np.abs(eq - oeq) / scale(oeq)).max() <= 1e-10
+    assert (np.abs(g - og) / scale(og)).max() <= 1e-10
+    np.testing.assert_allclose(cost, ocost, rtol=1e-12)
+    assert np.isfinite(eq).all() and np.isfinite(g).all()
+
+
+@pytest.mark.gpu
+def test_dt_eval_argument_errors():
+    from spline_trajectory_optimization_amd import _lib, ops
+    s, kappa, left, right, L, X, U, T = random_problem(2, 8)
+    with pytest.raises(AssertionError):
+        ops.dt_eval_nodes(MODEL, s[:-1], kappa, left, right, 1.2, L, X, U, T)
+    with pytest.raises(_lib.RlError):
+        ops.dt_eval_nodes(MODEL, s, kappa, left, right, 1.2, -1.0, X, U, T)
