@@ -524,7 +524,6 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         }
         G2_LAP(0);
         // [I2]
-        const double mu_sum = red_sum(0);
         g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
         __syncthreads();
         // [I3]
