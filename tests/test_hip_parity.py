@@ -625,3 +625,24 @@ def test_joint_window_qps_replayed(rl, fits, rings, monkeypatch):
                 n_inf += 1
         print(f"joint replay N={N}: {n_feas} windows accepted and re-solved identically, {n_inf} rejected consistently")
         assert n_feas == ns.sum() and n_feas > 0
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (one process per rank, sharded batch, asynchronous double-buffered gather
+    to rank 0) with both ranks on this box's single GPU and the gloo backend (--share-gpu test hook:
+    the numbers mean nothing, the plumbing is what runs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--share-gpu", "--batch", "64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, out.stdout[-2000:]
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
+    assert res["value"] > 0 and res["roofline"]["kernel"] == "k_sweep" and "cpu_baseline" not in res
