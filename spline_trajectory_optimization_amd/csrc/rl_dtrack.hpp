@@ -43,119 +43,219 @@ struct DtArgs {
   double* cost_part;     // [B,N]    per-node objective terms (summed on the host side of the ABI)
 };
 
-struct DtTyres { double fx[4], fy[4], fz[4]; };  // fl, fr, rl, rr
+// ---- scalar types: double for the values, Dual<ND> (value + ND directional derivatives, forward
+// mode) for the Jacobian.  The model code below is written once against these overloads.
+template <int ND>
+struct Dual {
+  double v;
+  double d[ND];
+};
+#define RL_DUAL_FOR for (int i_ = 0; i_ < ND; ++i_)
+template <int ND> __device__ __forceinline__ Dual<ND> mk(double v) { Dual<ND> r; r.v = v; RL_DUAL_FOR r.d[i_] = 0.0; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(Dual<ND> a, Dual<ND> b) { a.v += b.v; RL_DUAL_FOR a.d[i_] += b.d[i_]; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(Dual<ND> a, Dual<ND> b) { a.v -= b.v; RL_DUAL_FOR a.d[i_] -= b.d[i_]; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(Dual<ND> a) { a.v = -a.v; RL_DUAL_FOR a.d[i_] = -a.d[i_]; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(Dual<ND> a, Dual<ND> b) { Dual<ND> r; r.v = a.v * b.v; RL_DUAL_FOR r.d[i_] = a.d[i_] * b.v + a.v * b.d[i_]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(Dual<ND> a, Dual<ND> b) { Dual<ND> r; const double ib = 1.0 / b.v; r.v = a.v * ib; RL_DUAL_FOR r.d[i_] = (a.d[i_] - r.v * b.d[i_]) * ib; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(Dual<ND> a, double b) { a.v += b; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(double b, Dual<ND> a) { a.v += b; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(Dual<ND> a, double b) { a.v -= b; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(double b, Dual<ND> a) { a.v = b - a.v; RL_DUAL_FOR a.d[i_] = -a.d[i_]; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(Dual<ND> a, double b) { a.v *= b; RL_DUAL_FOR a.d[i_] *= b; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(double b, Dual<ND> a) { a.v *= b; RL_DUAL_FOR a.d[i_] *= b; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(Dual<ND> a, double b) { const double ib = 1.0 / b; a.v *= ib; RL_DUAL_FOR a.d[i_] *= ib; return a; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(double b, Dual<ND> a) { Dual<ND> r; r.v = b / a.v; const double f = -r.v / a.v; RL_DUAL_FOR r.d[i_] = f * a.d[i_]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> chain(Dual<ND> a, double v, double dv) { a.v = v; RL_DUAL_FOR a.d[i_] *= dv; return a; }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ double m_cos(double x) { return cos(x); }
+__device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ double m_atan(double x) { return atan(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ double m_fmod(double x, double m) { return fmod(x, m); }
+__device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double m_val(double x) { return x; }
+template <int ND> __device__ __forceinline__ Dual<ND> m_sin(Dual<ND> x) { return chain(x, sin(x.v), cos(x.v)); }
+template <int ND> __device__ __forceinline__ Dual<ND> m_cos(Dual<ND> x) { return chain(x, cos(x.v), -sin(x.v)); }
+template <int ND> __device__ __forceinline__ Dual<ND> m_tanh(Dual<ND> x) { const double t = tanh(x.v); return chain(x, t, 1.0 - t * t); }
+template <int ND> __device__ __forceinline__ Dual<ND> m_atan(Dual<ND> x) { return chain(x, atan(x.v), 1.0 / (1.0 + x.v * x.v)); }
+template <int ND> __device__ __forceinline__ Dual<ND> m_abs(Dual<ND> x) { return chain(x, fabs(x.v), x.v < 0.0 ? -1.0 : 1.0); }
+template <int ND> __device__ __forceinline__ Dual<ND> m_atan2(Dual<ND> y, Dual<ND> x) {
+  Dual<ND> r; r.v = atan2(y.v, x.v); const double q = 1.0 / (x.v * x.v + y.v * y.v);
+  RL_DUAL_FOR r.d[i_] = (x.v * y.d[i_] - y.v * x.d[i_]) * q; return r;
+}
+template <int ND> __device__ __forceinline__ Dual<ND> m_fmod(Dual<ND> x, double m) { x.v = fmod(x.v, m); return x; }
+template <int ND> __device__ __forceinline__ Dual<ND> m_max(Dual<ND> a, Dual<ND> b) { return a.v >= b.v ? a : b; }
+template <int ND> __device__ __forceinline__ double m_val(Dual<ND> x) { return x.v; }
+#undef RL_DUAL_FOR
 
-__device__ __forceinline__ void dt_dynamics(const double* p, const double x[6], const double u[4], double k,
-                                            double f[6], DtTyres& ty) {
-  const double n = x[1], phi = x[2], omega = x[3], beta = x[4], v = x[5];
-  const double fd = u[0] * (tanh(u[0]) * 0.5 + 0.5);   // :17
-  const double fb = u[0] * (tanh(-u[0]) * 0.5 + 0.5);  // :18
-  const double delta = u[2], gam = u[3];
+template <typename S>
+struct DtTyres { S fx[4], fy[4], fz[4]; };  // fl, fr, rl, rr
+
+template <typename S>
+__device__ __forceinline__ void dt_dynamics(const double* p, const S (&x)[6], const S (&u)[4], double k,
+                                            S (&f)[6], DtTyres<S>& ty) {
+  const S n = x[1], phi = x[2], omega = x[3], beta = x[4], v = x[5];
+  const S fd = u[0] * (m_tanh(u[0]) * 0.5 + 0.5);    // :17
+  const S fb = u[0] * (m_tanh(-u[0]) * 0.5 + 0.5);   // :18
+  const S delta = u[2], gam = u[3];
   const double m = p[DT_MASS], lf = p[DT_LF], lr = p[DT_LR], l = lf + lr;
   const double roll = 0.5 * p[DT_FR] * m * kDtGravity;
-  const double fxf = 0.5 * p[DT_KD_F] * fd + 0.5 * p[DT_KB_F] * fb - roll * lr / l;                  // :58
-  const double fxr = 0.5 * (1 - p[DT_KD_F]) * fd + 0.5 * (1 - p[DT_KB_F]) * fb - roll * lf / l;      // :61
-  const double v2 = v * v;
-  const double ax = (fd + fb - 0.5 * p[DT_CD] * p[DT_A] * v2 - p[DT_FR] * m * kDtGravity) / m;       // :67
-  const double stat = 0.5 * m * kDtGravity * lr / l, pitch = 0.5 * p[DT_HCOG] / l * m * ax;
-  const double fzf = stat - pitch + 0.25 * p[DT_CL_F] * p[DT_RHO] * p[DT_A] * v2;                    // :70-72
-  const double fzr = stat + pitch + 0.25 * p[DT_CL_R] * p[DT_RHO] * p[DT_A] * v2;                    // :75-77 (lr, as written)
+  const S fxf = 0.5 * p[DT_KD_F] * fd + 0.5 * p[DT_KB_F] * fb - roll * lr / l;                   // :58
+  const S fxr = 0.5 * (1 - p[DT_KD_F]) * fd + 0.5 * (1 - p[DT_KB_F]) * fb - roll * lf / l;       // :61
+  const S v2 = v * v;
+  const S ax = (fd + fb - 0.5 * p[DT_CD] * p[DT_A] * v2 - p[DT_FR] * m * kDtGravity) / m;        // :67
+  const double stat = 0.5 * m * kDtGravity * lr / l;
+  const S pitch = 0.5 * p[DT_HCOG] / l * m * ax;
+  const S fzf = stat - pitch + 0.25 * p[DT_CL_F] * p[DT_RHO] * p[DT_A] * v2;                     // :70-72
+  const S fzr = stat + pitch + 0.25 * p[DT_CL_R] * p[DT_RHO] * p[DT_A] * v2;                     // :75-77 (lr, as written)
   ty.fz[0] = fzf - p[DT_KROLL_F] * gam; ty.fz[1] = fzf + p[DT_KROLL_F] * gam;
   ty.fz[2] = fzr - (1 - p[DT_KROLL_F]) * gam; ty.fz[3] = fzr + (1 - p[DT_KROLL_F]) * gam;
-  double sb, cb;
-  sincos(beta, &sb, &cb);
-  const double vs = v * sb, vc = v * cb;
-  const double afl = delta - atan((lf * omega + vs) / (vc - 0.5 * p[DT_TWF] * omega));               // :83-90
-  const double afr = delta - atan((lf * omega + vs) / (vc + 0.5 * p[DT_TWF] * omega));
-  const double arl = atan((lr * omega - vs) / (vc - 0.5 * p[DT_TWR] * omega));
-  const double arr = atan((lr * omega - vs) / (vc + 0.5 * p[DT_TWR] * omega));
+  const S sb = m_sin(beta), cb = m_cos(beta);
+  const S vs = v * sb, vc = v * cb;
+  const S afl = delta - m_atan((lf * omega + vs) / (vc - 0.5 * p[DT_TWF] * omega));              // :83-90
+  const S afr = delta - m_atan((lf * omega + vs) / (vc + 0.5 * p[DT_TWF] * omega));
+  const S arl = m_atan((lr * omega - vs) / (vc - 0.5 * p[DT_TWR] * omega));
+  const S arr = m_atan((lr * omega - vs) / (vc + 0.5 * p[DT_TWR] * omega));
   const double mu = p[DT_MU];
-  ty.fy[0] = mu * ty.fz[0] * sin(p[DT_CF] * atan(p[DT_BF] * afl));                                   // :104-107
-  ty.fy[1] = mu * ty.fz[1] * sin(p[DT_CF] * atan(p[DT_BF] * afr));
-  ty.fy[2] = mu * ty.fz[2] * sin(p[DT_CR] * atan(p[DT_BR] * arl));
-  ty.fy[3] = mu * ty.fz[3] * sin(p[DT_CR] * atan(p[DT_BR] * arr));
+  ty.fy[0] = mu * ty.fz[0] * m_sin(p[DT_CF] * m_atan(p[DT_BF] * afl));                           // :104-107
+  ty.fy[1] = mu * ty.fz[1] * m_sin(p[DT_CF] * m_atan(p[DT_BF] * afr));
+  ty.fy[2] = mu * ty.fz[2] * m_sin(p[DT_CR] * m_atan(p[DT_BR] * arl));
+  ty.fy[3] = mu * ty.fz[3] * m_sin(p[DT_CR] * m_atan(p[DT_BR] * arr));
   ty.fx[0] = fxf; ty.fx[1] = fxf; ty.fx[2] = fxr; ty.fx[3] = fxr;
-  double sd, cd_, sdb, cdb;
-  sincos(delta, &sd, &cd_);
-  sincos(delta - beta, &sdb, &cdb);
-  const double fxF = ty.fx[0] + ty.fx[1], fxR = ty.fx[2] + ty.fx[3];
-  const double fyF = ty.fy[0] + ty.fy[1], fyR = ty.fy[2] + ty.fy[3];
-  const double drag = 0.5 * p[DT_CD] * p[DT_RHO] * p[DT_A] * v2;
-  const double v_dot = (fxR * cb + fxF * cdb + fyR * sb - fyF * sdb - drag * cb) / m;                // :110-113
-  const double beta_dot = -omega + (-fxR * sb + fxF * sdb + fyR * cb + fyF * cdb + drag * sb) / (m * v);  // :114-117
-  const double omega_dot = ((ty.fx[3] - ty.fx[2]) * p[DT_TWR] / 2 - fyR * lr +
-                            ((ty.fx[1] - ty.fx[0]) * cd_ + (ty.fy[0] - ty.fy[1]) * sd) * p[DT_TWF] / 2 +
-                            (fyF * cd_ + fxF * sd) * lf) / p[DT_JZZ];                                // :118-121
-  double s_dot = v * cos(phi + beta);
-  const double n_dot = v * sin(phi + beta);
-  s_dot /= (1 - n * k);                                                                               // :128
-  const double phi_dot = omega - k * s_dot;                                                           // :129
+  const S sd = m_sin(delta), cd_ = m_cos(delta), sdb = m_sin(delta - beta), cdb = m_cos(delta - beta);
+  const S fxF = ty.fx[0] + ty.fx[1], fxR = ty.fx[2] + ty.fx[3];
+  const S fyF = ty.fy[0] + ty.fy[1], fyR = ty.fy[2] + ty.fy[3];
+  const S drag = 0.5 * p[DT_CD] * p[DT_RHO] * p[DT_A] * v2;
+  const S v_dot = (fxR * cb + fxF * cdb + fyR * sb - fyF * sdb - drag * cb) / m;                 // :110-113
+  const S beta_dot = -omega + (-fxR * sb + fxF * sdb + fyR * cb + fyF * cdb + drag * sb) / (m * v);  // :114-117
+  const S omega_dot = ((ty.fx[3] - ty.fx[2]) * (p[DT_TWR] / 2) - fyR * lr +
+                       ((ty.fx[1] - ty.fx[0]) * cd_ + (ty.fy[0] - ty.fy[1]) * sd) * (p[DT_TWF] / 2) +
+                       (fyF * cd_ + fxF * sd) * lf) / p[DT_JZZ];                                  // :118-121
+  const S s_dot = v * m_cos(phi + beta) / (1 - n * k);                                           // :122, :128
+  const S n_dot = v * m_sin(phi + beta);
+  const S phi_dot = omega - k * s_dot;                                                           // :129
   f[0] = s_dot; f[1] = n_dot; f[2] = phi_dot; f[3] = omega_dot; f[4] = beta_dot; f[5] = v_dot;
 }
 
 __device__ __forceinline__ double dt_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
+
+// everything a node pair contributes: 8 equality residuals, 14 inequality values, the objective terms
+template <typename S>
+__device__ __forceinline__ void dt_pair(const DtArgs& a, int j, const S (&x)[6], const S (&u)[4], S t,
+                                        S (&xn)[6], const S (&un)[4], S (&eq)[kDtNeq], S (&g)[kDtNineq], S& cost) {
+  const double* p = a.p;
+  const double k = a.kappa[j];
+  // next state brought next to this one (utils.py:10-18)
+  {
+    const S d = xn[2] - x[2];
+    xn[2] = m_atan2(m_sin(d), m_cos(d)) + x[2];
+    const S ds = x[0] - xn[0], kk = m_abs(ds) + a.track_length / 2.0;
+    xn[0] = xn[0] + (kk - m_fmod(kk, a.track_length)) * dt_sign(m_val(ds));
+  }
+  S f1[6], f2[6], fm[6], xm[6];
+  DtTyres<S> ty, ty2;
+  dt_dynamics(p, x, u, k, f1, ty);
+  dt_dynamics(p, xn, u, k, f2, ty2);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) xm[c] = 0.5 * (x[c] + xn[c]) + (t / 8.0) * (f1[c] - f2[c]);  // :170
+  dt_dynamics(p, xm, u, k, fm, ty2);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) eq[c] = x[c] + (t / 6.0) * (f1[c] + 4.0 * fm[c] + f2[c]) - xn[c];  // :172
+  const S delta = u[2], gam = u[3], v = x[5];
+  const S sd = m_sin(delta), cd_ = m_cos(delta);
+  eq[6] = gam - p[DT_HCOG] / (0.5 * (p[DT_TWF] + p[DT_TWR])) *
+                    (ty.fy[2] + ty.fy[3] + (ty.fx[0] + ty.fx[1]) * sd + (ty.fy[0] + ty.fy[1]) * cd_);  // :183-184
+  eq[7] = x[0] - a.s[j];                                                                              // :130
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {                                                                       // :178-180
+    const S qx = ty.fx[w] / (p[DT_MU] * ty.fz[w]), qy = ty.fy[w] / (p[DT_MU] * ty.fz[w]);
+    g[w] = qx * qx + qy * qy - 1.0;
+  }
+  const S fd = u[0] * (m_tanh(u[0]) * 0.5 + 0.5);
+  g[4] = v * fd - p[DT_PMAX];                                                                         // :187
+  g[5] = 1.0 - v;                                                                                     // :188
+  g[6] = p[DT_FB_MAX] - u[0]; g[7] = u[0] - p[DT_FD_MAX];                                             // :193
+  g[8] = -p[DT_DELTA_MAX] - delta; g[9] = delta - p[DT_DELTA_MAX];                                    // :194
+  const S ru = (un[0] - u[0]) / t, rd = (un[2] - delta) / t;                                          // :199-201
+  // the two rate constraints are two-sided; the more violated side of each is reported
+  g[10] = m_max(p[DT_FB_MAX] / p[DT_TB] - ru, ru - p[DT_FD_MAX] / p[DT_TD]);
+  g[11] = m_max(-p[DT_DELTA_MAX] / p[DT_TDELTA] - rd, rd - p[DT_DELTA_MAX] / p[DT_TDELTA]);
+  g[12] = (a.right[j] + a.margin) - x[1]; g[13] = x[1] - (a.left[j] - a.margin);                      // :131-136
+  // objective (min_time_optimizer.py:119-123) in the reference's scaled controls
+  const double su[4] = {p[DT_FD_MAX], fabs(p[DT_FB_MAX]), p[DT_DELTA_MAX], p[DT_MASS] * 50.0};
+  cost = t;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const S a0 = u[q] / su[q], a1 = un[q] / su[q];
+    cost = cost + 1e-4 * a1 * a1 + 1e-1 * (a1 - a0) * (a1 - a0);
+  }
+}
 
 __global__ void __launch_bounds__(128) k_dt_eval_nodes(DtArgs a) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;  // left node of the pair (j, j+1)
   const int b = blockIdx.y;
   if (j >= a.N) return;
   const int jn = j + 1 == a.N ? 0 : j + 1;
-  const double* p = a.p;
   const size_t o = (size_t)b * a.N + j, on = (size_t)b * a.N + jn;
   double x[6], xn[6], u[4], un[4];
 #pragma unroll
   for (int c = 0; c < 6; ++c) { x[c] = a.X[o * 6 + c]; xn[c] = a.X[on * 6 + c]; }
 #pragma unroll
   for (int c = 0; c < 4; ++c) { u[c] = a.U[o * 4 + c]; un[c] = a.U[on * 4 + c]; }
-  const double t = a.T[o], k = a.kappa[j];
-  // next state brought next to this one (utils.py:10-18)
-  {
-    const double d = xn[2] - x[2];
-    xn[2] = atan2(sin(d), cos(d)) + x[2];
-    const double ds = x[0] - xn[0], kk = fabs(ds) + a.track_length / 2.0;
-    xn[0] = xn[0] + (kk - fmod(kk, a.track_length)) * dt_sign(ds);
+  double eq[kDtNeq], g[kDtNineq], cost;
+  dt_pair<double>(a, j, x, u, a.T[o], xn, un, eq, g, cost);
+#pragma unroll
+  for (int c = 0; c < kDtNeq; ++c) a.eq[o * kDtNeq + c] = eq[c];
+#pragma unroll
+  for (int c = 0; c < kDtNineq; ++c) a.ineq[o * kDtNineq + c] = g[c];
+  a.cost_part[o] = cost;
+}
+
+// Jacobian of the node-pair functions with respect to the 21 local variables
+//   [ x(6) | u(4) | t | x_next(6) | u_next(4) ]
+// by forward-mode differentiation, kDtJacND directions per thread (blockIdx.z selects the slice):
+// jac_eq [B,N,8,21], jac_ineq [B,N,14,21], grad_cost [B,N,21] (the node pair's objective terms).
+constexpr int kDtNvar = 21, kDtJacND = 3;
+struct DtJacArgs {
+  DtArgs f;
+  double* jac_eq;
+  double* jac_ineq;
+  double* grad_cost;
+};
+
+__global__ void __launch_bounds__(128) k_dt_eval_jac(DtJacArgs ja) {
+  const DtArgs& a = ja.f;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, v0 = blockIdx.z * kDtJacND;
+  if (j >= a.N) return;
+  const int jn = j + 1 == a.N ? 0 : j + 1;
+  const size_t o = (size_t)b * a.N + j, on = (size_t)b * a.N + jn;
+  using D = Dual<kDtJacND>;
+  D x[6], xn[6], u[4], un[4], t;
+  auto seed = [&](D& q, double val, int var) {
+    q.v = val;
+#pragma unroll
+    for (int i = 0; i < kDtJacND; ++i) q.d[i] = (var == v0 + i) ? 1.0 : 0.0;
+  };
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { seed(x[c], a.X[o * 6 + c], c); seed(xn[c], a.X[on * 6 + c], 11 + c); }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { seed(u[c], a.U[o * 4 + c], 6 + c); seed(un[c], a.U[on * 4 + c], 17 + c); }
+  seed(t, a.T[o], 10);
+  D eq[kDtNeq], g[kDtNineq], cost;
+  dt_pair<D>(a, j, x, u, t, xn, un, eq, g, cost);
+#pragma unroll
+  for (int i = 0; i < kDtJacND; ++i) {
+    const int var = v0 + i;
+    if (var < kDtNvar) {
+#pragma unroll
+      for (int c = 0; c < kDtNeq; ++c) ja.jac_eq[(o * kDtNeq + c) * kDtNvar + var] = eq[c].d[i];
+#pragma unroll
+      for (int c = 0; c < kDtNineq; ++c) ja.jac_ineq[(o * kDtNineq + c) * kDtNvar + var] = g[c].d[i];
+      ja.grad_cost[o * kDtNvar + var] = cost.d[i];
+    }
   }
-  double f1[6], f2[6], fm[6], xm[6];
-  DtTyres ty, ty2;
-  dt_dynamics(p, x, u, k, f1, ty);
-  dt_dynamics(p, xn, u, k, f2, ty2);
-#pragma unroll
-  for (int c = 0; c < 6; ++c) xm[c] = 0.5 * (x[c] + xn[c]) + (t / 8.0) * (f1[c] - f2[c]);  // :170
-  dt_dynamics(p, xm, u, k, fm, ty2);
-  double* eq = a.eq + o * kDtNeq;
-#pragma unroll
-  for (int c = 0; c < 6; ++c) eq[c] = x[c] + (t / 6.0) * (f1[c] + 4 * fm[c] + f2[c]) - xn[c];  // :172
-  const double delta = u[2], gam = u[3], v = x[5];
-  double sd, cd_;
-  sincos(delta, &sd, &cd_);
-  eq[6] = gam - p[DT_HCOG] / (0.5 * (p[DT_TWF] + p[DT_TWR])) *
-                    (ty.fy[2] + ty.fy[3] + (ty.fx[0] + ty.fx[1]) * sd + (ty.fy[0] + ty.fy[1]) * cd_);  // :183-184
-  eq[7] = x[0] - a.s[j];                                                                              // :130
-  double* g = a.ineq + o * kDtNineq;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {                                                                       // :178-180
-    const double qx = ty.fx[w] / (p[DT_MU] * ty.fz[w]), qy = ty.fy[w] / (p[DT_MU] * ty.fz[w]);
-    g[w] = qx * qx + qy * qy - 1.0;
-  }
-  const double fd = u[0] * (tanh(u[0]) * 0.5 + 0.5);
-  g[4] = v * fd - p[DT_PMAX];                                                                         // :187
-  g[5] = 1.0 - v;                                                                                     // :188
-  g[6] = p[DT_FB_MAX] - u[0]; g[7] = u[0] - p[DT_FD_MAX];                                             // :193
-  g[8] = -p[DT_DELTA_MAX] - delta; g[9] = delta - p[DT_DELTA_MAX];                                    // :194
-  const double ru = (un[0] - u[0]) / t, rd = (un[2] - delta) / t;                                     // :199-201
-  // the two rate constraints are two-sided; the more violated side of each is reported
-  g[10] = fmax(p[DT_FB_MAX] / p[DT_TB] - ru, ru - p[DT_FD_MAX] / p[DT_TD]);
-  g[11] = fmax(-p[DT_DELTA_MAX] / p[DT_TDELTA] - rd, rd - p[DT_DELTA_MAX] / p[DT_TDELTA]);
-  g[12] = (a.right[j] + a.margin) - x[1]; g[13] = x[1] - (a.left[j] - a.margin);                      // :131-136
-  // objective (min_time_optimizer.py:119-123) in the reference's scaled controls
-  const double su[4] = {p[DT_FD_MAX], fabs(p[DT_FB_MAX]), p[DT_DELTA_MAX], p[DT_MASS] * 50.0};
-  double c = t;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const double a0 = u[q] / su[q], a1 = un[q] / su[q];
-    c += 1e-4 * a1 * a1 + 1e-1 * (a1 - a0) * (a1 - a0);
-  }
-  a.cost_part[o] = c;
 }
 
 }  // namespace rl

@@ -864,6 +864,42 @@ int rl_dt_eval_nodes(rl_ctx* ctx, const double* model, int B, int N, const doubl
   return RL_OK;
 }
 
+int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
+                   const double* left, const double* right, double margin, double track_length,
+                   const double* X, const double* U, const double* T, double* jac_eq, double* jac_ineq,
+                   double* grad_cost) {
+  if (!ctx || !model || !s || !kappa || !left || !right || !X || !U || !T || !jac_eq || !jac_ineq || !grad_cost)
+    return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0 || N < 2 || !(track_length > 0.0)) return fail(RL_ERR_ARG, "bad sizes");
+  RL_HIP(hipSetDevice(ctx->device));
+  const size_t bn = (size_t)B * N;
+  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, dje, dji, dgc;
+  RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(N)); RL_HIP(dr.alloc(N));
+  RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn));
+  RL_HIP(dje.alloc(bn * rl::kDtNeq * rl::kDtNvar)); RL_HIP(dji.alloc(bn * rl::kDtNineq * rl::kDtNvar));
+  RL_HIP(dgc.alloc(bn * rl::kDtNvar));
+  auto up = [&](DevBuf<double>& d, const double* h) {
+    return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  };
+  RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
+  RL_HIP(up(dX, X)); RL_HIP(up(dU, U)); RL_HIP(up(dT, T));
+  rl::DtJacArgs ja;
+  rl::DtArgs& a = ja.f;
+  for (int i = 0; i < rl::DT_NPARAM; ++i) a.p[i] = model[i];
+  a.B = B; a.N = N; a.s = ds.p; a.kappa = dk.p; a.left = dl.p; a.right = dr.p; a.margin = margin;
+  a.track_length = track_length; a.X = dX.p; a.U = dU.p; a.T = dT.p;
+  a.eq = nullptr; a.ineq = nullptr; a.cost_part = nullptr;
+  ja.jac_eq = dje.p; ja.jac_ineq = dji.p; ja.grad_cost = dgc.p;
+  const int slices = (rl::kDtNvar + rl::kDtJacND - 1) / rl::kDtJacND;
+  hipLaunchKernelGGL(rl::k_dt_eval_jac, dim3((N + 127) / 128, B, slices), dim3(128), 0, ctx->stream, ja);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(jac_eq, dje.p, dje.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(jac_ineq, dji.p, dji.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(grad_cost, dgc.p, dgc.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
 }  // extern "C"
 
 static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter, double* cx, double* cy,

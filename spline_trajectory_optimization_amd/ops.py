@@ -252,3 +252,20 @@ def dt_eval_nodes(model, s, kappa, left, right, margin, track_length, X, U, T, d
     check(ctx.lib.rl_dt_eval_nodes(ctx.h, mp, B, N, sp, kp, lp, rp, float(margin), float(track_length), Xp, Up, Tp,
                                    eq.ctypes.data_as(_dp), g.ctypes.data_as(_dp), cost.ctypes.data_as(_dp)))
     return eq, g, cost
+
+
+def dt_eval_jac(model, s, kappa, left, right, margin, track_length, X, U, T, device=None):
+    """First derivatives of dt_eval_nodes' functions (include/rl_mincurv.h: rl_dt_eval_jac): per node pair
+    the blocks with respect to [x_j (6), u_j (4), t_j, x_{j+1} (6), u_{j+1} (4)].
+    Returns (jac_eq [B,N,8,21], jac_ineq [B,N,14,21], grad_cost [B,N,21])."""
+    ctx = Context.get(device)
+    mv, mp = as_d([float(model[k]) for k in DT_PARAMS])
+    X, Xp = as_d(X); U, Up = as_d(U); T, Tp = as_d(T)
+    B, N = T.shape
+    assert X.shape == (B, N, 6) and U.shape == (B, N, 4)
+    s, sp = as_d(s); kappa, kp = as_d(kappa); left, lp = as_d(left); right, rp = as_d(right)
+    assert len(s) == len(kappa) == len(left) == len(right) == N
+    je = np.empty((B, N, 8, 21)); ji = np.empty((B, N, 14, 21)); gc = np.empty((B, N, 21))
+    check(ctx.lib.rl_dt_eval_jac(ctx.h, mp, B, N, sp, kp, lp, rp, float(margin), float(track_length), Xp, Up, Tp,
+                                 je.ctypes.data_as(_dp), ji.ctypes.data_as(_dp), gc.ctypes.data_as(_dp)))
+    return je, ji, gc

@@ -104,6 +104,50 @@ def test_dt_eval_nodes_vs_numpy(B, N):
     assert np.isfinite(eq).all() and np.isfinite(g).all()
 
 
+def _pair_cost(Us, Uns, T):
+    return T + 1e-4 * (Uns ** 2).sum(-1) + 1e-1 * ((Uns - Us) ** 2).sum(-1)
+
+
+@pytest.mark.gpu
+def test_dt_jacobian_vs_finite_differences():
+    """rl_dt_eval_jac (forward-mode duals through the same device code) against central differences of
+    the numpy checker, variable by variable of the node pair's 21 local variables."""
+    from spline_trajectory_optimization_amd import ops
+    B, N = 3, 40
+    s, kappa, left, right, L, X, U, T = random_problem(B, N, seed=11)
+    je, ji, gc = ops.dt_eval_jac(MODEL, s, kappa, left, right, 1.2, L, X, U, T)
+    steps = np.array([1e-4] * 6 + [1e-2, 1e-4, 1e-6, 1e-2] + [1e-6] + [1e-4] * 6 + [1e-2, 1e-4, 1e-6, 1e-2])
+    su = np.array([MODEL["Fd_max"], abs(MODEL["Fb_max"]), MODEL["delta_max"], MODEL["mass"] * 50.0])
+    worst = 0.0
+    for j in range(0, N, 7):                      # a sample of node pairs, all 21 variables each
+        jn = (j + 1) % N
+        for var in range(21):
+            h = steps[var]
+            out = []
+            for sgn in (+1, -1):
+                X2, U2, T2 = X.copy(), U.copy(), T.copy()
+                if var < 6: X2[:, j, var] += sgn * h
+                elif var < 10: U2[:, j, var - 6] += sgn * h
+                elif var == 10: T2[:, j] += sgn * h
+                elif var < 17: X2[:, jn, var - 11] += sgn * h
+                else: U2[:, jn, var - 17] += sgn * h
+                eq, g, _ = dt.eval_nodes(MODEL, s, kappa, left, right, 1.2, L, X2, U2, T2)
+                c = _pair_cost(U2[:, j] / su, U2[:, jn] / su, T2[:, j])
+                out.append((eq[:, j], g[:, j], c))
+            fd_eq = (out[0][0] - out[1][0]) / (2 * h)
+            fd_g = (out[0][1] - out[1][1]) / (2 * h)
+            fd_c = (out[0][2] - out[1][2]) / (2 * h)
+            for fd, an in ((fd_eq, je[:, j, :, var]), (fd_g, ji[:, j, :, var]), (fd_c, gc[:, j, var])):
+                err = np.abs(fd - an) / np.maximum(1.0, np.maximum(np.abs(fd), np.abs(an)))
+                worst = max(worst, float(err.max()))
+    print(f"[dt jacobian] worst relative deviation from central differences {worst:.2e}")
+    assert worst <= 1e-4                          # the finite differences themselves are good to ~2e-5 here
+    # structure: the abscissa pin and the simple bounds have constant unit derivatives
+    assert np.all(je[:, :, 7, 0] == 1.0) and np.all(je[:, :, 7, 1:] == 0.0)
+    assert np.all(ji[:, :, 5, 5] == -1.0) and np.all(ji[:, :, 12, 1] == -1.0) and np.all(ji[:, :, 13, 1] == 1.0)
+    assert np.all(gc[:, :, 10] == 1.0)
+
+
 @pytest.mark.gpu
 def test_dt_eval_argument_errors():
     from spline_trajectory_optimization_amd import _lib, ops
