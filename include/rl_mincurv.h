@@ -179,7 +179,7 @@ int rl_mincurv_global_batch_host(rl_ctx* ctx, const rl_track* trk, const double*
  *   ineq [B,N,14] tyre ellipses fl fr rl rr, power, 1 - v, force lo / hi, steer lo / hi, force rate,
  *                 steer rate (more violated side), lateral lo / hi           (<= 0 at a solution)
  *   cost [B]      sum T + 1e-4 sum |U/scale|^2 + 1e-1 sum |dU/scale|^2 (min_time_optimizer.py:119-123)
- * Host pointers.  CPU checker for tests: oracle/double_track.py. */
+ * Host pointers.  CPU checker for tests: oracle/dt_checker.py. */
 enum rl_dt_param {
   RL_DT_KD_F, RL_DT_KB_F, RL_DT_MASS, RL_DT_JZZ, RL_DT_LF, RL_DT_LR, RL_DT_TWF, RL_DT_TWR, RL_DT_DELTA_MAX,
   RL_DT_FR, RL_DT_HCOG, RL_DT_KROLL_F, RL_DT_CL_F, RL_DT_CL_R, RL_DT_RHO, RL_DT_A, RL_DT_CD, RL_DT_MU,

@@ -19,43 +19,43 @@ def dynamics(m, x, u, k):
     """x [...,6] = s, n, xi, omega, beta, v; u [...,4]; k [...] curvature.  Returns xdot [...,6] and
     (Fx, Fy, Fz) each [...,4] in the order fl, fr, rl, rr."""
     n, phi, omega, beta, v = x[..., 1], x[..., 2], x[..., 3], x[..., 4], x[..., 5]
-    fd = u[..., 0] * (np.tanh(u[..., 0]) * 0.5 + 0.5)
-    fb = u[..., 0] * (np.tanh(-u[..., 0]) * 0.5 + 0.5)
-    delta, gam = u[..., 2], u[..., 3]
+    drive = u[..., 0] * (np.tanh(u[..., 0]) * 0.5 + 0.5)
+    brake = u[..., 0] * (np.tanh(-u[..., 0]) * 0.5 + 0.5)
+    delta, transfer = u[..., 2], u[..., 3]
     lf, lr = m["lf"], m["lr"]
     l = lf + lr
     mass = m["mass"]
-    Fx_f = 0.5 * m["kd_f"] * fd + 0.5 * m["kb_f"] * fb - 0.5 * m["fr"] * mass * G * lr / l
-    Fx_r = 0.5 * (1 - m["kd_f"]) * fd + 0.5 * (1 - m["kb_f"]) * fb - 0.5 * m["fr"] * mass * G * lf / l
-    ax = (fd + fb - 0.5 * m["cd"] * m["A"] * v ** 2 - m["fr"] * mass * G) / mass
-    Fz_f = 0.5 * mass * G * lr / l - 0.5 * m["hcog"] / l * mass * ax + 0.25 * m["cl_f"] * m["rho"] * m["A"] * v ** 2
-    Fz_r = 0.5 * mass * G * lr / l + 0.5 * m["hcog"] / l * mass * ax + 0.25 * m["cl_r"] * m["rho"] * m["A"] * v ** 2
-    Fz = np.stack([Fz_f - m["kroll_f"] * gam, Fz_f + m["kroll_f"] * gam,
-                   Fz_r - (1 - m["kroll_f"]) * gam, Fz_r + (1 - m["kroll_f"]) * gam], axis=-1)
+    fx_front = 0.5 * m["kd_f"] * drive + 0.5 * m["kb_f"] * brake - 0.5 * m["fr"] * mass * G * lr / l
+    fx_rear = 0.5 * (1 - m["kd_f"]) * drive + 0.5 * (1 - m["kb_f"]) * brake - 0.5 * m["fr"] * mass * G * lf / l
+    ax = (drive + brake - 0.5 * m["cd"] * m["A"] * v ** 2 - m["fr"] * mass * G) / mass
+    fz_front = 0.5 * mass * G * lr / l - 0.5 * m["hcog"] / l * mass * ax + 0.25 * m["cl_f"] * m["rho"] * m["A"] * v ** 2
+    fz_rear = 0.5 * mass * G * lr / l + 0.5 * m["hcog"] / l * mass * ax + 0.25 * m["cl_r"] * m["rho"] * m["A"] * v ** 2
+    Fz = np.stack([fz_front - m["kroll_f"] * transfer, fz_front + m["kroll_f"] * transfer,
+                   fz_rear - (1 - m["kroll_f"]) * transfer, fz_rear + (1 - m["kroll_f"]) * transfer], axis=-1)
     sb, cb = np.sin(beta), np.cos(beta)
-    a_fl = delta - np.arctan((lf * omega + v * sb) / (v * cb - 0.5 * m["twf"] * omega))
-    a_fr = delta - np.arctan((lf * omega + v * sb) / (v * cb + 0.5 * m["twf"] * omega))
-    a_rl = np.arctan((lr * omega - v * sb) / (v * cb - 0.5 * m["twr"] * omega))
-    a_rr = np.arctan((lr * omega - v * sb) / (v * cb + 0.5 * m["twr"] * omega))
+    slip_fl = delta - np.arctan((lf * omega + v * sb) / (v * cb - 0.5 * m["twf"] * omega))
+    slip_fr = delta - np.arctan((lf * omega + v * sb) / (v * cb + 0.5 * m["twf"] * omega))
+    slip_rl = np.arctan((lr * omega - v * sb) / (v * cb - 0.5 * m["twr"] * omega))
+    slip_rr = np.arctan((lr * omega - v * sb) / (v * cb + 0.5 * m["twr"] * omega))
     mu = m["mu"]
-    Fy = np.stack([mu * Fz[..., 0] * np.sin(m["Cf"] * np.arctan(m["Bf"] * a_fl)),
-                   mu * Fz[..., 1] * np.sin(m["Cf"] * np.arctan(m["Bf"] * a_fr)),
-                   mu * Fz[..., 2] * np.sin(m["Cr"] * np.arctan(m["Br"] * a_rl)),
-                   mu * Fz[..., 3] * np.sin(m["Cr"] * np.arctan(m["Br"] * a_rr))], axis=-1)
-    Fx = np.stack([Fx_f, Fx_f, Fx_r, Fx_r], axis=-1)
+    Fy = np.stack([mu * Fz[..., 0] * np.sin(m["Cf"] * np.arctan(m["Bf"] * slip_fl)),
+                   mu * Fz[..., 1] * np.sin(m["Cf"] * np.arctan(m["Bf"] * slip_fr)),
+                   mu * Fz[..., 2] * np.sin(m["Cr"] * np.arctan(m["Br"] * slip_rl)),
+                   mu * Fz[..., 3] * np.sin(m["Cr"] * np.arctan(m["Br"] * slip_rr))], axis=-1)
+    Fx = np.stack([fx_front, fx_front, fx_rear, fx_rear], axis=-1)
     drag = 0.5 * m["cd"] * m["rho"] * m["A"] * v ** 2
-    FxF, FxR = Fx[..., 0] + Fx[..., 1], Fx[..., 2] + Fx[..., 3]
-    FyF, FyR = Fy[..., 0] + Fy[..., 1], Fy[..., 2] + Fy[..., 3]
-    v_dot = (FxR * cb + FxF * np.cos(delta - beta) + FyR * sb - FyF * np.sin(delta - beta) - drag * cb) / mass
-    beta_dot = -omega + (-FxR * sb + FxF * np.sin(delta - beta) + FyR * cb + FyF * np.cos(delta - beta)
+    sum_fx_front, sum_fx_rear = Fx[..., 0] + Fx[..., 1], Fx[..., 2] + Fx[..., 3]
+    sum_fy_front, sum_fy_rear = Fy[..., 0] + Fy[..., 1], Fy[..., 2] + Fy[..., 3]
+    dv = (sum_fx_rear * cb + sum_fx_front * np.cos(delta - beta) + sum_fy_rear * sb - sum_fy_front * np.sin(delta - beta) - drag * cb) / mass
+    dbeta = -omega + (-sum_fx_rear * sb + sum_fx_front * np.sin(delta - beta) + sum_fy_rear * cb + sum_fy_front * np.cos(delta - beta)
                          + drag * sb) / (mass * v)
-    omega_dot = ((Fx[..., 3] - Fx[..., 2]) * m["twr"] / 2 - FyR * lr
+    domega = ((Fx[..., 3] - Fx[..., 2]) * m["twr"] / 2 - sum_fy_rear * lr
                  + ((Fx[..., 1] - Fx[..., 0]) * np.cos(delta) + (Fy[..., 0] - Fy[..., 1]) * np.sin(delta)) * m["twf"] / 2
-                 + (FyF * np.cos(delta) + FxF * np.sin(delta)) * lf) / m["Jzz"]
-    s_dot = v * np.cos(phi + beta) / (1 - n * k)
-    n_dot = v * np.sin(phi + beta)
-    phi_dot = omega - k * s_dot
-    return np.stack([s_dot, n_dot, phi_dot, omega_dot, beta_dot, v_dot], axis=-1), (Fx, Fy, Fz)
+                 + (sum_fy_front * np.cos(delta) + sum_fx_front * np.sin(delta)) * lf) / m["Jzz"]
+    ds_dt = v * np.cos(phi + beta) / (1 - n * k)
+    dn_dt = v * np.sin(phi + beta)
+    dxi_dt = omega - k * ds_dt
+    return np.stack([ds_dt, dn_dt, dxi_dt, domega, dbeta, dv], axis=-1), (Fx, Fy, Fz)
 
 
 def eval_nodes(m, s, kappa, left, right, margin, track_length, X, U, T):
@@ -74,14 +74,14 @@ def eval_nodes(m, s, kappa, left, right, margin, track_length, X, U, T):
     fm, _ = dynamics(m, Xm, U, k)
     eq = np.empty(X.shape[:2] + (8,))
     eq[..., :6] = X + (t / 6.0) * (f1 + 4 * fm + f2) - Xn
-    delta, gam, v = U[..., 2], U[..., 3], X[..., 5]
-    eq[..., 6] = gam - m["hcog"] / (0.5 * (m["twf"] + m["twr"])) * (
+    delta, transfer, v = U[..., 2], U[..., 3], X[..., 5]
+    eq[..., 6] = transfer - m["hcog"] / (0.5 * (m["twf"] + m["twr"])) * (
         Fy[..., 2] + Fy[..., 3] + (Fx[..., 0] + Fx[..., 1]) * np.sin(delta) + (Fy[..., 0] + Fy[..., 1]) * np.cos(delta))
     eq[..., 7] = X[..., 0] - s[None, :]
     g = np.empty(X.shape[:2] + (14,))
     g[..., :4] = (Fx / (m["mu"] * Fz)) ** 2 + (Fy / (m["mu"] * Fz)) ** 2 - 1.0
-    fd = U[..., 0] * (np.tanh(U[..., 0]) * 0.5 + 0.5)
-    g[..., 4] = v * fd - m["Pmax"]
+    drive = U[..., 0] * (np.tanh(U[..., 0]) * 0.5 + 0.5)
+    g[..., 4] = v * drive - m["Pmax"]
     g[..., 5] = 1.0 - v
     g[..., 6] = m["Fb_max"] - U[..., 0]; g[..., 7] = U[..., 0] - m["Fd_max"]
     g[..., 8] = -m["delta_max"] - delta; g[..., 9] = delta - m["delta_max"]

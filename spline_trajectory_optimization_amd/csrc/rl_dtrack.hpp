@@ -9,7 +9,7 @@
 // drive/brake force, and its quirks, e.g. `lr` in BOTH axle loads, :68-79) and :143-204 (node
 // constraints), min_time_optimizer.py:93-163 (cost, pairing of node i-1 with node i, curvature at
 // the left node), utils/utils.py:10-18 (yaw / abscissa alignment).  CPU checker:
-// oracle/double_track.py (numpy).  One thread per (instance, node pair); everything is FP64
+// oracle/dt_checker.py (numpy).  One thread per (instance, node pair); everything is FP64
 // transcendental-heavy arithmetic on 11 + 11 inputs -> 17 outputs: VALU bound.
 #pragma once
 #include <hip/hip_runtime.h>

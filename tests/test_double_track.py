@@ -4,14 +4,14 @@ NLP (include/rl_mincurv.h: rl_dt_eval_nodes).
 PARITY UNPINNED against the reference: models/double_track.py and min_time_optimizer.py build CasADi
 expressions, CasADi is not importable here and the reference ships no numbers for them.  What is
 checked:
-  * CPU: the numpy checker (oracle/double_track.py) against the physics it states -- straight-line
+  * CPU: the numpy checker (oracle/dt_checker.py) against the physics it states -- straight-line
     equilibrium, left/right mirror symmetry, Hermite-Simpson collocation order (the defect of an
     accurately integrated trajectory shrinks like h^5), the alignment helpers across the start line;
   * GPU: the HIP kernel against that checker on random states to 1e-10 relative."""
 import numpy as np
 import pytest
 
-from oracle import double_track as dt
+from oracle import dt_checker as dt
 
 MODEL = {  # the numbers of the reference's own model self-test (models/double_track.py:207-251)
     "kd_f": 0.0, "kb_f": 0.7, "mass": 1200.0, "Jzz": 1260, "lf": 1.5, "lr": 1.4, "twf": 1.6, "twr": 1.5,
