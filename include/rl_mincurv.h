@@ -208,7 +208,7 @@ int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double*
  * max_left_acc, max_right_acc, max_speed, max_jerk (VehicleParams field order, vehicle.py:7-15).
  * iters[B]: global iterations per instance, -1 where the reference would have raised
  * (np.seterr(all='raise'), simulator.py:164).  The speed profile of an instance is LDS resident
- * (24 B per sample): N up to ~6800 samples, RL_ERR_UNSUPPORTED beyond. */
+ * (18 B per sample): N up to ~8800 samples, RL_ERR_UNSUPPORTED beyond. */
 int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, const double* acc_c,
                int acc_m, const double* dcc_x, const double* dcc_c, int dcc_m, const double* params,
                int* iters);

@@ -1032,7 +1032,7 @@ __device__ __forceinline__ double qss_lat_acc(double v, double r, double bank) {
 // The reference steps the fronts of a sub-pass strictly in list order, each seeing the writes of the
 // fronts before it.  Here the list is taken 64 fronts at a time, one front per lane, by SPECULATION
 // WITH PREFIX COMMIT: every pending lane computes its step from the current profile; lanes that
-// would write stamp their target point with their lane number (LDS atomic min); a lane is
+// would write stamp their target point's bucket with their lane number (LDS atomic min); a lane is
 // conflicted when an EARLIER lane writes its source or its target point; all lanes before the
 // first conflicted one are exactly what the sequential order would have produced (their inputs
 // were untouched), so they commit together; the rest is re-speculated on the new profile.  The
@@ -1040,6 +1040,7 @@ __device__ __forceinline__ double qss_lat_acc(double v, double r, double bank) {
 // stop without writing (the common case) never conflict, and chains of actual writes degrade to the
 // sequential order.  Spawned fronts are appended in list order (ballot prefix) and finished fronts
 // compacted away by all lanes at the end of each global iteration.
+constexpr int kQssStamp = 1024;  // stamp buckets (point index mod 1024): a shared bucket only costs a false conflict
 __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
 #pragma clang fp contract(off)  // decisions below compare freshly computed speeds: keep the reference's roundings
   extern __shared__ double qss_lds[];
@@ -1050,8 +1051,8 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
   double* tab = qss_lds + 2 * N;   // acc_x [m+1], acc_c [4m], dcc_x [m'+1], dcc_c [4m']
   double* t_ax = tab; double* t_ac = t_ax + a.acc_m + 1;
   double* t_dx = t_ac + 4 * a.acc_m; double* t_dc = t_dx + a.dcc_m + 1;
-  int* OWN = reinterpret_cast<int*>(t_dc + 4 * a.dcc_m);  // [N] ITERATION_FLAG
-  int* STAMP = OWN + N;                                    // [N] lowest lane writing this point in the current round
+  int* STAMP = reinterpret_cast<int*>(t_dc + 4 * a.dcc_m);  // [kQssStamp] lowest lane writing a point of this bucket in the current round
+  unsigned short* OWN = reinterpret_cast<unsigned short*>(STAMP + kQssStamp);  // [N] ITERATION_FLAG (0xFFFF = -1)
   int* fE = a.flags + (size_t)b * 5 * cap;
   int* fT = fE + cap; int* fX = fT + cap; int* sE = fX + cap; int* sX = sE + cap;
   int* nw = a.fresh + (size_t)b * cap;
@@ -1060,6 +1061,7 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
   double* GS = RAD + N;
   constexpr int kFree = 0x7fffffff;
   const double lat0 = qss_acc_circle_lon(a, 0.0);
+  for (int i = lane; i < kQssStamp; i += 64) STAMP[i] = kFree;
   for (int i = lane; i <= a.acc_m; i += 64) t_ax[i] = a.acc_x[i];
   for (int i = lane; i < 4 * a.acc_m; i += 64) t_ac[i] = a.acc_c[i];
   for (int i = lane; i <= a.dcc_m; i += 64) t_dx[i] = a.dcc_x[i];
@@ -1074,8 +1076,7 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
     const double v = qss_calc_v(lat0, p[5], p[13]);
     V[i] = v < a.max_speed ? v : a.max_speed;
     A[i] = 0.0;
-    OWN[i] = i;
-    STAMP[i] = kFree;
+    OWN[i] = (unsigned short)i;
     fE[i] = i; fT[i] = i; fX[i] = i; sE[i] = 0; sX[i] = 0;
   }
   __syncthreads();
@@ -1126,7 +1127,7 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
               else if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve &&
                        greedy <= a.max_speed) {
                 const double pv = V[ni], pa = A[ni];
-                if (OWN[ni] != -1 && pv < greedy) {
+                if (OWN[ni] != 0xFFFF && pv < greedy) {
                   new_stop = 1;  // a slower profile already owns this point: stop
                 } else {
                   if (!(min_acc <= pa && pa <= max_acc)) new_stop = -1;  // merge mode
@@ -1143,21 +1144,21 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
                 }
               }
             }
-            if (wr) atomicMin(&STAMP[ni], lane);
+            if (wr) atomicMin(&STAMP[ni & (kQssStamp - 1)], lane);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           bool confl = false;
-          if (mine) { const int s1 = STAMP[li], s2 = STAMP[ni]; confl = (s1 < s2 ? s1 : s2) < lane; }
+          if (mine) { const int s1 = STAMP[li & (kQssStamp - 1)], s2 = STAMP[ni & (kQssStamp - 1)]; confl = (s1 < s2 ? s1 : s2) < lane; }
           const unsigned long long cm = __ballot(confl);
           const int qstar = cm != 0ull ? __ffsll((long long)cm) - 1 : 64;
           const bool commit = mine && lane < qstar;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (mine && wr) STAMP[ni] = kFree;
+          if (mine && wr) STAMP[ni & (kQssStamp - 1)] = kFree;
           if (commit) {
-            if (wr) { V[ni] = nv; A[ni] = na; OWN[ni] = nown; }
+            if (wr) { V[ni] = nv; A[ni] = na; OWN[ni] = (unsigned short)nown; }
             li = ni;
             ni = side == 0 ? (li - 1 < 0 ? N - 1 : li - 1) : (li + 1 == N ? 0 : li + 1);  // unused: one step per sub-pass
             if (new_stop != 0) my_stop = new_stop;
@@ -1213,7 +1214,7 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
     const double v = V[i];
     p[4] = v; p[14] = A[i];
     p[15] = v * v / RAD[i] + GS[i];
-    p[18] = (double)OWN[i];
+    p[18] = OWN[i] == 0xFFFF ? -1.0 : (double)OWN[i];
   }
   if (err) return;
   // Trajectory.fill_time (models/trajectory.py:158-180): per-segment times, written to the NEXT point

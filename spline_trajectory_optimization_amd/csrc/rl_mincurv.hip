@@ -802,7 +802,9 @@ int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, c
   RL_HIP(ddx.alloc(dcc_m + 1)); RL_HIP(ddc.alloc((size_t)4 * dcc_m));
   RL_HIP(dfl.alloc((size_t)B * cap * 5)); RL_HIP(dnw.alloc((size_t)B * cap)); RL_HIP(dit.alloc(B));
   RL_HIP(dcst.alloc((size_t)B * 3 * N));
-  const size_t lds = ((size_t)2 * N + 5 * (acc_m + dcc_m) + 2 + N + 1) * sizeof(double);  // speed, lon acc, tables, owner + stamp
+  if (N >= 65535) return fail(RL_ERR_UNSUPPORTED, "qss: owner indices are 16 bits");
+  const size_t lds = ((size_t)2 * N + 5 * (acc_m + dcc_m) + 2) * sizeof(double) + (size_t)rl::kQssStamp * sizeof(int) +
+                     (((size_t)N * sizeof(unsigned short) + 7) & ~(size_t)7);  // speed, lon acc, tables, stamp buckets, owner
   if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "qss: trajectory too long for the LDS-resident profile");
   RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   RL_HIP(hipMemcpyAsync(dax.p, acc_x, dax.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
