@@ -93,6 +93,35 @@ def make_track(spline: BSplineTrajectory, N: int, device=None):
     return _lib.Track(_lib.Context.get(device), t, cx, cy, k, N)
 
 
+# ---------------------------------------------------------------- min-time NLP plumbing (config 5)
+def min_time_initial_guess(points):
+    """The initial guess the reference hands to its min-time NLP when no previous solution is given
+    (min_time_optimizer.py:146-151): the QSS-simulated table's abscissa, speed and segment times, zero
+    lateral offset / relative yaw / yaw rate / slip, controls (1, -1, 0.001, 0) in physical units.
+    `points` = [N,19] after Simulator.run_simulation (rl_qss_sim).  Returns (s [N], X [N,6], U [N,4], T [N])
+    ready for ops.dt_eval_nodes / ops.dt_eval_jac."""
+    pts = np.asarray(points, dtype=np.float64)
+    N = len(pts)
+    s = pts[:, 6].copy()                      # DIST_TO_SF_BWD: race_track.abscissa (race_track.py:56)
+    X = np.zeros((N, 6)); X[:, 0] = s; X[:, 5] = pts[:, 4]
+    U = np.tile(np.array([1.0, -1.0, 0.001, 0.0]), (N, 1))
+    T = pts[:, 16].copy()
+    return s, X, U, T
+
+
+def signed_curvature(points):
+    """Centre-line curvature with sign at the samples of a sampled table (the turn radius of column 5 is
+    unsigned): heading change per arc length, central differences over the closed line."""
+    pts = np.asarray(points, dtype=np.float64)
+    yaw = np.unwrap(pts[:, 3])
+    dyaw = np.roll(yaw, -1) - np.roll(yaw, 1)
+    dyaw[0] += 2 * np.pi * round((yaw[-1] - yaw[0]) / (2 * np.pi)); dyaw[-1] += 2 * np.pi * round((yaw[-1] - yaw[0]) / (2 * np.pi))
+    L = pts[0, 7] if pts[0, 7] > 0 else pts[-1, 6]
+    ds = np.roll(pts[:, 6], -1) - np.roll(pts[:, 6], 1)
+    ds[0] += L; ds[-1] += L
+    return dyaw / ds
+
+
 # ---------------------------------------------------------------- rank sharding (SURVEY.md 8e)
 def shard_range(B, rank, world):
     """Contiguous block partition: rank r takes instances [lo, hi)."""

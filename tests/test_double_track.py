@@ -149,6 +149,38 @@ def test_dt_jacobian_vs_finite_differences():
 
 
 @pytest.mark.gpu
+def test_qss_warm_start_into_the_nlp_functions(fits, rings):
+    """Config 5's two GPU pieces together: the QSS simulation of the Monza centre line (k_qss_sim) gives
+    the initial guess the reference would hand to IPOPT (min_time_optimizer.py:146-151); the NLP functions
+    (k_dt_eval_nodes) at that guess are finite, the abscissa pins and the lateral bounds hold, and the
+    defects have the size of one sample spacing -- the guess is a starting point, not a solution."""
+    from scipy.interpolate import CubicSpline
+    from conftest import golden, spline
+    from oracle import oracle as orc
+    from spline_trajectory_optimization_amd import batch, ops
+    g = golden("G6_simulator.npz")
+    t, cx, cy, k, L = spline(fits, "c100")
+    N = 800
+    pts = ops.sample_along(t, cx, cy, k, L, np.linspace(0, 1, N, endpoint=False))
+    ops.fill_bounds(pts, rings[0], rings[1])
+    acc = CubicSpline(g["acc_lookup"][:, 0], g["acc_lookup"][:, 1]); dcc = CubicSpline(g["dcc_lookup"][:, 0], g["dcc_lookup"][:, 1])
+    sim, it = ops.qss_sim(pts, acc.x, acc.c, dcc.x, dcc.c, g["params"])
+    s, X, U, T = batch.min_time_initial_guess(sim)
+    kappa = batch.signed_curvature(sim)
+    wl, wr = batch.half_widths_from_bounds(sim)
+    eq, ineq, cost = ops.dt_eval_nodes(MODEL, s, kappa, wl, -wr, 1.2, L, X[None], U[None], T[None])
+    oeq, og, ocost = dt.eval_nodes(MODEL, s, kappa, wl, -wr, 1.2, L, X[None], U[None], T[None])
+    assert np.isfinite(eq).all() and np.isfinite(ineq).all()
+    assert (np.abs(eq - oeq) / np.maximum(1.0, np.abs(oeq))).max() <= 1e-10
+    assert np.abs(eq[0, :, 7]).max() == 0.0                    # abscissa pins
+    assert (ineq[0, :, 12:14] < 0).all()                       # on the centre line, inside the margins
+    assert np.abs(kappa).max() < 0.2 and abs(np.sum(kappa * (np.roll(s, -1) - s)[:N]) ) < 4 * np.pi
+    assert cost[0] == pytest.approx(ocost[0], rel=1e-12)
+    print(f"[config5 plumbing] QSS iterations {it[0]}, lap-time guess sum T = {T.sum():.2f} s, "
+          f"defect |s| median {np.median(np.abs(eq[0, :, 0])):.3f} m, |v| median {np.median(np.abs(eq[0, :, 5])):.3f} m/s")
+
+
+@pytest.mark.gpu
 def test_dt_eval_argument_errors():
     from spline_trajectory_optimization_amd import _lib, ops
     s, kappa, left, right, L, X, U, T = random_problem(2, 8)
