@@ -207,7 +207,8 @@ int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double*
  * (breakpoints x[m+1], coefficients c[4][m], c[0] = cubic term).  params = max_lon_acc, max_lon_dcc,
  * max_left_acc, max_right_acc, max_speed, max_jerk (VehicleParams field order, vehicle.py:7-15).
  * iters[B]: global iterations per instance, -1 where the reference would have raised
- * (np.seterr(all='raise'), simulator.py:164).  The speed profile of an instance is LDS resident
+ * (np.seterr(all='raise'), simulator.py:164) or after 16 N + 64 global iterations (the reference has no
+ * limit and would not return).  The speed profile of an instance is LDS resident
  * (18 B per sample): N up to ~8800 samples, RL_ERR_UNSUPPORTED beyond. */
 int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, const double* acc_c,
                int acc_m, const double* dcc_x, const double* dcc_c, int dcc_m, const double* params,

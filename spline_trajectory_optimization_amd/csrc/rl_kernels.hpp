@@ -1204,6 +1204,10 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
     __syncthreads();
     if (nf == 0) break;
     ++itr;
+    // The reference has no iteration limit (a front on a perfectly uniform circle would go round for
+    // ever); a GPU kernel must end: far beyond any real profile (334 iterations at N = 2000) it gives up
+    // and reports the instance like a raised error.
+    if (itr > 16 * N + 64) { err = 1; break; }
   }
   if (lane == 0) a.iters[b] = err ? -1 : itr;
   __syncthreads();
