@@ -57,9 +57,14 @@ typedef struct rl_stats {
 } rl_stats;
 
 int rl_version(void);
-/* test aid: with RL_DEBUG_DUMP=1 in the environment, rl_mincurv_sweep_joint records, for instance 0
- * and every window, the QP it assembled and what it decided (48 header doubles + 9 per row, see
- * tests/test_hip_parity.py::test_joint_window_qps_replayed); this copies the first n doubles out. */
+/* Test aids (no effect on results).  rl_debug_dump_enable(m), m > 0: the next sweep calls record what
+ * they assembled and decided -- the sliding-window variant for instance 0, per window (48 header doubles
+ * + 9 per row, tests/test_hip_parity.py::test_joint_window_qps_replayed); the degree-5 sweep for the first
+ * min(m, B) instances, per step: [idx, H_xx, H_yy, g_x, g_y, lo_x, hi_x, lo_y, hi_y, zero-row flag,
+ * accepted, new x, new y, 3 reserved] + the control points the step started from, cx[n], cy[n]
+ * (tests/test_sweep_replay.py re-derives every step with the oracle from those control points).
+ * rl_debug_dump_enable(0) switches it off; rl_debug_read copies the first n doubles of the record out. */
+int rl_debug_dump_enable(int instances);
 int rl_debug_read(double* out, long long n);
 const char* rl_last_error(void);
 
@@ -95,6 +100,13 @@ void rl_track_destroy(rl_track* trk);
 int rl_track_set_rings(rl_track* trk, const double* ringL, int nL, const double* ringR, int nR);
 /* replace the shared initial control points (BSplineTrajectory.set_control_point, trajectory.py:296) */
 int rl_track_set_control_points(rl_track* trk, const double* cx0, const double* cy0);
+/* BSplineTrajectory._length of the spline the track was made from (models/trajectory.py:223); only used
+ * to fill DIST_TO_SF_FWD of the table rl_mincurv_sweep / _joint return (the reference keeps the length
+ * of the spline as constructed: set_control_point, trajectory.py:296-298, never updates it). */
+int rl_track_set_length(rl_track* trk, double length);
+/* Threading: an rl_track owns device scratch (per-instance ring / crossing scratch of the sweep, tables
+ * of the global QP) that solves write: a track is SINGLE-STREAM.  Use one rl_track per stream; distinct
+ * tracks and distinct contexts are independent. */
 
 /* ---- a7: TrajectoryOptimizer.min_curvature_cost  (optimization/optimizer.py:24-86)
  * for n_idx control points at once; z is [n_idx,2] (NULL = the current control points);
@@ -111,7 +123,9 @@ int rl_track_constraint(rl_ctx* ctx, const rl_track* trk, const double* points, 
 /* ---- a7+a8+a11+a4+a3+a5+a12: TrajectoryOptimizer.run_min_curvature_qp
  * (optimization/optimizer.py:256-341) for ONE instance bounded by the shared rings of `trk`.
  * i_start[max_iter] pins np.random.randint of optimizer.py:303.  cx, cy [n] in/out;
- * points [N,19] out (final sample_along table with bounds; may be NULL);
+ * points [N,19] out (may be NULL): the final table = sample_along(ts = i/N) of the optimised spline
+ *   (X, Y, YAW, turn radius, IDX, ITER_FLAG = -1) + fill_bounds (LBX..RBY); DIST_TO_SF_BWD / _FWD
+ *   (models/trajectory.py:283-289) are filled when rl_track_set_length was called, 0 otherwise;
  * n_success[2*max_iter] out (forward/backward successes per iteration, optimizer.py:314,325). */
 int rl_mincurv_sweep(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_iter,
                      double* cx, double* cy, double* points, int* n_success, rl_stats* stats);

@@ -547,6 +547,117 @@ void orc_solve_width_batch(const double* t, int nt, const double* cx0, const dou
   free(base);
 }
 
+/* ---------------------------------------------------------------- teacher-forced step replay
+ *
+ * Test aid for the HIP sweep kernel's per-step dump (tests/test_sweep_replay.py): for each recorded
+ * step the kernel supplies the control points it held BEFORE the step and the control point it
+ * worked on; this re-derives that ONE step exactly as optimize_one does (optimizer.py:263-293) from
+ * those control points -- sample_along + fill_bounds of the samples the step reads (the support of
+ * idx; the reference re-samples the whole table after every update, so the table is a pure function
+ * of the current control points), min_curvature_cost, track_constraint, the QP -- and reports, besides
+ * the result, how far rounding noise can move each decision (the 1/b amplification of DESIGN.md
+ * "Conditioning").  Steps are independent of each other (teacher forcing), hence the OpenMP loop.
+ *
+ * out[s][ORC_REPLAY_STRIDE]:
+ *   0 status (0 solved, 2 infeasible, 3 not convex / non-finite)   1,2 H_xx, H_yy   3,4 g_x, g_y
+ *   5..8  clamp interval lo_x, hi_x, lo_y, hi_y implied by the rows with b > 0
+ *   9,10  minimiser x, y (valid when status == 0)
+ *   11..14 noise radius [m] of lo_x, hi_x, lo_y, hi_y: the largest eps / b among the rows that can set it
+ *          within their own errors
+ *   15    smallest slack of the b == 0 rows (min over rows of min(-lba, uba); +inf when there are none):
+ *         below eps the zero-row verdict is decided by rounding
+ *   16    support size M                                                                   */
+void orc_width_rings(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
+                     const double* widths /*[N,2]*/, double* ringL /*[N,2]*/, double* ringR /*[N,2]*/) {
+  /* identical arithmetic to orc_solve_width_batch's ring construction */
+  double* base = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
+  double* u = (double*)malloc((size_t)N * sizeof(double));
+  for (int i = 0; i < N; ++i) u[i] = grid_u(i, N);
+  orc_trajectory_init(base, N);
+  sample_geometry(t, nt, cx0, cy0, k, u, N, base);
+  for (int i = 0; i < N; ++i) {
+    const double* p = base + (size_t)i * ORC_NCOL;
+    double wl = widths[(size_t)i * 2], wr = widths[(size_t)i * 2 + 1];
+    ringL[2 * i] = p[ORC_X] + wl * cos(p[ORC_YAW] + M_PI / 2.0);
+    ringL[2 * i + 1] = p[ORC_Y] + wl * sin(p[ORC_YAW] + M_PI / 2.0);
+    ringR[2 * i] = p[ORC_X] + wr * cos(p[ORC_YAW] + (-M_PI / 2.0));
+    ringR[2 * i + 1] = p[ORC_Y] + wr * sin(p[ORC_YAW] + (-M_PI / 2.0));
+  }
+  free(u);
+  free(base);
+}
+
+void orc_replay_steps(const double* t, int nt, int k, int N, const double* ringL, int nL,
+                      const double* ringR, int nR, int n_steps, const int* idx,
+                      const double* cxs /*[n_steps][n]*/, const double* cys /*[n_steps][n]*/,
+                      double* out /*[n_steps][ORC_REPLAY_STRIDE]*/, int nthreads) {
+  const int n = nt - k - 1;
+  const double eps = 8.0 * 2.220446049250313e-16 * 2048.0; /* as orc_qp_solve_separable */
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int s = 0; s < n_steps; ++s) {
+    const double* cx = cxs + (size_t)s * n;
+    const double* cy = cys + (size_t)s * n;
+    double* o = out + (size_t)s * ORC_REPLAY_STRIDE;
+    for (int q = 0; q < ORC_REPLAY_STRIDE; ++q) o[q] = 0.0;
+    int i0, i1;
+    support_range(t, k, idx[s], N, &i0, &i1);
+    const int M = i1 - i0;
+    o[16] = (double)M;
+    double* points = (double*)calloc((size_t)N * ORC_NCOL, sizeof(double));
+    double* u = (double*)malloc((size_t)(M > 0 ? M : 1) * sizeof(double));
+    double* A = (double*)malloc((size_t)(M > 0 ? M : 1) * 8 * sizeof(double));
+    double *lba = A + (size_t)M * 4, *uba = A + (size_t)M * 6;
+    for (int i = 0; i < M; ++i) u[i] = grid_u(i0 + i, N);
+    if (M > 0) {
+      sample_geometry(t, nt, cx, cy, k, u, M, points + (size_t)i0 * ORC_NCOL);       /* :286 */
+      orc_fill_bounds(points + (size_t)i0 * ORC_NCOL, M, ringL, nL, ringR, nR, 100.0); /* :288 */
+    }
+    double z0[2] = {cx[idx[s]], cy[idx[s]]}, H[4], g[2], x[2] = {0.0, 0.0};
+    orc_min_curvature_cost(z0, idx[s], t, nt, cx, cy, k, N, H, g);
+    orc_track_constraint(idx[s], t, nt, cx, cy, k, points, N, A, lba, uba);
+    const int st = orc_qp_solve_separable(H, g, A, lba, uba, M, x);
+    o[0] = (double)st; o[1] = H[0]; o[2] = H[3]; o[3] = g[0]; o[4] = g[1]; o[9] = x[0]; o[10] = x[1];
+    double zero_slack = INFINITY;
+    for (int c = 0; c < 2; ++c) {
+      double lo = -INFINITY, hi = INFINITY, a_lo = INFINITY, a_hi = INFINITY;
+      for (int i = 0; i < M; ++i) {
+        int r = 2 * i + c;
+        double a = A[2 * r + c], l = lba[r], uu = uba[r];
+        if (a > 0.0) {
+          double ql = l / a, qu = uu / a;
+          if (ql > lo) { lo = ql; a_lo = a; }
+          if (qu < hi) { hi = qu; a_hi = a; }
+        } else if (a == 0.0) {
+          double sl = fmin(-l, uu);
+          if (sl < zero_slack) zero_slack = sl;
+        }
+      }
+      o[5 + 2 * c] = lo; o[6 + 2 * c] = hi;
+      /* noise radius of lo = max_i l_i/a_i when every quotient carries its own error e_i = eps/a_i:
+       * the largest e_i among the rows that can win the max within the errors (the binding row's
+       * own radius at least); likewise for hi */
+      double r_lo = eps / a_lo, r_hi = eps / a_hi;
+      for (int i = 0; i < M; ++i) {
+        int r = 2 * i + c;
+        double a = A[2 * r + c];
+        if (a > 0.0) {
+          double e = eps / a;
+          if (lba[r] / a + e >= lo - eps / a_lo && e > r_lo) r_lo = e;
+          if (uba[r] / a - e <= hi + eps / a_hi && e > r_hi) r_hi = e;
+        }
+      }
+      o[11 + 2 * c] = r_lo; o[12 + 2 * c] = r_hi;
+    }
+    o[15] = zero_slack;
+    free(A);
+    free(u);
+    free(points);
+  }
+}
+
 /* ---------------------------------------------------------------- QSS speed-profile simulator */
 
 /* scipy.interpolate.CubicSpline.__call__ (PPoly.evaluate, extrapolate=True): breakpoints x[m+1],

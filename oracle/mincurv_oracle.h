@@ -141,6 +141,14 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
 double orc_last_kappa(void);
 void orc_reset_kappa(void);
 
+/* Teacher-forced replay of recorded sweep steps (see the comment block in mincurv_oracle.c). */
+#define ORC_REPLAY_STRIDE 20
+void orc_width_rings(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
+                     const double* widths, double* ringL, double* ringR);
+void orc_replay_steps(const double* t, int nt, int k, int N, const double* ringL, int nL,
+                      const double* ringR, int nR, int n_steps, const int* idx,
+                      const double* cxs, const double* cys, double* out, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

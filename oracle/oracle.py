@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmincurv_oracle.so")
+# ORACLE_SO: load another build of the same source (the -fsanitize build of tools/run_oracle_sanitized.sh)
+_SO = os.environ.get("ORACLE_SO") or os.path.join(_HERE, "libmincurv_oracle.so")
 
 NCOL = 19
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -246,3 +247,34 @@ def global_mincurv(t, cx0, cy0, k, N, w_left, w_right, margin=0.0, n_outer=6):
            cy.ctypes.data_as(_dp), xy.ctypes.data_as(_dp), a.ctypes.data_as(_dp), st.ctypes.data_as(_dp))
     assert rc == 0
     return cx, cy, xy, a, st
+
+
+REPLAY_STRIDE = 20
+
+
+def width_rings(t, cx0, cy0, k, N, widths):
+    """Rings of one width-form instance, built exactly as solve_width_batch builds them."""
+    t, tp = _d(t); cx0, xp = _d(cx0); cy0, yp = _d(cy0); widths, wp = _d(widths)
+    assert widths.shape == (N, 2)
+    rl = np.zeros((N, 2)); rr = np.zeros((N, 2))
+    f = lib().orc_width_rings
+    f.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]
+    f.restype = None
+    f(tp, len(t), xp, yp, int(k), int(N), wp, rl.ctypes.data_as(_dp), rr.ctypes.data_as(_dp))
+    return rl, rr
+
+
+def replay_steps(t, k, N, ringL, ringR, idx, cxs, cys, nthreads=8):
+    """Teacher-forced re-derivation of recorded sweep steps (mincurv_oracle.c: orc_replay_steps).
+    idx [S], cxs/cys [S,n] = the control points BEFORE each step.  Returns [S, REPLAY_STRIDE]."""
+    t, tp = _d(t); ringL, lp = _d(ringL); ringR, rp = _d(ringR)
+    idx, ip = _i(idx); cxs, xp = _d(cxs); cys, yp = _d(cys)
+    S = len(idx)
+    assert cxs.shape == (S, len(t) - k - 1) and cys.shape == cxs.shape
+    out = np.zeros((S, REPLAY_STRIDE))
+    f = lib().orc_replay_steps
+    f.argtypes = [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int,
+                  ctypes.c_int, _ip, _dp, _dp, _dp, ctypes.c_int]
+    f.restype = None
+    f(tp, len(t), int(k), int(N), lp, len(ringL), rp, len(ringR), S, ip, xp, yp, out.ctypes.data_as(_dp), int(nthreads))
+    return out

@@ -36,6 +36,7 @@ class RlError(RuntimeError):
 _SIGNATURES = {
     "rl_version": (ctypes.c_int, []),
     "rl_last_error": (ctypes.c_char_p, []),
+    "rl_debug_dump_enable": (ctypes.c_int, [ctypes.c_int]),
     "rl_debug_read": (ctypes.c_int, [_dp, ctypes.c_longlong]),
     "rl_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "rl_ctx_destroy": (None, [_vp]),
@@ -52,6 +53,7 @@ _SIGNATURES = {
     "rl_track_destroy": (None, [_vp]),
     "rl_track_set_rings": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, ctypes.c_int]),
     "rl_track_set_control_points": (ctypes.c_int, [_vp, _dp, _dp]),
+    "rl_track_set_length": (ctypes.c_int, [_vp, ctypes.c_double]),
     "rl_mincurv_cost": (ctypes.c_int, [_vp, _vp, _ip, ctypes.c_int, _dp, _dp, _dp, _ip]),
     "rl_track_constraint": (ctypes.c_int, [_vp, _vp, _dp, ctypes.c_int, _dp, _dp, _dp, _ip]),
     "rl_mincurv_sweep": (ctypes.c_int, [_vp, _vp, _ip, ctypes.c_int, _dp, _dp, _dp, _ip,
@@ -177,6 +179,9 @@ class Track:
         ringL, lp = as_d(ringL)
         ringR, rp = as_d(ringR)
         check(self.ctx.lib.rl_track_set_rings(self.h, lp, len(ringL), rp, len(ringR)))
+
+    def set_length(self, length):
+        check(self.ctx.lib.rl_track_set_length(self.h, float(length)))
 
     def set_control_points(self, cx, cy):
         cx, xp = as_d(cx)

@@ -109,7 +109,8 @@ __global__ void k_sample_geometry(const double* __restrict__ t, int nt,
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int n = nt - K - 1;
-  const double x = u[i];
+  // u == nullptr: the uniform grid Trajectory.ts() = np.linspace(0, 1, N, endpoint=False)
+  const double x = u ? u[i] : (double)i * (1.0 / (double)N);
   const int l = find_interval(t, K, n, x);
   double h[K + 1];
   double v[6];
@@ -121,20 +122,22 @@ __global__ void k_sample_geometry(const double* __restrict__ t, int nt,
     for (int a = 0; a <= K; ++a) { sx += cx[l - K + a] * h[a]; sy += cy[l - K + a] * h[a]; }
     v[2 * m] = sx; v[2 * m + 1] = sy;
   }
-  double* p = points + (size_t)i * 19;
+  if (points) {  // points == nullptr: only the segment lengths are wanted
+    double* p = points + (size_t)i * 19;
 #pragma unroll
-  for (int c = 0; c < 19; ++c) p[c] = 0.0;
-  p[0] = v[0];
-  p[1] = v[1];
-  p[3] = atan2(v[3], v[2]);
-  const double s2 = v[2] * v[2] + v[3] * v[3];
-  const double curvature = fabs(v[2] * v[5] - v[3] * v[4]) / sqrt(s2 * s2 * s2);
-  p[5] = 1.0 / fabs(curvature);
-  p[17] = (double)i;
-  p[18] = -1.0;
+    for (int c = 0; c < 19; ++c) p[c] = 0.0;
+    p[0] = v[0];
+    p[1] = v[1];
+    p[3] = atan2(v[3], v[2]);
+    const double s2 = v[2] * v[2] + v[3] * v[3];
+    const double curvature = fabs(v[2] * v[5] - v[3] * v[4]) / sqrt(s2 * s2 * s2);
+    p[5] = 1.0 / fabs(curvature);
+    p[17] = (double)i;
+    p[18] = -1.0;
+  }
   double len = 0.0;
   if (i > 0) {
-    const double a = u[i - 1], b = x;
+    const double a = u ? u[i - 1] : (double)(i - 1) * (1.0 / (double)N), b = x;
     const double centr = 0.5 * (a + b), hl = 0.5 * (b - a);
     double resk = c_wgk[10] * speed_at<K>(t, n, cx, cy, centr);
     for (int j = 0; j < 5; ++j) {
@@ -150,6 +153,12 @@ __global__ void k_sample_geometry(const double* __restrict__ t, int nt,
     len = resk * hl;
   }
   seg[i] = len;
+}
+
+// [n,2] interleaved control points -> [2][n]
+__global__ void k_split_ctrl(const double* __restrict__ ctrl, int n, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) { out[j] = ctrl[2 * j]; out[n + j] = ctrl[2 * j + 1]; }
 }
 
 // sequential accumulation, in the reference's order (one lane; N adds)
@@ -291,9 +300,19 @@ struct SweepArgs {
   int* status;          // [B] or null
   double* gscratch;     // per-instance global scratch when rings/sigma do not fit LDS
   size_t gscratch_stride;  // doubles per instance
-  double* dbg;          // optional per-window QP dump of instance 0 (joint variant, tests only)
-  int debug;            // timing ablations only (RL_DEBUG_FLAGS): results are WRONG when non-zero
+  double* dbg;          // test aid (rl_debug_dump_enable): per-window QP dump of instance 0 (joint variant) /
+                        // per-step dump of the first dbg_instances instances (sweep, DUMP instantiation)
+  int dbg_instances;
+  int debug;            // timing ablations, only in -DRL_ABLATION builds (results are WRONG when non-zero)
 };
+
+// Timing-ablation switches exist only in a diagnostic build (hipcc -DRL_ABLATION, tools/profile_bench.sh):
+// the shipped library has no way to skip a phase.
+#ifdef RL_ABLATION
+#define RL_ABLATE(a, bit) (((a).debug & (bit)) != 0)
+#else
+#define RL_ABLATE(a, bit) false
+#endif
 
 // LDS carve (doubles).  cpad = n rounded up to even so every later array is 16-byte aligned.
 struct SweepLds {
@@ -329,7 +348,13 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   return L;
 }
 
-template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false>
+// Per-step record of the DUMP instantiation (tests/test_sweep_replay.py): kSweepDumpHead scalars, then the
+// control points the step STARTED from (cx[n], cy[n]).
+//   0 idx  1,2 H_xx,H_yy  3,4 g_x,g_y  5..8 lo_x,hi_x,lo_y,hi_y  9 zero-row / NaN flag  10 accepted
+//   11,12 the new control point (when accepted)
+constexpr int kSweepDumpHead = 16;
+
+template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false>
 __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         eval_sample<K, 1>(tr, cx, cy, i, l, c);
         double dx, dy, inv_s2;
         scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);  // max_dist * (cos, sin)(yaw + pi/2)
-        const bool skip = (a.debug & 2) != 0;
+        const bool skip = RL_ABLATE(a, 2);
         const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
                                             dx, dy, a.max_dist, skip);
         const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
@@ -841,7 +866,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         double hxx = 0.0, hyy = 0.0, gx = 0.0, gy = 0.0;
         double lox = -INFINITY, hix = INFINITY, loy = -INFINITY, hiy = INFINITY;
         bool bad = false;
-        for (int i = s0 + tid; i < s1 && !(a.debug & 4); i += BLOCK) {
+        for (int i = s0 + tid; i < s1 && !RL_ABLATE(a, 4); i += BLOCK) {
           const int l = tr.ell[i];
           CurvePoint<K, 2> c;
           eval_sample<K, 2>(tr, cx, cy, i, l, c);
@@ -909,11 +934,25 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           const double g0 = s[2] + s[2], g1 = s[3];
           const bool okw = (s[8] == 0.0) && (H0 > 0.0) && (H1 > 0.0) && isfinite(H0) && isfinite(H1) &&
                            isfinite(g0) && isfinite(g1) && (s[4] <= s[5]) && (s[6] <= s[7]);
+          double* rec = nullptr;
+          if (DUMP) {
+            if (a.dbg && b < a.dbg_instances) {
+              const size_t per_inst = (size_t)a.max_iter * 2 * steps * (kSweepDumpHead + 2 * n);
+              rec = a.dbg + (size_t)b * per_inst + ((size_t)(it * 2 + pass) * steps + stp) * (kSweepDumpHead + 2 * n);
+              for (int j = lane; j < n; j += kWave) { rec[kSweepDumpHead + j] = cx[j]; rec[kSweepDumpHead + n + j] = cy[j]; }
+              if (tid == 0) {
+                rec[0] = (double)idx; rec[1] = H0; rec[2] = H1; rec[3] = g0; rec[4] = g1;
+                rec[5] = s[4]; rec[6] = s[5]; rec[7] = s[6]; rec[8] = s[7]; rec[9] = s[8];
+                rec[10] = okw ? 1.0 : 0.0; rec[11] = 0.0; rec[12] = 0.0;
+              }
+            }
+          }
           if (tid == 0) {
             if (okw) {
               double nzx = -g0 / H0, nzy = -g1 / H1;
               nzx = fmin(fmax(nzx, s[4]), s[5]);
               nzy = fmin(fmax(nzy, s[6]), s[7]);
+              if (DUMP) { if (rec) { rec[11] = nzx; rec[12] = nzy; } }
               // optimizer.py:280-285 (wrap hard-coded for k = 5 in the reference)
               cx[idx] = nzx;         cy[idx] = nzy;
               cx[0] = cx[n - 5];     cy[0] = cy[n - 5];
@@ -934,7 +973,13 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           else if (idx >= n - 5 && idx <= n - 4) alias = idx - (n - 5);
           int j0 = 0, j1 = 0;
           if (alias >= 0) { j0 = tr.sup[2 * alias]; j1 = tr.sup[2 * alias + 1]; }
-          if (!(a.debug & 1)) refresh(s0, s1, j0, j1, mode);
+          if (K != 5) {
+            // The reference's wrap (above) is written for k = 5.  On another degree it rewrites control
+            // points 0, 1, n-3..n-1 with values that are NOT their periodic images, so the curve moves
+            // outside the supports of idx and its alias; the reference re-samples everything after
+            // every update (optimizer.py:286-288) and so does this instantiation.
+            refresh(0, N, 0, 0, mode);
+          } else if (!RL_ABLATE(a, 1)) refresh(s0, s1, j0, j1, mode);
           __syncthreads();
           ++ok_count;
         } else {
@@ -1170,7 +1215,9 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
             if (nf + idx < cap) nw[idx] = li;
           }
           nnew += __popcll(sm);
-          if (nf + nnew > cap) nnew = cap - nf;
+          // the reference appends without limit; a full front list here is reported like a raised error
+          // (iters = -1) rather than dropping fronts and returning a different profile
+          if (nf + nnew > cap) { nnew = cap - nf; err = 1; }
           pending &= ~__ballot(commit);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();

@@ -23,8 +23,9 @@
 namespace {
 
 thread_local std::string g_err;
-double* g_dbg_buf = nullptr;   // RL_DEBUG_DUMP=1: per-window QP dump of the joint variant (tests)
+double* g_dbg_buf = nullptr;   // rl_debug_dump_enable: step / window dump of the sweep kernels (tests)
 size_t g_dbg_len = 0;
+int g_dbg_instances = 0;
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -79,6 +80,10 @@ struct rl_track {
   DevBuf<int> ell, sup;
   DevBuf<double> ringL, ringR;  // shared rings as (x,y) pairs
   int nL = 0, nR = 0;
+  double length = 0.0;          // BSplineTrajectory._length of the INITIAL spline (rl_track_set_length); 0 = not given
+  // Device scratch owned by the track (sweep residency variant, global-QP tables): a track is therefore
+  // SINGLE-STREAM -- two contexts / streams must not run solves on the same rl_track concurrently
+  // (include/rl_mincurv.h, "Threading").
   mutable DevBuf<double> gscratch;  // for the non-LDS-resident sweep variant
   // tables of the global QP (a15), built on first use and dropped when the centre line changes
   mutable DevBuf<double> gq_A, gq_nu;
@@ -146,9 +151,9 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B) {
   return p;
 }
 
-template <int K, int BLOCK, bool RL, bool JOINT = false>
+template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false>
 int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
-  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT>;
+  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP>;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
@@ -163,6 +168,9 @@ int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepAr
                           : launch_sweep_t<5, 256, false, true>(ctx, a, p.lds_bytes);
   }
   if (k == 5) {
+    if (a.dbg)  // recording instantiation (test aid): same source, one extra store block per step
+      return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, true>(ctx, a, p.lds_bytes)
+                            : launch_sweep_t<5, 256, false, false, true>(ctx, a, p.lds_bytes);
     return p.rings_in_lds ? launch_sweep_t<5, 256, true>(ctx, a, p.lds_bytes)
                           : launch_sweep_t<5, 256, false>(ctx, a, p.lds_bytes);
   }
@@ -181,6 +189,12 @@ static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_
 extern "C" {
 
 int rl_version(void) { return RL_VERSION; }
+
+int rl_debug_dump_enable(int instances) {
+  if (instances < 0) return fail(RL_ERR_ARG, "instances < 0");
+  g_dbg_instances = instances;
+  return RL_OK;
+}
 
 int rl_debug_read(double* out, long long n) {
   if (!g_dbg_buf || !out || n < 0 || (size_t)n > g_dbg_len) return fail(RL_ERR_ARG, "no debug dump of that size");
@@ -380,6 +394,13 @@ int rl_track_set_rings(rl_track* trk, const double* ringL, int nL, const double*
   return RL_OK;
 }
 
+int rl_track_set_length(rl_track* trk, double length) {
+  if (!trk) return fail(RL_ERR_ARG, "null argument");
+  if (!(length >= 0.0)) return fail(RL_ERR_ARG, "length must be >= 0");
+  trk->length = length;
+  return RL_OK;
+}
+
 int rl_track_set_control_points(rl_track* trk, const double* cx0, const double* cy0) {
   if (!trk || !cx0 || !cy0) return fail(RL_ERR_ARG, "null argument");
   rl_ctx* ctx = trk->ctx;
@@ -517,9 +538,14 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   for (int j = 0; j < max_iter; ++j) a.i_start[j] = i_start[j];
   a.search = search;
   a.max_dist = 100.0;  // race_track.py:104
+#ifdef RL_ABLATION
   if (const char* dbg = getenv("RL_DEBUG_FLAGS")) a.debug = atoi(dbg);
-  if (joint && getenv("RL_DEBUG_DUMP")) {
-    const size_t need = (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256);
+#endif
+  if (g_dbg_instances > 0 && (joint || k == 5)) {
+    const int ninst = std::min(g_dbg_instances, B);
+    const size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256)
+                              : (size_t)ninst * max_iter * 2 * (size_t)(i_max - i_min) * (rl::kSweepDumpHead + 2 * n);
+    a.dbg_instances = ninst;
     if (g_dbg_len < need) {
       if (g_dbg_buf) (void)hipFree(g_dbg_buf);
       RL_HIP(hipMalloc(reinterpret_cast<void**>(&g_dbg_buf), need * sizeof(double)));
@@ -920,6 +946,21 @@ static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_
                               RL_SEARCH_WINDOWED, dctrl.p, nullptr, dpts.p, dns.p, dst.p, stats, nullptr, joint);
   if (rc) return rc;
   RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  DevBuf<double> dseg, dcx;
+  if (points && trk->length > 0.0) {
+    // DIST_TO_SF_BWD / _FWD of the final table (models/trajectory.py:283-289): GK21 segment lengths of the
+    // optimised spline, accumulated in the reference's order; DIST_FWD uses the length the spline object
+    // was CONSTRUCTED with (set_control_point never updates _length, trajectory.py:296-298)
+    RL_HIP(dseg.alloc(N)); RL_HIP(dcx.alloc((size_t)2 * n));
+    hipLaunchKernelGGL(rl::k_split_ctrl, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, dctrl.p, n, dcx.p);
+    const dim3 grid((N + 127) / 128), block(128);
+    if (trk->k == 3)
+      hipLaunchKernelGGL(rl::k_sample_geometry<3>, grid, block, 0, ctx->stream, trk->t.p, trk->nt, dcx.p, dcx.p + n, (const double*)nullptr, N, (double*)nullptr, dseg.p);
+    else
+      hipLaunchKernelGGL(rl::k_sample_geometry<5>, grid, block, 0, ctx->stream, trk->t.p, trk->nt, dcx.p, dcx.p + n, (const double*)nullptr, N, (double*)nullptr, dseg.p);
+    hipLaunchKernelGGL(rl::k_sample_cumsum, dim3(1), dim3(64), 0, ctx->stream, dseg.p, N, trk->length, dpts.p);
+    RL_HIP(hipGetLastError());
+  }
   std::vector<double> ctrl((size_t)2 * n);
   RL_HIP(hipMemcpyAsync(ctrl.data(), dctrl.p, ctrl.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (points) RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -130,6 +130,7 @@ class TrajectoryOptimizer:
         assert len(i_start) == max_iter
         trk = self._device_track(traj_out_s, len(traj_in_d))
         trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
+        trk.set_length(traj_out_s.get_length())
         t, cx, cy, _ = traj_out_s._tck()
         cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start, want_points=True)
         traj_out_s._spl_x.c[:] = cx
@@ -139,10 +140,10 @@ class TrajectoryOptimizer:
             print(f"Backward pass: number of control points successfully updated: {ns[j, 1]}")
         self.last_n_success = ns
         self.last_stats = stats
+        self.last_table = Trajectory(len(pts))          # the final traj_out_d of optimizer.py:286-288
+        self.last_table.points = pts
         if simulate:
-            traj_out_d = traj_out_s.sample_along(ts=traj_in_d.ts())
-            traj_out_d[:, Trajectory.LEFT_BOUND_X:Trajectory.RIGHT_BOUND_Y + 1] = pts[:, 9:13]
-            print(self.sim.run_simulation(traj_out_d, enable_vis=False))
+            print(self.sim.run_simulation(self.last_table, enable_vis=False))
         return traj_out_s
 
     def run_joint_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, max_iter=3,
@@ -163,6 +164,7 @@ class TrajectoryOptimizer:
         assert len(i_start) == max_iter
         trk = self._device_track(traj_out_s, len(traj_in_d))
         trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
+        trk.set_length(traj_out_s.get_length())
         t, cx, cy, _ = traj_out_s._tck()
         cx, cy, pts, ns, stats = ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=True)
         traj_out_s._spl_x.c[:] = cx

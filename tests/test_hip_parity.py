@@ -4,45 +4,23 @@ and against the CPU oracle on the same seeded inputs.  Need a real MI355X:  pyte
 Tolerance: north_star asks for <= 1e-4 m lateral deviation from the reference solution.  On the
 reference-generated Monza fixtures (G7) the HIP path is held to 1e-6 m (measured: 1e-9 .. 1e-12).
 
-Batches of perturbed instances are judged statistically, because the REFERENCE ALGORITHM ITSELF is
-not reproducible to 1e-4 m on every instance: it forms each constraint row as
-min(L,R) - (p - b*z_old) (optimizer.py:236-248) and the implied bound on z divides the ~1e-13 m
-rounding noise of the O(1e3) m coordinates by b, which is ~1e-10 for samples at the edge of a basis
-function's support.  Whenever such a row is the binding one (its sample sits within nanometres of
-its box edge, which earlier clamps produce routinely) the new control point carries up to ~1e-3 m of
-rounding noise.  Two IEEE-legal builds of the SAME oracle source (with / without FMA contraction)
-already disagree by up to 7e-4 m on ~10 % of such instances ("Conditioning").  The HIP path
-differs from the oracle in summation order, FMA contraction and ocml-vs-libm rounding, so the same
-fraction of instances lands on a different noise realisation."""
+Batches of perturbed instances are judged PER INSTANCE (tests/parity_rule.py): every instance must be
+within 1e-4 m of the oracle, unless the oracle itself certifies the instance as ill-conditioned --
+two IEEE-legal builds of the same oracle source (with / without FMA contraction) end more than
+1e-4 m apart on it -- in which case the HIP result must stay within 10x that spread.  Why such
+instances exist: the REFERENCE forms each constraint row as min(L,R) - (p - b*z_old)
+(optimizer.py:236-248) and the implied bound on z divides the ~1e-13 m rounding noise of the
+O(1e3) m coordinates by b, which is ~1e-10 for samples at the edge of a basis function's support
+("Conditioning").  The kernel's per-step logic is pinned independently of that noise by
+tests/test_sweep_replay.py (teacher-forced replay of every step against the oracle)."""
 import numpy as np
 import pytest
 
 from conftest import golden, spline
 from oracle import oracle as orc
+from parity_rule import NOISE_M, TIGHT_M, TOL_M, batch_parity, oracle_pair
 
 pytestmark = pytest.mark.gpu
-
-TOL_M = 1e-4       # north_star
-TIGHT_M = 1e-6     # what we hold on well-conditioned runs
-NOISE_M = 2e-2     # bound on a noise-driven deviation (rows with b ~ 1e-10: 1e-13/1e-10 * few steps)
-
-
-def batch_parity(xy, oxy, ns, ons, label=""):
-    """Per-instance max deviation [m] + the statistical acceptance described in the module docstring."""
-    B = xy.shape[0]
-    dev = np.abs(xy - oxy).reshape(B, -1).max(axis=1)
-    same = (ns.reshape(B, -1) == ons.reshape(B, -1)).all(axis=1)
-    q = np.sort(dev)
-    print(f"[parity {label}] B={B} median={np.median(dev):.2e} p90={q[int(0.9 * (B - 1))]:.2e} "
-          f"max={dev.max():.2e}  <=1e-6: {(dev <= TIGHT_M).mean():.0%}  <=1e-4: {(dev <= TOL_M).mean():.0%}  "
-          f"same n_success: {same.mean():.0%}")
-    assert np.median(dev) <= 1e-5
-    assert (dev <= TOL_M).mean() >= 0.6
-    # a flipped feasible/infeasible decision (also noise-driven) moves one control point by metres;
-    # everything else stays within the noise bound
-    assert (dev[same] <= NOISE_M).all()
-    assert same.mean() >= 0.6
-    return dev
 
 
 @pytest.fixture(scope="module")
@@ -219,6 +197,9 @@ def monza_like_widths(rl, fits, rings, tag, N, B, seed):
     return rl.batch.width_batch(wl, wr, B, seed=seed)
 
 
+_PAIR_CACHE = {}
+
+
 @pytest.mark.parametrize("search", [0, 1, 2])
 @pytest.mark.parametrize("tag,N,B,max_iter", [("c100", 200, 24, 2), ("c30", 333, 16, 1), ("c100", 500, 16, 2)])
 def test_batch_widths_vs_oracle(rl, fits, rings, tag, N, B, max_iter, search):
@@ -228,8 +209,10 @@ def test_batch_widths_vs_oracle(rl, fits, rings, tag, N, B, max_iter, search):
     i_start = rl.batch.default_i_start(len(cx), k, max_iter, seed=B)
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
     ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=search)
-    octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, length, N, widths, i_start, nthreads=8)
-    batch_parity(xy, oxy, ns, ons, f"{tag} N={N} it={max_iter} search={search}")
+    key = (tag, N, B, max_iter)
+    if key not in _PAIR_CACHE:
+        _PAIR_CACHE[key] = oracle_pair(t, cx, cy, k, length, N, widths, i_start)
+    batch_parity(xy, ns, _PAIR_CACHE[key], f"{tag} N={N} it={max_iter} search={search}")
     steps = 2 * max_iter * (len(cx) - 5)
     np.testing.assert_array_equal(status, steps - ns.reshape(B, -1).sum(axis=1))
 
@@ -286,45 +269,49 @@ def test_bound_points_form_matches_widths_form(rl, fits):
     pts[:, :, 0] = base[:, 0] + widths[:, :, 0] * nx; pts[:, :, 1] = base[:, 1] + widths[:, :, 0] * ny
     pts[:, :, 2] = base[:, 0] - widths[:, :, 1] * nx; pts[:, :, 3] = base[:, 1] - widths[:, :, 1] * ny
     b = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_POINTS, pts, i_start)
-    batch_parity(b[1], a[1], b[2], a[2], "bound-points form vs widths form")
+    pair = oracle_pair(t, cx, cy, k, length, N, widths, i_start)
+    batch_parity(a[1], a[2], pair, "widths form")
+    batch_parity(b[1], b[2], pair, "bound-points form (rings from numpy cos/sin) vs the widths-form oracle")
 
 
-def test_full_size_properties(rl, fits):
-    """BASELINE config 2 at full size (Monza N=2000, B=1024 is trimmed to 256 here for test time;
-    bench.py runs 1024): size-independent properties instead of an oracle run."""
+def test_full_size_properties(rl, fits, rings):
+    """BASELINE configs[1] AS BENCHED: Monza widths (real boundary rings), N=2000, B=1024 width-perturbed
+    instances (numpy default_rng(1234)), max_iter=5, sweep order of bench.py -- size-independent
+    properties on the whole batch, and the per-instance oracle rule on a sample of it."""
     t, cx, cy, k, length = spline(fits, "c100")
-    N, B, max_iter = 2000, 256, 1
+    N, B, max_iter = 2000, 1024, 5
     n = len(cx)
-    rng = np.random.default_rng(7)
-    wl = 4.0 + 2.0 * rng.random(N); wr = 4.0 + 2.0 * rng.random(N)
-    widths = rl.batch.width_batch(wl, wr, B, seed=1234)
-    widths[17] = widths[3]                       # duplicate instance
+    widths = monza_like_widths(rl, fits, rings, "c100", N, B, seed=1234)
     i_start = rl.batch.default_i_start(n, k, max_iter, seed=0)
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
     ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
-    print("N=2000 B=256 kernel ms:", st.kernel_ms, "lds:", st.lds_bytes, "rings_in_lds:", st.rings_in_lds)
+    print(f"N={N} B={B} it={max_iter} kernel ms:", st.kernel_ms, "lds:", st.lds_bytes, "rings_in_lds:", st.rings_in_lds)
     assert np.isfinite(ctrl).all() and np.isfinite(xy).all()
-    # (a) deterministic
+    # (a) deterministic, bit for bit
     ctrl2, xy2, ns2, _, _ = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
-    np.testing.assert_array_equal(ctrl, ctrl2); np.testing.assert_array_equal(xy, xy2)
-    # (b) instances are independent: duplicates agree bitwise, a permuted batch permutes the results
-    np.testing.assert_array_equal(ctrl[17], ctrl[3])
-    perm = rng.permutation(B)
-    ctrl3, xy3, _, _, _ = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths[perm], i_start)
-    np.testing.assert_array_equal(ctrl3, ctrl[perm])
+    np.testing.assert_array_equal(ctrl, ctrl2); np.testing.assert_array_equal(xy, xy2); np.testing.assert_array_equal(ns, ns2)
+    # (b) instances are independent: a permuted batch (with a duplicated instance) permutes the results
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(B); perm[17] = perm[3]
+    ctrl3, xy3, ns3, _, _ = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths[perm], i_start)
+    np.testing.assert_array_equal(ctrl3, ctrl[perm]); np.testing.assert_array_equal(ns3, ns[perm])
     # (c) periodic wrap (optimizer.py:281-285)
     np.testing.assert_array_equal(ctrl[:, 0], ctrl[:, n - 5]); np.testing.assert_array_equal(ctrl[:, 1], ctrl[:, n - 4])
     np.testing.assert_array_equal(ctrl[:, n - 3], ctrl[:, 2]); np.testing.assert_array_equal(ctrl[:, n - 1], ctrl[:, 4])
-    # (d) bookkeeping
+    # (d) bookkeeping: every one of the 2 * max_iter * (n - k) QPs is either counted as updated or as skipped
     np.testing.assert_array_equal(status, 2 * max_iter * (n - 5) - ns.reshape(B, -1).sum(axis=1))
-    # (e) out_xy is the optimised spline sampled on the grid
+    # (e) out_xy is the optimised spline sampled on the grid; the line moved and stayed near the track
     u = np.linspace(0.0, 1.0, N, endpoint=False)
-    for b in (0, 100, 255):
+    for b in (0, 100, 511, 1023):
         rx = orc.bspline_eval(t, ctrl[b, :, 0], k, u); ry = orc.bspline_eval(t, ctrl[b, :, 1], k, u)
         assert np.hypot(xy[b, :, 0] - rx, xy[b, :, 1] - ry).max() < 1e-9
-    # (f) eight full-size instances against the oracle (one per host core)
-    octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, length, N, widths[:8], i_start, nthreads=8)
-    batch_parity(xy[:8], oxy, ns[:8], ons, "N=2000 full size")
+    x0 = orc.bspline_eval(t, cx, k, u); y0 = orc.bspline_eval(t, cy, k, u)
+    move = np.hypot(xy[:, :, 0] - x0, xy[:, :, 1] - y0).max(axis=1)
+    assert move.min() > 0.5 and move.max() < 60.0, (move.min(), move.max())
+    # (f) the oracle rule, per instance, on a sample: the first 16 instances + 8 drawn at random
+    sample = np.r_[np.arange(16), np.sort(rng.choice(np.arange(16, B), 8, replace=False))]
+    pair = oracle_pair(t, cx, cy, k, length, N, widths[sample], i_start)
+    batch_parity(xy[sample], ns[sample], pair, f"configs[1] at full size, sample of {len(sample)}")
 
 
 def test_n4000_global_scratch_variant(rl, fits):
@@ -337,10 +324,27 @@ def test_n4000_global_scratch_variant(rl, fits):
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
     ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
     assert st.rings_in_lds == 0
-    octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, length, N, widths, i_start, nthreads=2)
-    dev = np.abs(xy - oxy).reshape(B, -1).max(axis=1)
-    print("N=4000 deviation per instance [m]:", dev)
-    assert dev.min() <= TIGHT_M and dev.max() <= NOISE_M
+    pair = oracle_pair(t, cx, cy, k, length, N, widths, i_start, nthreads=2)
+    batch_parity(xy, ns, pair, "N=4000")
+
+
+def test_degree3_sweep_vs_oracle(rl, fits):
+    """A degree-3 centre line through the same driver.  The reference's periodic wrap is written for
+    k = 5 (optimizer.py:281-285); on k = 3 it rewrites control points 0, 1, n-3..n-1 with values that are
+    not their periodic images.  Reproduced as is: the k = 3 instantiation re-samples the whole line
+    after every accepted update, like the reference does."""
+    t, cx, cy, k, length = spline(fits, "l10")
+    assert k == 3
+    n = len(cx)
+    for N, B, max_iter in ((300, 3, 1), (500, 2, 2)):
+        widths = rl.batch.width_batch(np.full(N, 4.0), np.full(N, 3.0), B, seed=5)
+        i_start = rl.batch.default_i_start(n, k, max_iter, seed=3)
+        trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+        ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
+        np.testing.assert_array_equal(status, 2 * max_iter * (n - k) - ns.reshape(B, -1).sum(axis=1))
+        pair = oracle_pair(t, cx, cy, k, length, N, widths, i_start, nthreads=B)
+        batch_parity(xy, ns, pair, f"k=3 N={N}")
+        assert ns.sum() > 0
 
 
 def test_argument_errors(rl, fits):
@@ -527,8 +531,8 @@ def test_mixed_batch_monza_and_oval(rl, fits, rings):
     for (ctrl, xy, ns, status), (tt, c0x, c0y, kk, ll), w, ist, name in (
             (res[0], (t, cx, cy, k, length), w_monza, i_starts[0], "monza"),
             (res[1], (ot, ocx, ocy, ok_, oval.get_length()), w_oval, i_starts[1], "oval")):
-        octrl, oxy, ons = orc.solve_width_batch(tt, c0x, c0y, kk, ll, N, w, ist, nthreads=8)
-        batch_parity(xy, oxy, ns, ons, f"config 3 / {name}")
+        pair = oracle_pair(tt, c0x, c0y, kk, ll, N, w, ist)
+        batch_parity(xy, ns, pair, f"config 3 / {name}")
         assert np.abs(ctrl - np.stack([c0x, c0y], axis=1)).max() > 0.5   # the lines moved
 
 
@@ -560,9 +564,12 @@ def test_joint_sweep_vs_oracle(rl, fits, rings):
         with orc.fma_variant():
             fcx, fcy, _, fns = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start)
         noise = np.hypot(ocx - fcx, ocy - fcy).max()
-        dev = np.hypot(hcx - ocx, hcy - ocy).max()
-        same = bool(np.array_equal(ns, ons) and dev < NOISE_M)
+        dev = min(np.hypot(hcx - ocx, hcy - ocy).max(), np.hypot(hcx - fcx, hcy - fcy).max())
+        same = bool((np.array_equal(ns, ons) or np.array_equal(ns, fns)) and dev <= TOL_M)
         agree += same
+        # the per-instance rule of tests/parity_rule.py: inside the tolerance, or certified chaotic by the
+        # oracle's own two roundings and then within 10x their spread
+        assert same or (noise > TOL_M and dev <= 10.0 * noise), (N, i_start, dev, noise)
         print(f"joint N={N} i_start={i_start}: windows HIP {ns.tolist()} oracle {ons.tolist()} oracle-fma {fns.tolist()}  "
               f"oracle re-rounding {noise:.1e} m  HIP-oracle {dev:.1e} m  {'AGREE' if same else 'other realisation'}  "
               f"kernel {st.kernel_ms:.2f} ms")
@@ -570,7 +577,7 @@ def test_joint_sweep_vs_oracle(rl, fits, rings):
         assert hcx[0] == hcx[n - 5] and hcx[1] == hcx[n - 4] and hcx[n - 3] == hcx[2] and hcx[n - 1] == hcx[4]
         assert 0 <= ns.min() and ns.max() <= n - 8 - 2        # windows per iteration: i_max - i_min
         assert np.hypot(hcx - cx, hcy - cy).max() > 0.5        # the line moved
-    assert agree >= 2, agree
+    print(f"joint driver: {agree} of {len(JOINT_CASES)} cases inside 1e-4 m with equal window counts")
 
 
 def test_joint_sweep_search_modes_and_api(rl, fits, rings, monkeypatch):
@@ -615,7 +622,7 @@ def test_joint_window_qps_replayed(rl, fits, rings, monkeypatch):
     This pins the GPU's QP logic (rows, zero-row verdict, dual active set) independently of where the
     chaotic trajectory goes."""
     import ctypes
-    monkeypatch.setenv("RL_DEBUG_DUMP", "1")
+    rl.lib.check(rl.lib.load().rl_debug_dump_enable(1))
     t, cx, cy, k, length = spline(fits, "c100")
     n = len(cx)
     nwin = (n - 3 - 5) - 2
@@ -654,6 +661,7 @@ def test_joint_window_qps_replayed(rl, fits, rings, monkeypatch):
                 n_inf += 1
         print(f"joint replay N={N}: {n_feas} windows accepted and re-solved identically, {n_inf} rejected consistently")
         assert n_feas == ns.sum() and n_feas > 0
+    rl.lib.check(rl.lib.load().rl_debug_dump_enable(0))
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):
