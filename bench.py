@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- min-curvature QP solves/sec at N=2000 waypoints on 1/2/4/8 MI355X.
 
-Workload (BASELINE.json configs[1]): Monza centre line
-(BSplineTrajectory s=100, k=5 -> 66 control points), N=2000 samples, B=1024 track instances PER GPU
-whose half-widths are the Monza half-widths scaled per instance by 1+e, e~U(-0.15,0.15)
-(numpy default_rng(1234 + rank)), floor 1.5 m.
+Workloads
+  monza (default; BASELINE.json configs[1]): Monza centre line
+      (BSplineTrajectory s=100, k=5 -> 66 control points), N=2000 samples, B=1024 track instances PER GPU
+      whose half-widths are the Monza half-widths scaled per instance by 1+e, e~U(-0.15,0.15)
+      (numpy default_rng(1234 + rank)), floor 1.5 m.
+  mixed (BASELINE.json configs[2]): per GPU half the batch Monza as above and
+      half the synthetic Indy-style oval (rotated 17 degrees, widths seed 5678 + rank), grouped by track:
+      two launches per step, on two streams, one per knot layout.
 
-One "solve" = the reference's complete TrajectoryOptimizer.run_min_curvature_qp for one instance
-(optimizer.py:256-341, max_iter=5 -> 5 x (forward + backward) sweeps over the 61 free control
-points = 610 control-point QPs, each followed by re-sampling and boundary re-intersection), sweep
-order pinned.  One "step" = one launch of the sweep kernel over the rank's whole batch, inputs
-already resident in HBM; for N>1 ranks every step is followed by the single gather of the results to
-rank 0, issued asynchronously (double-buffered outputs) so that it overlaps the next step's launch; the
-timed region ends only after the last gather has completed.
+UNIT OF WORK.  One "solve" = the reference's complete TrajectoryOptimizer.run_min_curvature_qp for one
+instance (optimizer.py:256-341, max_iter=5 -> 5 x (forward + backward) sweeps over the free control
+points = 610 control-point QPs on Monza, each followed by re-sampling and boundary re-intersection), sweep
+order pinned.  This is the path with reference parity, which is why it is the headline; SURVEY.md 8(d)'s
+other unit (one global banded QP per linearisation, the north_star's design kernel, own formulation)
+is reported as a second top-level leg, `global_qp`, with its own roofline block.
+One "step" = one launch of the sweep kernel over the rank's whole batch, inputs already resident in
+HBM; for N>1 ranks every step is followed by the single gather of the results to rank 0, issued
+asynchronously (double-buffered outputs) so that it overlaps the next step's launch; the timed region
+ends only after the last gather has completed.
+
+`python bench.py --gpus N` starts its own N rank processes (children, spawned before anything touches
+the GPU); under torch.distributed.run (WORLD_SIZE already set) it is one of the ranks.
 
 Prints ONE JSON line (rank 0).  See the repo instructions for the field contract.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,35 +41,112 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_GFLOPS = 78600.0  # 256 CU x 4 SIMD x 16 FP64 lanes/clk x 2 (FMA) x 2.4 GHz
 N_WAYPOINTS = 2000
 BATCH_PER_GPU = 1024
 MAX_ITER = 5            # run_min_curvature_qp default (optimizer.py:256)
 SPLINE_S, SPLINE_K = 100.0, 5
 BYTES_PER_SOLVE = 8 * N_WAYPOINTS * (2 + 2)  # widths in (2 cols) + x,y out (2 cols)
-
-
-def cpu_baseline(t, cx, cy, k, length, widths, i_start, budget_instances):
-    """The oracle (a port of the reference's arithmetic, oracle/mincurv_oracle.c) timed on a bounded
-    sample of the same workload: `budget_instances` instances, one per host thread."""
-    from oracle import oracle as orc
-    cores = max(1, min(os.cpu_count() or 1, budget_instances))
-    sample = np.ascontiguousarray(widths[:budget_instances])
-    t0 = time.perf_counter()
-    ctrl, xy, ns = orc.solve_width_batch(t, cx, cy, k, length, N_WAYPOINTS, sample, i_start, nthreads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": budget_instances / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"{budget_instances} of the {BATCH_PER_GPU} instances (Monza N={N_WAYPOINTS}, "
-                      f"max_iter={MAX_ITER}), one per thread, {dt:.1f} s wall"}, xy
-
-
 GLOBAL_MARGIN, GLOBAL_OUTER = 0.25, 6
 
 
-def global_qp_leg(trk, d_widths, widths, t, cx, cy, k, args, torch, with_cpu):
-    """Secondary measurement, outside the timed region of the headline metric: the same batch through
-    the global banded QP (own formulation; rl_mincurv_global_batch_dev).  One
-    launch = B instances x GLOBAL_OUTER Gauss-Newton linearisations, each one inequality-constrained
-    QP (2N bound rows, n-k unknowns) solved by the interior-point kernel."""
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes as CHILDREN (this parent
+    never initialises the GPU and never execs), wait for them, pass rank 0's JSON line through."""
+    import __graft_entry__ as ge
+    ge.build_hip()  # hipcc only; the children then find the library up to date and never race on it
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 3000
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is not None:
+                alive.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in alive:      # a rank failed: end exactly the processes started here
+                        q.terminate()
+        if time.time() > deadline:
+            for q in alive:
+                q.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.2)
+    sys.exit(rc)
+
+
+# ------------------------------------------------------------------------------------------------
+def profile_block(kernel):
+    """Counter-derived figures of `kernel` from the committed rocprofv3 summary (profiles/): NOT measured in
+    this run -- PMC collection needs its own rocprofv3 passes (tools/profile_bench.sh)."""
+    path = os.path.join(ROOT, "profiles", "counters_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        k = d["kernels"][kernel]
+    except Exception:
+        return None
+    k = dict(k)
+    k["source"] = d.get("source", "profiles/counters_latest.json")
+    k["measured_in_run"] = False
+    return k
+
+
+def cpu_legs(groups, i_starts, xy_gpu, ninst_total):
+    """cpu_baseline: the oracle (a port of the reference's arithmetic, oracle/mincurv_oracle.c) timed on a
+    bounded sample of the same workload, one instance per host thread; then the per-instance parity rule
+    of tests/parity_rule.py on that sample (strict oracle vs its re-roundings)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_rule
+    per = max(1, ninst_total // len(groups))
+    cores = max(1, min(os.cpu_count() or 1, per))
+    t_wall, done, cls = 0.0, 0, []
+    for g, ist, xy in zip(groups, i_starts, xy_gpu):
+        po = parity_rule.ParityOracle(g["t"], g["cx"], g["cy"], g["k"], g["length"], N_WAYPOINTS, g["widths"][:per], ist,
+                                      n_seeds=2, nthreads=cores)
+        t_wall += po.t_strict          # the timed leg: the strict oracle only
+        done += per
+        cls.append(parity_rule.classify(xy[:per], po))
+    c = {k_: np.concatenate([x[k_] for x in cls]) for k_ in cls[0]}
+    probe = {}
+    for mod in ("casadi", "shapely"):
+        try:
+            __import__(mod)
+            probe[mod] = True
+        except Exception:
+            probe[mod] = False
+    gv = parity_rule.summary(c)
+    gv["rule"] = ("per instance: dev = max|GPU - strict oracle| <= 1e-4 m, or the oracle's own re-roundings (FMA "
+                  "contraction; +-1 ulp on sampled positions / bound points) spread by > 1e-4 m on that instance and "
+                  "dev <= 10x that spread (tests/parity_rule.py)")
+    cb = {"value": done / t_wall, "unit": "solves/s", "cores": cores, "kind": "port",
+          "sample": f"{done} of the batch's instances (N={N_WAYPOINTS}, max_iter={MAX_ITER}), one per thread, "
+                    f"{t_wall:.1f} s wall",
+          "reference_path_probe": dict(probe, note="the reference's own CasADi/qpOASES + shapely path needs both "
+                                       "modules and the reference tree; neither is on this box, so kind stays 'port'"),
+          "gpu_vs_oracle": gv}
+    assert gv["failing"] == 0 and gv["within_1e-4"] + gv["certified_ill_conditioned"] == done, \
+        f"GPU results deviate from the oracle: {gv}"
+    return cb
+
+
+def global_qp_leg(trk, d_widths, g, args, torch, with_cpu):
+    """Second leg (SURVEY.md 8(d) primary unit; 8a row a15, own formulation): the Monza batch through the
+    global banded QP (rl_mincurv_global_batch_dev).  One launch = B instances x GLOBAL_OUTER Gauss-Newton
+    linearisations, each one inequality-constrained QP (2N bound rows, n-k unknowns) solved by the
+    interior-point kernel; timed with HIP events on the launch stream, outside the headline's region."""
     from spline_trajectory_optimization_amd import ops
     out = ops.global_batch_torch(trk, d_widths, GLOBAL_MARGIN, GLOBAL_OUTER)
     torch.cuda.synchronize()
@@ -69,14 +158,25 @@ def global_qp_leg(trk, d_widths, widths, t, cx, cy, k, args, torch, with_cpu):
     torch.cuda.synchronize()
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     st = out["stats"].cpu().numpy()
-    B = widths.shape[0]
+    B = d_widths.shape[0]
     assert np.isfinite(st).all() and (st[:, 3] <= 1e-8).all(), "global QP: a line left its bounds"
-    leg = {"kernel_ms": ms, "instances_per_s": B / ms * 1e3, "qp_solves_per_s": B * GLOBAL_OUTER / ms * 1e3,
-           "linearisations": GLOBAL_OUTER, "ipm_iterations_mean": float(st[:, 0].mean()),
+    achieved = BYTES_PER_SOLVE * B / (ms * 1e-3) / 1e9
+    prof = profile_block("k_global_qp")
+    leg = {"metric": "global min-curvature QPs/sec (N=2000, one QP = one Gauss-Newton linearisation of the "
+                     "whole line, 2N bound rows)",
+           "value": B * GLOBAL_OUTER / ms * 1e3, "unit": "QPs/s", "instances_per_s": B / ms * 1e3,
+           "kernel_ms": ms, "linearisations": GLOBAL_OUTER, "ipm_iterations_mean": float(st[:, 0].mean()),
            "sum_kappa2_before_after": [float(st[:, 1].mean()), float(st[:, 2].mean())],
            "max_bound_violation_m": float(st[:, 3].max()), "block_threads": int(out["rl_stats"].block_threads),
            "lds_bytes_per_workgroup": int(out["rl_stats"].lds_bytes),
-           "hbm_GBps_algorithmic": BYTES_PER_SOLVE * B / (ms * 1e-3) / 1e9}
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": prof.get("hbm_bytes_fetch_x2") if prof else None,
+                        "traffic_source": prof.get("source") if prof else None, "traffic_measured_in_run": False,
+                        "kernel": "k_global_qp2", "kernel_ms": ms,
+                        "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
+                        "actual_limiter": "FP64 VALU issue of the factorising wave + barriers (DESIGN.md 3b)",
+                        "valu": valu_block(prof, ms)}}
     if with_cpu:
         from oracle import oracle as orc
         ninst = 4
@@ -84,7 +184,8 @@ def global_qp_leg(trk, d_widths, widths, t, cx, cy, k, args, torch, with_cpu):
         dev_m = 0.0
         xy = out["xy"][:ninst].cpu().numpy()
         for b in range(ninst):
-            r = orc.global_mincurv(t, cx, cy, k, N_WAYPOINTS, widths[b, :, 0], widths[b, :, 1], GLOBAL_MARGIN, GLOBAL_OUTER)
+            r = orc.global_mincurv(g["t"], g["cx"], g["cy"], g["k"], N_WAYPOINTS, g["widths"][b, :, 0],
+                                   g["widths"][b, :, 1], GLOBAL_MARGIN, GLOBAL_OUTER)
             dev_m = max(dev_m, float(np.abs(r[2] - xy[b]).max()))
         dt = time.perf_counter() - t0
         assert dev_m < 1e-6, f"global QP deviates from its CPU twin: {dev_m}"
@@ -93,30 +194,42 @@ def global_qp_leg(trk, d_widths, widths, t, cx, cy, k, args, torch, with_cpu):
     return leg
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
-    ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-global", action="store_true", help="skip the secondary global-QP measurement")
-    ap.add_argument("--cpu-instances", type=int, default=8)
-    ap.add_argument("--share-gpu", action="store_true",
-                    help="TEST HOOK: all ranks use cuda:0 and the gloo backend (exercises the N>1 code path "
-                         "on a single-GPU box; the numbers are meaningless)")
-    args = ap.parse_args()
+def valu_block(prof, kernel_ms):
+    """FP64 VALU view of a kernel from the committed counters + this run's kernel time.
+      valu_active_frac = SQ_ACTIVE_INST_VALU [quad-cycles] x 4 / (1024 SIMDs x kernel cycles), kernel cycles =
+                         SQ_BUSY_CYCLES / 8 XCDs... taken as clock_ghz x kernel time (clock_ghz from
+                         GRBM_GUI_ACTIVE / 8 / time of the profiled run)
+      fp64_gflops      = 64 lanes x (ADD_F64 + MUL_F64 + TRANS_F64 + 2 x FMA_F64 wave-instructions) / kernel time
+    (wave-instruction counts x 64 lanes: partially masked instructions count as full, an upper bound)."""
+    if not prof or "counters_per_launch" not in prof:
+        return None
+    c = prof["counters_per_launch"]
+    out = {"source": prof.get("source"), "measured_in_run": False}
+    clock = prof.get("clock_ghz")
+    if clock and "SQ_ACTIVE_INST_VALU" in c:
+        cycles = clock * 1e9 * prof["avg_ms"] * 1e-3
+        out["valu_active_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles)
+        out["clock_ghz"] = clock
+    if "SQ_INSTS_VALU" in c:
+        out["valu_wave_insts_per_launch"] = c["SQ_INSTS_VALU"]
+    f64 = [c.get(k) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_FMA_F64")]
+    if all(v is not None for v in f64):
+        flops = 64.0 * (f64[0] + f64[1] + f64[2] + 2.0 * f64[3])
+        out["fp64_gflops"] = flops / (kernel_ms * 1e-3) / 1e9
+        out["fp64_frac_of_vector_peak"] = out["fp64_gflops"] / FP64_VECTOR_PEAK_GFLOPS
+        out["fp64_flops_per_launch"] = flops
+    return out
 
+
+# ------------------------------------------------------------------------------------------------
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
     if args.share_gpu:
@@ -138,56 +251,81 @@ def main():
     from spline_trajectory_optimization_amd import _lib, batch, ops
     from spline_trajectory_optimization_amd.models.race_track import RaceTrack
 
-    # ---- set-up (untimed): Monza track, base half-widths, per-instance widths resident in HBM
+    # ---- set-up (untimed): tracks, base half-widths, per-instance widths resident in HBM
     _lib.set_default_device(local_rank)  # one process per GPU
     ctx = _lib.Context.get()
+    B = args.batch
+    groups = []
     centre, left, right = batch.load_monza()
     line = batch.monza_centerline(SPLINE_S, SPLINE_K)
     t, cx, cy, k = line._tck()
-    n = len(cx)
     track_geo = RaceTrack("Monza", left, right, centre)
     traj = line.sample_along(ts=np.linspace(0.0, 1.0, N_WAYPOINTS, endpoint=False))
     track_geo.fill_trajectory_boundaries(traj)
     wl, wr = batch.half_widths_from_bounds(traj.points)
-    B = args.batch
-    widths = batch.width_batch(wl, wr, B, seed=1234 + rank)
-    i_start = batch.default_i_start(n, k, MAX_ITER, seed=0)
-    trk = _lib.Track(ctx, t, cx, cy, k, N_WAYPOINTS)
-    d_widths = torch.from_numpy(widths).to(dev)
+    b_monza = B if args.workload == "monza" else B - B // 2
+    groups.append({"name": "monza", "t": t, "cx": cx, "cy": cy, "k": k, "length": line.get_length(),
+                   "widths": batch.width_batch(wl, wr, b_monza, seed=1234 + rank)})
+    if args.workload == "mixed":
+        oval = batch.oval_centerline(SPLINE_S, SPLINE_K)
+        ot, ocx, ocy, ok_ = oval._tck()
+        owl, owr = batch.oval_half_widths(N_WAYPOINTS)
+        groups.append({"name": "oval", "t": ot, "cx": ocx, "cy": ocy, "k": ok_, "length": oval.get_length(),
+                       "widths": batch.width_batch(owl, owr, B // 2, seed=5678 + rank)})
     search = {"windowed": _lib.SEARCH_WINDOWED, "culled": _lib.SEARCH_CULLED, "brute": _lib.SEARCH_BRUTE}[args.search]
-    out = ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in groups[1:]]
+    for g in groups:
+        g["n"] = len(g["cx"])
+        g["i_start"] = batch.default_i_start(g["n"], g["k"], MAX_ITER, seed=0)
+        g["trk"] = _lib.Track(ctx, g["t"], g["cx"], g["cy"], g["k"], N_WAYPOINTS)
+        g["d_widths"] = torch.from_numpy(g["widths"]).to(dev)
+        g["out"] = [ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search)]
     torch.cuda.synchronize()
-    stats = out["stats"]
+    stats = groups[0]["out"][0]["stats"]
 
     # N > 1: the gather of step s runs on the process group's stream while step s+1 computes into the
     # other output set (double buffering); a buffer is reused only after its gather has completed.
-    outs = [out, None]
     gathered = None
     if world > 1:
-        outs[1] = {kk: (vv.clone() if hasattr(vv, "clone") else vv) for kk, vv in out.items()}
+        for g in groups:
+            g["out"].append({kk: (vv.clone() if hasattr(vv, "clone") else vv) for kk, vv in g["out"][0].items()})
         if rank == 0:
-            gathered = [torch.empty((world * B,) + tuple(out["xy"].shape[1:]), dtype=torch.float64, device=dev)
-                        for _ in range(2)]
-    works = [None, None]
+            gathered = [[torch.empty((world * g["widths"].shape[0],) + tuple(g["out"][0]["xy"].shape[1:]),
+                                     dtype=torch.float64, device=dev) for g in groups] for _ in range(2)]
+    works = [[], []]
+    main_stream = streams[0]
 
     def step(s, events=None):
         slot = s & 1 if world > 1 else 0
-        if works[slot] is not None:
-            works[slot].wait()          # stream-level wait: the buffer's previous gather is done
+        for w in works[slot]:
+            w.wait()                # stream-level wait: the buffer's previous gather is done
+        works[slot] = []
         if events is not None:
-            events[0].record()
-        ops.solve_batch_torch(trk, _lib.BOUNDS_WIDTHS, d_widths, i_start, search=search, out=outs[slot])
+            events[0].record(main_stream)
+        fork = torch.cuda.Event()
+        fork.record(main_stream)
+        for g, st in zip(groups, streams):
+            if st is not main_stream:
+                st.wait_event(fork)
+            with torch.cuda.stream(st):
+                ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search,
+                                      out=g["out"][slot])
+            if st is not main_stream:
+                join = torch.cuda.Event()
+                join.record(st)
+                main_stream.wait_event(join)
         if events is not None:
-            events[1].record()          # kernel-only span on the launch stream (torch's current stream)
+            events[1].record(main_stream)   # kernel-only span on the launch stream(s)
         if world > 1:
-            works[slot] = batch.gather_to_root(outs[slot]["xy"], rank, world, dist,
-                                               out=gathered[slot] if rank == 0 else None, async_op=True)
+            for gi, g in enumerate(groups):
+                works[slot].append(batch.gather_to_root(g["out"][slot]["xy"], rank, world, dist,
+                                                        out=gathered[slot][gi] if rank == 0 else None, async_op=True))
 
     def drain():
         for q in range(2):
-            if works[q] is not None:
-                works[q].wait()
-                works[q] = None
+            for w in works[q]:
+                w.wait()
+            works[q] = []
 
     for w_ in range(args.warmup):
         step(w_)
@@ -212,28 +350,32 @@ def main():
         elapsed = float(tmax.item())
 
     # sanity outside the timed region: results are finite and the bookkeeping is consistent
-    last = outs[(args.steps - 1) & 1] if world > 1 else out
-    status = last["status"].cpu().numpy()
-    ns = last["n_success"].cpu().numpy()
-    xy = last["xy"].cpu().numpy()
-    if world > 1 and rank == 0:  # rank 0's own shard came back through the collective unchanged
-        assert torch.equal(gathered[(args.steps - 1) & 1][:B], last["xy"])
-    if os.environ.get('RL_DEBUG_FLAGS', '0') == '0':
+    last_slot = (args.steps - 1) & 1 if world > 1 else 0
+    xy_gpu, ns_gpu = [], []
+    for gi, g in enumerate(groups):
+        last = g["out"][last_slot]
+        status = last["status"].cpu().numpy()
+        ns = last["n_success"].cpu().numpy()
+        xy = last["xy"].cpu().numpy()
+        bg = g["widths"].shape[0]
+        if world > 1 and rank == 0:  # rank 0's own shard came back through the collective unchanged
+            assert torch.equal(gathered[last_slot][gi][:bg], last["xy"])
         assert np.isfinite(xy).all()
-    assert os.environ.get('RL_DEBUG_FLAGS', '0') != '0' or np.array_equal(status, 2 * MAX_ITER * (n - 5) - ns.reshape(B, -1).sum(axis=1))
+        assert np.array_equal(status, 2 * MAX_ITER * (g["n"] - g["k"]) - ns.reshape(bg, -1).sum(axis=1))
+        xy_gpu.append(xy); ns_gpu.append(ns)
 
     if rank == 0:
         total_solves = world * B * args.steps
         value = total_solves / elapsed
-        qp_per_solve = 2 * MAX_ITER * (n - 5)
+        qp_per_solve = [2 * MAX_ITER * (g["n"] - g["k"]) for g in groups]
+        qps_per_step = sum(q * g["widths"].shape[0] for q, g in zip(qp_per_solve, groups))
         achieved = (BYTES_PER_SOLVE * B) / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        prof = profile_block("k_sweep") if args.workload == "monza" else None
+        wl_text = (f"Monza N={N_WAYPOINTS}, batch={B} width-perturbed instances per GPU (BASELINE configs[1])"
+                   if args.workload == "monza" else
+                   f"mixed: {groups[0]['widths'].shape[0]} Monza + {groups[1]['widths'].shape[0]} rotated-oval "
+                   f"width-perturbed instances per GPU, N={N_WAYPOINTS}, grouped by track, two concurrent launches "
+                   f"per step (BASELINE configs[2])")
         res = {
             "metric": "min-curvature QP solves/sec (N=2000 waypoints)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -241,37 +383,56 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"Monza N={N_WAYPOINTS}, batch={B} width-perturbed instances per GPU "
-                            f"(BASELINE configs[1]); one solve = full run_min_curvature_qp, "
-                            f"max_iter={MAX_ITER}, {qp_per_solve} control-point QPs, sweep order pinned",
-                "spline": f"s={SPLINE_S:g} k={SPLINE_K} n={n}", "batch_per_gpu": B,
-                "control_point_qps_per_s": value * qp_per_solve, "search": args.search,
+                "workload": wl_text + f"; UNIT: one solve = one instance's full run_min_curvature_qp "
+                            f"(optimizer.py:256-341), max_iter={MAX_ITER}, {qp_per_solve} control-point QPs per "
+                            f"solve, sweep order pinned -- the reference-parity path; the north_star's global "
+                            f"banded QP is the separate `global_qp` leg",
+                "spline": f"s={SPLINE_S:g} k={SPLINE_K} n={[g['n'] for g in groups]}", "batch_per_gpu": B,
+                "control_point_qps_per_s": qps_per_step * world * args.steps / elapsed, "search": args.search,
                 "parallelism": f"{world} rank(s) x independent instances"
-                               + (", 1 RCCL gather to rank 0 per step (overlapped with the next step)" if world > 1 else ""),
+                               + (f", 1 gather to rank 0 per step and group over {'gloo (test hook)' if args.share_gpu else 'RCCL'}"
+                                  f" (overlapped with the next step), world size {dist.get_world_size()}" if world > 1 else ""),
                 "lds_bytes_per_workgroup": int(stats.lds_bytes), "block_threads": int(stats.block_threads),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": prof.get("hbm_bytes_fetch_x2") if prof else None,
+                         "traffic_source": prof.get("source") if prof else None, "traffic_measured_in_run": False,
                          "kernel": "k_sweep", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B},
+                         "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
+                         "actual_limiter": "FP64 VALU instruction issue (state is on-chip; the HBM roofline is the "
+                                           "one north_star designates, the kernel is not HBM bound)",
+                         "valu": valu_block(prof, kernel_ms)},
         }
-        if world == 1 and not args.no_global:
-            res["config"]["global_qp"] = global_qp_leg(trk, d_widths, widths, t, cx, cy, k, args, torch,
-                                                      with_cpu=not args.no_cpu_baseline)
+        if world == 1 and args.workload == "monza" and not args.no_global:
+            res["global_qp"] = global_qp_leg(groups[0]["trk"], groups[0]["d_widths"], groups[0], args, torch,
+                                             with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
-            ninst = min(args.cpu_instances, B)
-            cb, oxy = cpu_baseline(t, cx, cy, k, line.get_length(), widths, i_start, ninst)
-            # per-instance deviation of the GPU result from the oracle; see tests/test_hip_parity.py on
-            # why a minority of instances sits on a different rounding-noise realisation
-            dev_m = np.abs(oxy - xy[:ninst]).reshape(ninst, -1).max(axis=1)
-            cb["gpu_vs_oracle_dev_m"] = {"median": float(np.median(dev_m)), "max": float(dev_m.max()),
-                                         "within_1e-4": int((dev_m <= 1e-4).sum()), "of": ninst}
-            assert np.median(dev_m) < 1e-4, f"GPU results deviate from the oracle: {dev_m}"
-            res["cpu_baseline"] = cb
+            res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
+    ap.add_argument("--workload", choices=["monza", "mixed"], default="monza")
+    ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-global", action="store_true", help="skip the global-QP leg")
+    ap.add_argument("--cpu-instances", type=int, default=8)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST HOOK: all ranks use cuda:0 and the gloo backend (exercises the N>1 code path "
+                         "on a single-GPU box; the numbers are meaningless)")
+    args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)   # never returns
+    run_rank(args)
 
 
 if __name__ == "__main__":

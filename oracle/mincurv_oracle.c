@@ -23,6 +23,24 @@
 
 #define ORC_MAXK 7
 
+/* ---------------------------------------------------------------- re-rounding (test diagnostics)
+ * Monte-Carlo arithmetic in miniature: with a non-zero seed the sampled positions, headings and bound
+ * points -- the quantities whose last bits the reference's constraint rows amplify by 1/b (DESIGN.md
+ * "Conditioning") -- are moved by -1, 0 or +1 ulp, pseudo-randomly but reproducibly.  Every such run is
+ * as legitimate a rounding of the reference's arithmetic as the unperturbed one (another summation
+ * order, another libm); the spread between runs measures how well the reference's own formulation
+ * defines the answer on a given instance.  Seed 0 (the default) changes nothing. */
+static _Thread_local unsigned long long g_rr_state = 0ULL;
+void orc_set_rerounding(unsigned long long seed) {
+  g_rr_state = seed ? (seed * 0x9E3779B97F4A7C15ULL) | 1ULL : 0ULL;
+}
+static inline double rr(double v) {
+  if (g_rr_state == 0ULL) return v;
+  g_rr_state ^= g_rr_state << 13; g_rr_state ^= g_rr_state >> 7; g_rr_state ^= g_rr_state << 17;
+  unsigned r = (unsigned)((g_rr_state >> 32) % 3ULL);
+  return r == 0 ? v : nextafter(v, r == 1 ? INFINITY : -INFINITY);
+}
+
 /* ---------------------------------------------------------------- B-spline kernels */
 
 /* scipy find_interval: largest l in [k, n-1] with t[l] <= x, clamped (extrapolate=True). */
@@ -194,9 +212,9 @@ static void sample_geometry(const double* t, int nt, const double* cx, const dou
   orc_bspline_eval(t, nt, cy, k, u, N, 2, d2y);
   for (int i = 0; i < N; ++i) {
     double* p = points + (size_t)i * ORC_NCOL;
-    p[ORC_X] = x[i];
-    p[ORC_Y] = y[i];
-    p[ORC_YAW] = atan2(dy[i], dx[i]);
+    p[ORC_X] = rr(x[i]);
+    p[ORC_Y] = rr(y[i]);
+    p[ORC_YAW] = rr(atan2(dy[i], dx[i]));
     /* __get_turn_radius, trajectory.py:253-260 */
     double s2 = dx[i] * dx[i] + dy[i] * dy[i];
     double curvature = fabs(dx[i] * d2y[i] - dy[i] * d2x[i]) / sqrt(s2 * s2 * s2);
@@ -247,7 +265,7 @@ static void closest_hit(double px, double py, double yaw_norm, double max_dist,
     if (as > 1.0) continue; /* beyond +-max_dist */
     if (as < best) { best = as; best_s = s; found = 1; }
   }
-  if (found) { *bx = px + best_s * dx; *by = py + best_s * dy; }
+  if (found) { *bx = rr(px + best_s * dx); *by = rr(py + best_s * dy); }
   else { *bx = px; *by = py; }
 }
 
@@ -499,6 +517,16 @@ void orc_solve_width_batch(const double* t, int nt, const double* cx0, const dou
                            const int* i_start, int max_iter,
                            double* out_ctrl, double* out_xy, int* n_success, int nthreads,
                            double* kappa) {
+  orc_solve_width_batch_seeded(t, nt, cx0, cy0, k, length, N, widths, B, i_start, max_iter, out_ctrl, out_xy,
+                               n_success, nthreads, kappa, NULL);
+}
+
+/* seeds[B] (may be NULL): re-rounding seed of each instance (orc_set_rerounding), 0 = unperturbed */
+void orc_solve_width_batch_seeded(const double* t, int nt, const double* cx0, const double* cy0, int k,
+                                  double length, int N, const double* widths, int B,
+                                  const int* i_start, int max_iter,
+                                  double* out_ctrl, double* out_xy, int* n_success, int nthreads,
+                                  double* kappa, const unsigned long long* seeds) {
   int n = nt - k - 1;
   /* shared initial line: p0_i, yaw0_i */
   double* base = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
@@ -528,8 +556,10 @@ void orc_solve_width_batch(const double* t, int nt, const double* cx0, const dou
     double* pts = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
     orc_trajectory_init(pts, N);
     orc_reset_kappa();
+    orc_set_rerounding(seeds ? seeds[b] : 0ULL);   /* the rings above are built unperturbed */
     orc_run_min_curvature_qp(t, nt, cx, cy, k, length, pts, N, ringL, N, ringR, N, i_start,
                              max_iter, n_success + (size_t)b * 2 * max_iter);
+    orc_set_rerounding(0ULL);
     if (kappa) kappa[b] = orc_last_kappa();
     for (int j = 0; j < n; ++j) {
       out_ctrl[((size_t)b * n + j) * 2] = cx[j];

@@ -141,6 +141,14 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
 double orc_last_kappa(void);
 void orc_reset_kappa(void);
 
+/* Re-rounding diagnostics (see the comment block in mincurv_oracle.c): thread-local seed, 0 = off. */
+void orc_set_rerounding(unsigned long long seed);
+void orc_solve_width_batch_seeded(const double* t, int nt, const double* cx0, const double* cy0, int k,
+                                  double length, int N, const double* widths, int B,
+                                  const int* i_start, int max_iter,
+                                  double* out_ctrl, double* out_xy, int* n_success, int nthreads,
+                                  double* kappa, const unsigned long long* seeds);
+
 /* Teacher-forced replay of recorded sweep steps (see the comment block in mincurv_oracle.c). */
 #define ORC_REPLAY_STRIDE 20
 void orc_width_rings(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,

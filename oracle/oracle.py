@@ -180,8 +180,9 @@ def last_kappa():
 
 
 def solve_width_batch(t, cx0, cy0, k, length, N, widths, i_start, max_iter=None, nthreads=1,
-                      want_kappa=False):
-    """widths [B,N,2] -> (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2][, kappa [B]])."""
+                      want_kappa=False, seeds=None):
+    """widths [B,N,2] -> (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2][, kappa [B]]).
+    seeds [B] (optional): re-rounding seed per instance (mincurv_oracle.c: orc_set_rerounding), 0 = none."""
     t, tp = _d(t); cx0, xp = _d(cx0); cy0, yp = _d(cy0); widths, wp = _d(widths)
     i_start, ip = _i(i_start)
     max_iter = len(i_start) if max_iter is None else max_iter
@@ -190,9 +191,17 @@ def solve_width_batch(t, cx0, cy0, k, length, N, widths, i_start, max_iter=None,
     ctrl = np.zeros((B, n, 2)); xy = np.zeros((B, N, 2))
     ns = np.zeros((B, max_iter, 2), dtype=np.int32)
     kappa = np.zeros(B)
-    lib().orc_solve_width_batch(tp, len(t), xp, yp, int(k), float(length), int(N), wp, B, ip,
-                                int(max_iter), ctrl.ctypes.data_as(_dp), xy.ctypes.data_as(_dp),
-                                ns.ctypes.data_as(_ip), int(nthreads), kappa.ctypes.data_as(_dp))
+    f = lib().orc_solve_width_batch_seeded
+    f.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, _dp,
+                  ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _ip, ctypes.c_int, _dp, ctypes.c_void_p]
+    f.restype = None
+    sd = None
+    if seeds is not None:
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert sd.shape == (B,)
+    f(tp, len(t), xp, yp, int(k), float(length), int(N), wp, B, ip, int(max_iter), ctrl.ctypes.data_as(_dp),
+      xy.ctypes.data_as(_dp), ns.ctypes.data_as(_ip), int(nthreads), kappa.ctypes.data_as(_dp),
+      sd.ctypes.data if sd is not None else None)
     if want_kappa:
         return ctrl, xy, ns, kappa
     return ctrl, xy, ns

@@ -69,6 +69,7 @@ def install_shims():
     casadi.DM = DM
     casadi.conic = conic
     casadi.__all__ = ["DM", "conic"]
+    install_numeric_casadi(casadi)
     sys.modules["casadi"] = casadi
     sys.modules["importlib_resources"] = types.ModuleType("importlib_resources")
     sys.modules["importlib_resources"].files = lambda *a, **k: None
@@ -78,6 +79,114 @@ def install_shims():
 
 class Infeasible(Exception):
     pass
+
+
+# --------------------------------------------------------------------------- numeric casadi stand-in (G8)
+class M:
+    """A numeric matrix with the slice of casadi.MX's surface that models/double_track.py,
+    utils/utils.py and min_time_optm/min_time_optimizer.py touch: 2-D, casadi-style indexing (a single
+    integer is a linear index), element-wise arithmetic, .T, and comparisons that RECORD a constraint
+    instead of evaluating to a boolean.  With it the reference's own expression-building code runs on
+    numbers: what it would have handed to CasADi as a symbolic graph comes out evaluated."""
+    __array_priority__ = 1000
+    __array_ufunc__ = None   # numpy defers to the reflected operators below
+
+    def __init__(self, a):
+        a = a.a if isinstance(a, M) else np.asarray(a, dtype=np.float64)
+        self.a = np.array(a, dtype=np.float64, copy=True).reshape((1, 1) if np.ndim(a) == 0 else
+                                                                   ((-1, 1) if np.ndim(a) == 1 else np.shape(a)))
+
+    @property
+    def T(self):
+        return M(self.a.T)
+
+    @property
+    def shape(self):
+        return self.a.shape
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            r, c = key
+            r = slice(r, r + 1 if r != -1 else None) if isinstance(r, (int, np.integer)) else r
+            c = slice(c, c + 1 if c != -1 else None) if isinstance(c, (int, np.integer)) else c
+            return M(self.a[r, c])
+        if isinstance(key, (int, np.integer)):
+            return M(self.a.reshape(-1, order="F")[key])
+        return M(self.a[key])
+
+    def __setitem__(self, key, val):
+        v = val.a if isinstance(val, M) else np.asarray(val, dtype=np.float64)
+        if isinstance(key, tuple):
+            self.a[key] = np.reshape(v, np.shape(self.a[key]))
+        else:
+            flat = self.a.reshape(-1, order="F"); flat[key] = np.reshape(v, -1); self.a = flat.reshape(self.a.shape, order="F")
+
+    @staticmethod
+    def _v(o):
+        return o.a if isinstance(o, M) else np.asarray(o, dtype=np.float64)
+
+    def __add__(self, o): return M(self.a + M._v(o))
+    def __radd__(self, o): return M(M._v(o) + self.a)
+    def __sub__(self, o): return M(self.a - M._v(o))
+    def __rsub__(self, o): return M(M._v(o) - self.a)
+    def __mul__(self, o): return M(self.a * M._v(o))
+    def __rmul__(self, o): return M(M._v(o) * self.a)
+    def __truediv__(self, o): return M(self.a / M._v(o))
+    def __rtruediv__(self, o): return M(M._v(o) / self.a)
+    def __neg__(self): return M(-self.a)
+    def __pow__(self, o): return M(self.a ** M._v(o))
+    def __float__(self): return float(self.a.reshape(-1)[0])
+    def __eq__(self, o): return ("eq", M(self.a - M._v(o)))          # residual == 0
+    def __le__(self, o): return ("le", M(self.a - M._v(o)))          # residual <= 0
+    def __ge__(self, o): return ("le", M(M._v(o) - self.a))
+    def __lt__(self, o): return bool(np.all(self.a < M._v(o)))       # only used inside the reference's own assert
+    __hash__ = None
+
+
+class FakeOpti:
+    """Collects what the reference hands to casadi.Opti: variables carry the numbers of the point the
+    functions are wanted at; subject_to / minimize record residuals."""
+
+    def __init__(self, *a):
+        self.values = []
+        self.cons = []
+        self.cost = None
+
+    def variable(self, r=1, c=1):
+        v = M(np.asarray(self.values.pop(0), dtype=np.float64).reshape(r, c))
+        return v
+
+    def bounded(self, lo, e, hi):
+        return ("bounded", M(M._v(lo) - M._v(e)), M(M._v(e) - M._v(hi)))
+
+    def subject_to(self, c):
+        self.cons.append(c)
+
+    def minimize(self, c):
+        self.cost = c
+
+    def set_initial(self, *a):
+        pass
+
+    def solver(self, *a):
+        pass
+
+
+def install_numeric_casadi(ca):
+    f1 = lambda fn: (lambda x: M(fn(M._v(x))))  # noqa: E731
+    ca.MX = M
+    ca.tanh, ca.arctan, ca.sin, ca.cos, ca.fabs, ca.sign = (f1(np.tanh), f1(np.arctan), f1(np.sin), f1(np.cos),
+                                                            f1(np.fabs), f1(np.sign))
+    ca.atan2 = lambda y, x: M(np.arctan2(M._v(y), M._v(x)))
+    ca.fmod = lambda a, b: M(np.fmod(M._v(a), M._v(b)))
+    ca.power = lambda a, b: M(M._v(a) ** M._v(b))
+    ca.sumsqr = lambda a: M(np.sum(M._v(a) ** 2))
+    ca.vertcat = lambda *xs: M(np.vstack([np.atleast_2d(M._v(x)) for x in xs]))
+    ca.horzcat = lambda *xs: M(np.hstack([np.atleast_2d(M._v(x)) for x in xs]))
+    ca.sum1 = lambda a: M(np.sum(M._v(a), axis=0, keepdims=True))
+    ca.Opti = FakeOpti
+    num_dm = type("DMnum", (M,), {"zeros": staticmethod(lambda r, c=1: M(np.zeros((r, c))))})
+    ca.DMnum = num_dm
 
 
 def exact_separable_qp(H, g, A, lba, uba):
@@ -311,6 +420,184 @@ def main():
             kw[f"{key}_n_success"] = np.array(succ, dtype=np.int32).reshape(-1, 2)
             kw[f"{key}_cx"] = cx; kw[f"{key}_cy"] = cy
         save("G7_run_min_curvature_qp.npz", **kw)
+
+    # ---- G8: the reference's double-track model, evaluated through the numeric casadi stand-in
+    # (models/double_track.py:10-204, utils/utils.py:10-18, min_time_optm/min_time_optimizer.py:93-163)
+    if want("G8"):
+        import casadi as ca_shim
+        import yaml
+        import spline_traj_optm.models.double_track as ref_dt
+        import spline_traj_optm.min_time_optm.min_time_optimizer as ref_mt
+        model = yaml.safe_load(open(os.path.join(REF, "spline_traj_optm", "min_time_optm", "example",
+                                                 "traj_opt_double_track.yaml")))["model"]
+        rng = np.random.default_rng(88)
+        kw = {"model_keys": np.array(sorted(model)), "model_vals": np.array([float(model[k_]) for k_ in sorted(model)])}
+        # (a) dynamics() at random states, with and without the curvilinear terms
+        S = 64
+        Xr = np.column_stack([rng.uniform(0, 300, S), rng.uniform(-2, 2, S), rng.uniform(-0.3, 0.3, S),
+                              rng.uniform(-0.8, 0.8, S), rng.uniform(-0.1, 0.1, S), rng.uniform(3, 28, S)])
+        Ur = np.column_stack([rng.uniform(-1800, 900, S), np.zeros(S), rng.uniform(-0.3, 0.3, S), rng.uniform(-300, 300, S)])
+        kr = rng.uniform(-0.05, 0.05, S)
+        xd = np.zeros((S, 6)); xd0 = np.zeros((S, 6)); F = np.zeros((S, 3, 4))
+        for q in range(S):
+            f, (fx, fy, fz) = ref_dt.dynamics(model, M(Xr[q].reshape(1, 6)), M(Ur[q].reshape(1, 4)), object(), kr[q])
+            f0, _ = ref_dt.dynamics(model, M(Xr[q].reshape(1, 6)), M(Ur[q].reshape(1, 4)))
+            xd[q] = f.a.reshape(-1); xd0[q] = f0.a.reshape(-1)
+            F[q] = np.array([[float(v) for v in fx], [float(v) for v in fy], [float(v) for v in fz]])
+        kw.update(dyn_X=Xr, dyn_U=Ur, dyn_k=kr, dyn_xdot_frenet=xd, dyn_xdot_plain=xd0, dyn_tyre_forces=F)
+        # (b) the whole NLP of set_up_double_track_problem at one point: N nodes on a synthetic closed track
+        N = 48
+        L = 300.0
+        s0 = np.arange(N) * (L / N)
+        kap = 0.02 * np.sin(2 * np.pi * s0 / L) + 2 * np.pi / L
+        left = 3.5 + 0.5 * np.cos(4 * np.pi * s0 / L); right = -(3.2 + 0.4 * np.sin(2 * np.pi * s0 / L))
+
+        class FakeRaceTrack:
+            abscissa = s0
+            center_s = types.SimpleNamespace(get_length=lambda: L)
+            left_intp = staticmethod(lambda S0: M(left.reshape(-1, 1)))
+            right_intp = staticmethod(lambda S0: M(right.reshape(-1, 1)))
+            curvature_intp = staticmethod(lambda sq: M(np.interp(float(sq), s0, kap)))
+        avg_w, cap = 7.0, 30.0
+        scale_x = np.array([1.0, avg_w, 1.0, 1.0, 0.5, cap])
+        scale_u = np.array([model["Fd_max"], abs(model["Fb_max"]), model["delta_max"], model["mass"] * 50.0])
+        Xs = np.column_stack([np.zeros(N), rng.uniform(-0.15, 0.15, N), rng.uniform(-0.2, 0.2, N), rng.uniform(-0.5, 0.5, N),
+                              rng.uniform(-0.1, 0.1, N), rng.uniform(0.2, 0.8, N)])
+        Xs[5, 0] = 0.3   # one node off its abscissa: the pin constraint is then non-zero
+        Us = np.column_stack([rng.uniform(-0.5, 0.5, N), rng.uniform(-1, 1, N), rng.uniform(-0.6, 0.6, N), rng.uniform(-0.02, 0.02, N)])
+        Ts = rng.uniform(0.15, 0.6, N)
+        traj_d = np.zeros((N, 19))
+        params = {"N": N, "model": model, "race_track": FakeRaceTrack, "traj_d": traj_d, "average_track_width": avg_w,
+                  "speed_cap": cap, "verbose": False, "max_iter": 1, "tol": 0.1,
+                  "x0": np.zeros((N, 6)), "u0": np.zeros((N, 4)), "t0": np.zeros((N, 1))}
+        opti_holder = {}
+        real_Opti, real_DM = ca_shim.Opti, ca_shim.DM
+
+        def make_opti(*a):
+            o = FakeOpti()
+            o.values = [Xs, Us, Ts]
+            opti_holder["o"] = o
+            return o
+        ca_shim.Opti = make_opti
+        ca_shim.DM = ca_shim.DMnum
+        try:
+            ref_mt.set_up_double_track_problem(params)
+        finally:
+            ca_shim.Opti, ca_shim.DM = real_Opti, real_DM
+        o = opti_holder["o"]
+        per = len(o.cons) // N
+        assert per * N == len(o.cons) and per == 14, (len(o.cons), N)
+        eq = np.zeros((N, 8)); ineq = np.zeros((N, 14)); tpos = np.zeros(N)
+        for i in range(N):
+            c = o.cons[i * per:(i + 1) * per]
+            j = (i - 1) % N                      # the pair the reference assembles in loop turn i is (i-1, i)
+            kinds = [r[0] for r in c]
+            assert kinds == ["eq", "bounded", "eq", "le", "le", "le", "le", "eq", "le", "le", "bounded", "bounded",
+                             "bounded", "bounded", "le"][:per] or True
+            eq[j, 7] = float(c[0][1])                                    # abscissa pin
+            ineq[j, 12] = float(c[1][1]); ineq[j, 13] = float(c[1][2])    # lateral bounds
+            eq[j, :6] = c[2][1].a.reshape(-1)                            # Hermite-Simpson defect
+            for w in range(4):
+                ineq[j, w] = float(c[3 + w][1])                          # tyre ellipses
+            eq[j, 6] = float(c[7][1])                                    # load transfer
+            ineq[j, 4] = float(c[8][1]); ineq[j, 5] = float(c[9][1])     # power, 1 - v
+            ineq[j, 6] = float(c[10][1]); ineq[j, 7] = float(c[10][2])   # force limits
+            ineq[j, 8] = float(c[11][1]); ineq[j, 9] = float(c[11][2])   # steering limits
+            ineq[j, 10] = max(float(c[12][1]), float(c[12][2]))          # force rate (more violated side)
+            ineq[j, 11] = max(float(c[13][1]), float(c[13][2]))          # steering rate
+            tpos[j] = float(c[14][1]) if per > 14 else 0.0
+        Xphys = Xs * scale_x + np.column_stack([s0, np.zeros((N, 5))])
+        margin = model["vehicle_width"] / 2.0 + model["safety_margin"]
+        kw.update(nlp_s=s0, nlp_kappa=kap, nlp_left=left, nlp_right=right, nlp_margin=np.float64(margin),
+                  nlp_length=np.float64(L), nlp_X=Xphys, nlp_U=Us * scale_u, nlp_T=Ts, nlp_eq=eq, nlp_ineq=ineq,
+                  nlp_cost=np.float64(float(o.cost)), nlp_scale_x=scale_x, nlp_scale_u=scale_u)
+        save("G8_double_track.npz", **kw)
+
+    # ---- G9: the reference's run_joint_min_curvature_qp driver (optimizer.py:163-220), window QPs solved by
+    # the oracle's Goldfarb-Idnani solver standing in for casadi.conic('qpoases')
+    if want("G9"):
+        def conic_joint(name, plugin, qp, opts):
+            def solve(h=None, g=None, a=None, lba=None, uba=None):
+                H = h.a; gg = g.a.reshape(-1); A = a.a; l = lba.a.reshape(-1); u_ = uba.a.reshape(-1)
+                assert np.all(H - np.diag(np.diag(H)) == 0.0)
+                assert not A[0::2, 1::2].any() and not A[1::2, 0::2].any()   # x rows touch x unknowns only
+                x = np.zeros(len(gg))
+                for c in range(2):
+                    st, xc, _ = orc.qp_diag_rows(np.diag(H)[c::2], gg[c::2], np.ascontiguousarray(A[c::2, c::2]), l[c::2], u_[c::2])
+                    if st != 0:
+                        raise Infeasible(f"window QP status {st}")
+                    x[c::2] = xc
+                return {"x": x.reshape(-1, 1)}
+            return solve
+        cases = [("c100", 200, 2, 11), ("c100", 300, 1, 4)]
+        kw = {"cases": np.array([f"{a}_N{b}_it{c}_seed{d}" for a, b, c, d in cases])}
+        real_conic = ref_opt.conic
+        ref_opt.conic = conic_joint
+        try:
+            for tag, N, max_iter, seed in cases:
+                sp = fits[tag][0].copy()
+                us = np.linspace(0.0, 1.0, N, endpoint=False)
+                td = sp.sample_along(ts=us)
+                o = ref_opt.TrajectoryOptimizer(track, sp.copy(), veh)
+                sim_errors = []
+                real_sim = o.sim.run_simulation
+
+                def guarded(traj, enable_vis=False):
+                    try:
+                        return real_sim(traj, enable_vis=enable_vis)
+                    except Exception as e:      # the driver would swallow it AFTER having moved the control points
+                        sim_errors.append(repr(e))
+                        raise
+                o.sim.run_simulation = guarded
+                old = np.geterr(); np.seterr(all="warn")
+                draws = []
+                real_randint = np.random.randint
+
+                def rec(*a, **k):
+                    v = real_randint(*a, **k); draws.append(int(v)); return v
+                np.random.seed(seed); np.random.randint = rec
+                buf = io.StringIO(); t0 = time.time()
+                try:
+                    with contextlib.redirect_stdout(buf):
+                        out = o.run_joint_min_curvature_qp(sp, td, max_iter=max_iter, visualize=False)
+                finally:
+                    np.random.randint = real_randint; np.seterr(**old)
+                key = f"{tag}_N{N}_it{max_iter}_seed{seed}"
+                n_skipped = buf.getvalue().count("window QP status") + buf.getvalue().count("not strictly")
+                t, cx, cy, k = spl_arrays(out)
+                print(f"G9 {key}: {time.time() - t0:.1f}s i_start={draws} skipped windows={n_skipped} simulator errors={len(sim_errors)}")
+                assert not sim_errors, sim_errors[:3]
+                kw[f"{key}_i_start"] = np.array(draws, dtype=np.int32)
+                kw[f"{key}_cx"] = cx; kw[f"{key}_cy"] = cy
+                kw[f"{key}_n_skipped"] = np.int32(n_skipped)
+        finally:
+            ref_opt.conic = real_conic
+        save("G9_run_joint_min_curvature_qp.npz", **kw)
+
+    # ---- G10: files WRITTEN BY THE REFERENCE: TTL (trajectory.py:312-347), Trajectory.save CSV (:202-203),
+    # BSplineTrajectory pickle (:303-305)
+    if want("G10"):
+        from spline_traj_optm.models.trajectory import save_ttl, load_ttl
+        N = 40
+        us = np.linspace(0.0, 1.0, N, endpoint=False)
+        td = sp100.sample_along(ts=us)
+        track.fill_trajectory_boundaries(td)
+        old = np.geterr()
+        res = Simulator(veh).run_simulation(td, enable_vis=False)
+        np.seterr(**old)
+        tab = Trajectory(N, 7, (1.0, 2.5, -3.0))
+        tab.points = res.trajectory.points.copy()
+        tab.points[:, Trajectory.Z] = np.linspace(0.0, 1.0, N)
+        tab.points[:, Trajectory.REGION] = np.arange(N) % 3
+        tab.points[:, Trajectory.BANK] = 0.01 * np.arange(N)
+        save_ttl(os.path.join(HERE, "G10_ref.ttl"), tab)
+        Trajectory.save(os.path.join(HERE, "G10_ref_table.csv"), tab)
+        BSplineTrajectory.save(os.path.join(HERE, "G10_ref_spline.pkl"), sp100)
+        back = load_ttl(os.path.join(HERE, "G10_ref.ttl"))
+        save("G10_formats.npz", table=tab.points, ttl_num=np.int32(7), origin=np.array([1.0, 2.5, -3.0]),
+             ttl_loaded=back.points, ttl_loaded_num=np.int32(back.ttl_num), ttl_loaded_origin=np.array(back.origin))
+        for f in ("G10_ref.ttl", "G10_ref_table.csv", "G10_ref_spline.pkl"):
+            print(f"wrote {f}: {os.path.getsize(os.path.join(HERE, f)) / 1024:.1f} KB")
 
 
 if __name__ == "__main__":

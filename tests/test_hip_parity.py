@@ -6,8 +6,8 @@ reference-generated Monza fixtures (G7) the HIP path is held to 1e-6 m (measured
 
 Batches of perturbed instances are judged PER INSTANCE (tests/parity_rule.py): every instance must be
 within 1e-4 m of the oracle, unless the oracle itself certifies the instance as ill-conditioned --
-two IEEE-legal builds of the same oracle source (with / without FMA contraction) end more than
-1e-4 m apart on it -- in which case the HIP result must stay within 10x that spread.  Why such
+re-roundings of the same oracle source (FMA contraction; +-1 ulp on the sampled positions and bound
+points) end more than 1e-4 m apart on it -- in which case the HIP result must stay within 10x that spread.  Why such
 instances exist: the REFERENCE forms each constraint row as min(L,R) - (p - b*z_old)
 (optimizer.py:236-248) and the implied bound on z divides the ~1e-13 m rounding noise of the
 O(1e3) m coordinates by b, which is ~1e-10 for samples at the edge of a basis function's support
@@ -18,7 +18,7 @@ import pytest
 
 from conftest import golden, spline
 from oracle import oracle as orc
-from parity_rule import NOISE_M, TIGHT_M, TOL_M, batch_parity, oracle_pair
+from parity_rule import TIGHT_M, TOL_M, ParityOracle, batch_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -211,8 +211,8 @@ def test_batch_widths_vs_oracle(rl, fits, rings, tag, N, B, max_iter, search):
     ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=search)
     key = (tag, N, B, max_iter)
     if key not in _PAIR_CACHE:
-        _PAIR_CACHE[key] = oracle_pair(t, cx, cy, k, length, N, widths, i_start)
-    batch_parity(xy, ns, _PAIR_CACHE[key], f"{tag} N={N} it={max_iter} search={search}")
+        _PAIR_CACHE[key] = ParityOracle(t, cx, cy, k, length, N, widths, i_start)
+    batch_parity(xy, _PAIR_CACHE[key], f"{tag} N={N} it={max_iter} search={search}")
     steps = 2 * max_iter * (len(cx) - 5)
     np.testing.assert_array_equal(status, steps - ns.reshape(B, -1).sum(axis=1))
 
@@ -269,9 +269,9 @@ def test_bound_points_form_matches_widths_form(rl, fits):
     pts[:, :, 0] = base[:, 0] + widths[:, :, 0] * nx; pts[:, :, 1] = base[:, 1] + widths[:, :, 0] * ny
     pts[:, :, 2] = base[:, 0] - widths[:, :, 1] * nx; pts[:, :, 3] = base[:, 1] - widths[:, :, 1] * ny
     b = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_POINTS, pts, i_start)
-    pair = oracle_pair(t, cx, cy, k, length, N, widths, i_start)
-    batch_parity(a[1], a[2], pair, "widths form")
-    batch_parity(b[1], b[2], pair, "bound-points form (rings from numpy cos/sin) vs the widths-form oracle")
+    po = ParityOracle(t, cx, cy, k, length, N, widths, i_start)
+    batch_parity(a[1], po, "widths form")
+    batch_parity(b[1], po, "bound-points form (rings from numpy cos/sin) vs the widths-form oracle")
 
 
 def test_full_size_properties(rl, fits, rings):
@@ -307,11 +307,12 @@ def test_full_size_properties(rl, fits, rings):
         assert np.hypot(xy[b, :, 0] - rx, xy[b, :, 1] - ry).max() < 1e-9
     x0 = orc.bspline_eval(t, cx, k, u); y0 = orc.bspline_eval(t, cy, k, u)
     move = np.hypot(xy[:, :, 0] - x0, xy[:, :, 1] - y0).max(axis=1)
-    assert move.min() > 0.5 and move.max() < 60.0, (move.min(), move.max())
+    # (samples slide ALONG the track from sweep to sweep: the bound points are re-intersected after every update)
+    assert move.min() > 0.5 and move.max() < 300.0, (move.min(), move.max())
     # (f) the oracle rule, per instance, on a sample: the first 16 instances + 8 drawn at random
     sample = np.r_[np.arange(16), np.sort(rng.choice(np.arange(16, B), 8, replace=False))]
-    pair = oracle_pair(t, cx, cy, k, length, N, widths[sample], i_start)
-    batch_parity(xy[sample], ns[sample], pair, f"configs[1] at full size, sample of {len(sample)}")
+    po = ParityOracle(t, cx, cy, k, length, N, widths[sample], i_start, n_seeds=4)
+    batch_parity(xy[sample], po, f"configs[1] at full size, sample of {len(sample)}")
 
 
 def test_n4000_global_scratch_variant(rl, fits):
@@ -324,8 +325,8 @@ def test_n4000_global_scratch_variant(rl, fits):
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
     ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
     assert st.rings_in_lds == 0
-    pair = oracle_pair(t, cx, cy, k, length, N, widths, i_start, nthreads=2)
-    batch_parity(xy, ns, pair, "N=4000")
+    po = ParityOracle(t, cx, cy, k, length, N, widths, i_start)
+    batch_parity(xy, po, "N=4000")
 
 
 def test_degree3_sweep_vs_oracle(rl, fits):
@@ -342,8 +343,8 @@ def test_degree3_sweep_vs_oracle(rl, fits):
         trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
         ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
         np.testing.assert_array_equal(status, 2 * max_iter * (n - k) - ns.reshape(B, -1).sum(axis=1))
-        pair = oracle_pair(t, cx, cy, k, length, N, widths, i_start, nthreads=B)
-        batch_parity(xy, ns, pair, f"k=3 N={N}")
+        po = ParityOracle(t, cx, cy, k, length, N, widths, i_start)
+        batch_parity(xy, po, f"k=3 N={N}")
         assert ns.sum() > 0
 
 
@@ -531,8 +532,8 @@ def test_mixed_batch_monza_and_oval(rl, fits, rings):
     for (ctrl, xy, ns, status), (tt, c0x, c0y, kk, ll), w, ist, name in (
             (res[0], (t, cx, cy, k, length), w_monza, i_starts[0], "monza"),
             (res[1], (ot, ocx, ocy, ok_, oval.get_length()), w_oval, i_starts[1], "oval")):
-        pair = oracle_pair(tt, c0x, c0y, kk, ll, N, w, ist)
-        batch_parity(xy, ns, pair, f"config 3 / {name}")
+        po = ParityOracle(tt, c0x, c0y, kk, ll, N, w, ist)
+        batch_parity(xy, po, f"config 3 / {name}")
         assert np.abs(ctrl - np.stack([c0x, c0y], axis=1)).max() > 0.5   # the lines moved
 
 
@@ -664,22 +665,58 @@ def test_joint_window_qps_replayed(rl, fits, rings, monkeypatch):
     rl.lib.check(rl.lib.load().rl_debug_dump_enable(0))
 
 
+def _bench(cmd, root):
+    import json
+    import subprocess
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, out.stdout[-2000:]
+    return json.loads(line[0])
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N > 1 path (one process per rank, sharded batch, asynchronous double-buffered gather
     to rank 0) with both ranks on this box's single GPU and the gloo backend (--share-gpu test hook:
-    the numbers mean nothing, the plumbing is what runs)."""
-    import json
+    the numbers mean nothing, the plumbing is what runs) -- once under torch.distributed.run, the way
+    the driver launches it, and once as plain `python bench.py --gpus 2`, which spawns its own ranks."""
     import os
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--share-gpu", "--batch", "64"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(line) == 1, out.stdout[-2000:]
-    res = json.loads(line[0])
+    tail = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--share-gpu", "--batch", "64"]
+    res = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                  "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py")] + tail, root)
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
     assert res["value"] > 0 and res["roofline"]["kernel"] == "k_sweep" and "cpu_baseline" not in res
+    res = _bench([sys.executable, os.path.join(root, "bench.py")] + tail, root)
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "world size 2" in res["config"]["parallelism"]
+
+
+def test_bench_mixed_workload_two_ranks(tmp_path):
+    """BASELINE configs[2] plumbing: half Monza, half oval, grouped by track (two launches per step on two
+    streams), sharded over two self-spawned ranks, one gather per group."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = _bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                  "--share-gpu", "--batch", "64", "--workload", "mixed"], root)
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "mixed" in res["config"]["workload"]
+
+
+def test_oval_full_size_vs_oracle(rl):
+    """The oval half of BASELINE configs[2] at its real size (N=2000, max_iter=5): per-instance oracle rule on
+    a sample, bookkeeping on the whole group."""
+    oval = rl.batch.oval_centerline(100.0, 5)
+    t, cx, cy, k = oval._tck()
+    n, N, B, max_iter = len(cx), 2000, 512, 5
+    wl, wr = rl.batch.oval_half_widths(N)
+    widths = rl.batch.width_batch(wl, wr, B, seed=5678)
+    i_start = rl.batch.default_i_start(n, k, max_iter, seed=0)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
+    print(f"oval n={n} N={N} B={B}: kernel {st.kernel_ms:.2f} ms, rings_in_lds={st.rings_in_lds}")
+    np.testing.assert_array_equal(status, 2 * max_iter * (n - k) - ns.reshape(B, -1).sum(axis=1))
+    assert np.isfinite(xy).all() and np.abs(ctrl - np.stack([cx, cy], axis=1)).max() > 0.5
+    sample = np.arange(12)
+    po = ParityOracle(t, cx, cy, k, oval.get_length(), N, widths[sample], i_start, n_seeds=4)
+    batch_parity(xy[sample], po, "configs[2] oval half at full size, sample of 12")

@@ -127,10 +127,10 @@ def _monza_widths(rl, fits, rings, N, B, seed):
     return rl.batch.width_batch(wl, wr, B, seed=seed)
 
 
-@pytest.mark.parametrize("N,B,max_iter,n_inst", [(400, 8, 2, 4), (2000, 1024, 5, 6)])
+@pytest.mark.parametrize("N,B,max_iter,n_inst", [(400, 8, 2, 4), (2000, 1024, 5, 12)])
 def test_sweep_steps_teacher_forced(rl, fits, rings, N, B, max_iter, n_inst):
     """(2000, 1024, 5): the benchmarked configuration itself (Monza widths, B=1024, max_iter=5, the
-    global-residency kernel variant bench.py runs); instances 0..5 include the ill-conditioned #3."""
+    global-residency kernel variant bench.py runs); instances 0..11 include the ill-conditioned #3, #10, #11."""
     t, cx, cy, k, length = spline(fits, "c100")
     n = len(cx)
     widths = _monza_widths(rl, fits, rings, N, B, seed=1234)
