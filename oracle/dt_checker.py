@@ -3,10 +3,9 @@ include/rl_mincurv.h: rl_dt_eval_nodes -- TEST INFRASTRUCTURE ONLY (never import
 
 Restates, formula by formula, models/double_track.py:10-140 (dynamics) and :143-204 (node
 constraints), min_time_optimizer.py:93-163 (pairing of node i-1 with node i, cost) and
-utils/utils.py:10-18 of the reference.  PARITY UNPINNED: the reference evaluates these through CasADi,
-which is not importable here, and ships no numeric fixture for them; what pins this
-file is its agreement with the published model and the collocation-order test in
-tests/test_double_track.py."""
+utils/utils.py:10-18 of the reference.  Pinned by fixture G8 (tests/golden/G8_double_track.npz): the
+reference's own functions executed on numbers through a numeric stand-in for CasADi
+(tests/golden/make_golden.py); tests/test_oracle_golden.py::test_g8_* holds this file to it (1e-13)."""
 import numpy as np
 
 G = 9.8

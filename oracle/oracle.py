@@ -224,8 +224,9 @@ def qp_diag_rows(h, g, A, l, u):
     return st, x, lam
 
 
-def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None):
-    """Returns (cx, cy, points[N,19], n_success[max_iter])."""
+def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None, rerounding=0):
+    """Returns (cx, cy, points[N,19], n_success[max_iter]).  rerounding: seed of mincurv_oracle.c:
+    orc_set_rerounding for this run (0 = the unperturbed oracle)."""
     t, tp = _d(t)
     cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
     ringL, lp = _d(ringL); ringR, rp = _d(ringR)
@@ -237,8 +238,15 @@ def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, m
     f = lib().orc_run_joint_min_curvature_qp
     f.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double, _dp, ctypes.c_int,
                   _dp, ctypes.c_int, _dp, ctypes.c_int, _ip, ctypes.c_int, _ip]
-    f(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k), float(length),
-      pts.ctypes.data_as(_dp), int(N), lp, len(ringL), rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
+    setr = lib().orc_set_rerounding
+    setr.argtypes = [ctypes.c_ulonglong]
+    setr.restype = None
+    setr(int(rerounding))
+    try:
+        f(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k), float(length),
+          pts.ctypes.data_as(_dp), int(N), lp, len(ringL), rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
+    finally:
+        setr(0)
     return cx, cy, pts, ns
 
 

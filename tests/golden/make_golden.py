@@ -486,14 +486,13 @@ def main():
             ca_shim.Opti, ca_shim.DM = real_Opti, real_DM
         o = opti_holder["o"]
         per = len(o.cons) // N
-        assert per * N == len(o.cons) and per == 14, (len(o.cons), N)
+        assert per * N == len(o.cons) and per == 15, (len(o.cons), N)
         eq = np.zeros((N, 8)); ineq = np.zeros((N, 14)); tpos = np.zeros(N)
         for i in range(N):
             c = o.cons[i * per:(i + 1) * per]
             j = (i - 1) % N                      # the pair the reference assembles in loop turn i is (i-1, i)
-            kinds = [r[0] for r in c]
-            assert kinds == ["eq", "bounded", "eq", "le", "le", "le", "le", "eq", "le", "le", "bounded", "bounded",
-                             "bounded", "bounded", "le"][:per] or True
+            assert [r[0] for r in c] == ["eq", "bounded", "eq", "le", "le", "le", "le", "eq", "le", "le", "bounded",
+                                         "bounded", "bounded", "bounded", "le"], [r[0] for r in c]
             eq[j, 7] = float(c[0][1])                                    # abscissa pin
             ineq[j, 12] = float(c[1][1]); ineq[j, 13] = float(c[1][2])    # lateral bounds
             eq[j, :6] = c[2][1].a.reshape(-1)                            # Hermite-Simpson defect
@@ -505,12 +504,13 @@ def main():
             ineq[j, 8] = float(c[11][1]); ineq[j, 9] = float(c[11][2])   # steering limits
             ineq[j, 10] = max(float(c[12][1]), float(c[12][2]))          # force rate (more violated side)
             ineq[j, 11] = max(float(c[13][1]), float(c[13][2]))          # steering rate
-            tpos[j] = float(c[14][1]) if per > 14 else 0.0
+            tpos[j] = float(c[14][1])                                    # 0 <= t as -t <= 0
         Xphys = Xs * scale_x + np.column_stack([s0, np.zeros((N, 5))])
         margin = model["vehicle_width"] / 2.0 + model["safety_margin"]
         kw.update(nlp_s=s0, nlp_kappa=kap, nlp_left=left, nlp_right=right, nlp_margin=np.float64(margin),
                   nlp_length=np.float64(L), nlp_X=Xphys, nlp_U=Us * scale_u, nlp_T=Ts, nlp_eq=eq, nlp_ineq=ineq,
-                  nlp_cost=np.float64(float(o.cost)), nlp_scale_x=scale_x, nlp_scale_u=scale_u)
+                  nlp_cost=np.float64(float(o.cost)), nlp_scale_x=scale_x, nlp_scale_u=scale_u,
+                  nlp_neg_t=tpos)
         save("G8_double_track.npz", **kw)
 
     # ---- G9: the reference's run_joint_min_curvature_qp driver (optimizer.py:163-220), window QPs solved by
@@ -529,7 +529,13 @@ def main():
                     x[c::2] = xc
                 return {"x": x.reshape(-1, 1)}
             return solve
-        cases = [("c100", 200, 2, 11), ("c100", 300, 1, 4)]
+        # The sliding-window driver is chaotic in the rounding (DESIGN.md "Conditioning"): of 40 (N, seed,
+        # max_iter) combinations tried, the strict oracle reproduces the reference's run to <= 2.5e-8 m with
+        # identical window counts on 23 and ends metres away on the rest.  The cases below are five of the
+        # reproducible ones (they pin the driver logic: window order, wrap, skip semantics, the simulator call
+        # not feeding back) and one chaotic one (N=200, seed 3), flagged per case in `<key>_well_conditioned`.
+        cases = [("c100", 200, 2, 0), ("c100", 200, 2, 1), ("c100", 300, 2, 1), ("c100", 400, 2, 0), ("c100", 400, 2, 3),
+                 ("c100", 200, 2, 3)]
         kw = {"cases": np.array([f"{a}_N{b}_it{c}_seed{d}" for a, b, c, d in cases])}
         real_conic = ref_opt.conic
         ref_opt.conic = conic_joint
@@ -570,6 +576,13 @@ def main():
                 kw[f"{key}_i_start"] = np.array(draws, dtype=np.int32)
                 kw[f"{key}_cx"] = cx; kw[f"{key}_cy"] = cy
                 kw[f"{key}_n_skipped"] = np.int32(n_skipped)
+                nwin = (len(cx) - 3 - 5) - 2
+                kw[f"{key}_n_ok"] = np.int32(nwin * max_iter - n_skipped)
+                t0_, cx0_, cy0_, k0_ = spl_arrays(fits[tag][0])
+                ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t0_, cx0_, cy0_, k0_, fits[tag][5], N, track.ringL, track.ringR, draws)
+                dev = float(np.hypot(ocx - cx, ocy - cy).max())
+                kw[f"{key}_well_conditioned"] = np.bool_(dev < 1e-6 and int(ons.sum()) == nwin * max_iter - n_skipped)
+                print(f"   strict oracle vs this run: {dev:.2e} m, windows {ons.tolist()} vs {nwin * max_iter - n_skipped}")
         finally:
             ref_opt.conic = real_conic
         save("G9_run_joint_min_curvature_qp.npz", **kw)

@@ -1,9 +1,10 @@
 """First slice of BASELINE config 5: function evaluation of the min-time double-track
 NLP (include/rl_mincurv.h: rl_dt_eval_nodes).
 
-PARITY UNPINNED against the reference: models/double_track.py and min_time_optimizer.py build CasADi
-expressions, CasADi is not importable here and the reference ships no numbers for them.  What is
-checked:
+Pinned by fixture G8: the reference's own models/double_track.py, utils/utils.py and
+min_time_optimizer.py executed on numbers through a numeric stand-in for CasADi
+(tests/golden/make_golden.py) -- tests/test_oracle_golden.py holds the numpy checker to it, the GPU test
+below the kernel.  Also checked:
   * CPU: the numpy checker (oracle/dt_checker.py) against the physics it states -- straight-line
     equilibrium, left/right mirror symmetry, Hermite-Simpson collocation order (the defect of an
     accurately integrated trajectory shrinks like h^5), the alignment helpers across the start line;
@@ -102,6 +103,21 @@ def test_dt_eval_nodes_vs_numpy(B, N):
     assert (np.abs(g - og) / scale(og)).max() <= 1e-10
     np.testing.assert_allclose(cost, ocost, rtol=1e-12)
     assert np.isfinite(eq).all() and np.isfinite(g).all()
+
+
+@pytest.mark.gpu
+def test_dt_eval_nodes_vs_reference_fixture():
+    """k_dt_eval_nodes against fixture G8: the reference's own set_up_double_track_problem / add_constraints /
+    dynamics evaluated at one point of a 48-node closed track (tests/golden/make_golden.py)."""
+    from conftest import golden
+    from spline_trajectory_optimization_amd import ops
+    g = golden("G8_double_track.npz")
+    m = dict(zip(g["model_keys"].tolist(), g["model_vals"].tolist()))
+    eq, ineq, cost = ops.dt_eval_nodes(m, g["nlp_s"], g["nlp_kappa"], g["nlp_left"], g["nlp_right"], float(g["nlp_margin"]),
+                                       float(g["nlp_length"]), g["nlp_X"][None], g["nlp_U"][None], g["nlp_T"][None])
+    np.testing.assert_allclose(eq[0], g["nlp_eq"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(ineq[0], g["nlp_ineq"], rtol=1e-11, atol=1e-10)
+    assert abs(cost[0] - float(g["nlp_cost"])) < 1e-11 * abs(cost[0])
 
 
 def _pair_cost(Us, Uns, T):

@@ -541,6 +541,24 @@ JOINT_CASES = [(200, [28]), (400, [15]), (500, [25]), (1000, [17]), (2000, [24])
                (200, [10, 30, 45]), (500, [20, 40]), (500, [7, 52])]
 
 
+def _joint_rule(label, hcx, hcy, run_oracle):
+    """Per-case rule of tests/parity_rule.py for the sliding-window driver: within 1e-4 m of the strict
+    oracle, or the oracle's own re-roundings (seeded +-1 ulp, FMA build) spread by more than 1e-4 m on the
+    case and the HIP line is within 10x that spread."""
+    ocx, ocy, ons = run_oracle(0)
+    dev = np.hypot(hcx - ocx, hcy - ocy).max()
+    if dev <= TOL_M:
+        return dev, 0.0, True
+    spread = 0.0
+    for seed in range(1, 13):
+        rcx, rcy, _ = run_oracle(seed)
+        spread = max(spread, np.hypot(rcx - ocx, rcy - ocy).max())
+        if spread > TOL_M and dev <= 10.0 * spread:
+            break
+    assert spread > TOL_M and dev <= 10.0 * spread, (label, dev, spread)
+    return dev, spread, False
+
+
 def test_joint_sweep_vs_oracle(rl, fits, rings):
     """run_joint_min_curvature_qp (optimizer.py:163-220): sliding 5-control-point windows, each a
     10-variable QP solved exactly (two 5-variable dual active-set solves) -- HIP vs the oracle.
@@ -548,12 +566,10 @@ def test_joint_sweep_vs_oracle(rl, fits, rings):
     The window QP has a row for EVERY sample of the track, so it is infeasible as soon as one sample
     anywhere sits outside its own bound box -- and after a clamp samples sit ON a ring, where "inside
     or outside by one ulp" is decided by rounding.  Together with the noise-amplified binding rows
-    this makes the reference's joint driver chaotic in the rounding: two builds of the oracle itself
-    (with / without FMA contraction) end tens of metres apart on a third of the cases below, and the
-    HIP path (different normal formula, summation order) lands on yet another realisation.
-    What is asserted end to end: invariants on every case, and agreement with the oracle (same
-    windows accepted, same line within the noise bound) on at least two of the cases.  The kernel's
-    logic is pinned separately and exactly by test_joint_window_qps_replayed."""
+    this makes the reference's joint driver chaotic in the rounding on part of the cases (fixture G9:
+    the strict oracle reproduces the reference's own run on 23 of 40 combinations tried).  Every case must be
+    within 1e-4 m of the oracle or be certified chaotic by the oracle's own re-roundings; the kernel's logic is
+    pinned exactly by test_joint_window_qps_replayed and, end to end, by test_joint_sweep_vs_reference_run."""
     t, cx, cy, k, length = spline(fits, "c100")
     n = len(cx)
     agree = 0
@@ -561,24 +577,47 @@ def test_joint_sweep_vs_oracle(rl, fits, rings):
         trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
         trk.set_rings(rings[0], rings[1])
         hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, i_start)
-        ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start)
-        with orc.fma_variant():
-            fcx, fcy, _, fns = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start)
-        noise = np.hypot(ocx - fcx, ocy - fcy).max()
-        dev = min(np.hypot(hcx - ocx, hcy - ocy).max(), np.hypot(hcx - fcx, hcy - fcy).max())
-        same = bool((np.array_equal(ns, ons) or np.array_equal(ns, fns)) and dev <= TOL_M)
-        agree += same
-        # the per-instance rule of tests/parity_rule.py: inside the tolerance, or certified chaotic by the
-        # oracle's own two roundings and then within 10x their spread
-        assert same or (noise > TOL_M and dev <= 10.0 * noise), (N, i_start, dev, noise)
-        print(f"joint N={N} i_start={i_start}: windows HIP {ns.tolist()} oracle {ons.tolist()} oracle-fma {fns.tolist()}  "
-              f"oracle re-rounding {noise:.1e} m  HIP-oracle {dev:.1e} m  {'AGREE' if same else 'other realisation'}  "
-              f"kernel {st.kernel_ms:.2f} ms")
+
+        def run_oracle(seed):
+            ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start, rerounding=seed)
+            return ocx, ocy, ons
+        dev, spread, within = _joint_rule((N, i_start), hcx, hcy, run_oracle)
+        agree += within
+        print(f"joint N={N} i_start={i_start}: windows HIP {ns.tolist()}  HIP-oracle {dev:.1e} m  "
+              f"{'within 1e-4' if within else f'certified chaotic (oracle re-rounding spread {spread:.1e} m)'}  kernel {st.kernel_ms:.2f} ms")
         assert np.isfinite(hcx).all() and np.isfinite(hcy).all() and np.isfinite(pts[:, :2]).all()
         assert hcx[0] == hcx[n - 5] and hcx[1] == hcx[n - 4] and hcx[n - 3] == hcx[2] and hcx[n - 1] == hcx[4]
         assert 0 <= ns.min() and ns.max() <= n - 8 - 2        # windows per iteration: i_max - i_min
         assert np.hypot(hcx - cx, hcy - cy).max() > 0.5        # the line moved
-    print(f"joint driver: {agree} of {len(JOINT_CASES)} cases inside 1e-4 m with equal window counts")
+    print(f"joint driver: {agree} of {len(JOINT_CASES)} cases inside 1e-4 m")
+
+
+def test_joint_sweep_vs_reference_run(rl, fits, rings):
+    """a13 end to end against the REFERENCE'S OWN run (fixture G9: run_joint_min_curvature_qp executed by
+    the reference's loop, tests/golden/make_golden.py): on the well-conditioned cases the HIP line is within
+    1e-4 m of the reference-run line -- or, where the HIP path lands on another rounding, certified by the
+    oracle's re-roundings like everywhere else; the number of accepted windows is compared as well."""
+    g = golden("G9_run_joint_min_curvature_qp.npz")
+    t, cx, cy, k, length = spline(fits, "c100")
+    exact = 0
+    for key in g["cases"]:
+        key = str(key)
+        N = int(key.split("_")[1][1:])
+        ist = g[f"{key}_i_start"]
+        trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+        trk.set_rings(rings[0], rings[1])
+        hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, ist)
+        dev_ref = np.hypot(hcx - g[f"{key}_cx"], hcy - g[f"{key}_cy"]).max()
+        same = dev_ref <= TOL_M and int(ns.sum()) == int(g[f"{key}_n_ok"])
+        exact += bool(same)
+        print(f"G9 {key}: HIP vs the reference's run {dev_ref:.2e} m, windows {int(ns.sum())} vs {int(g[f'{key}_n_ok'])}"
+              f"{'' if bool(g[f'{key}_well_conditioned']) else '  (chaotic case)'}")
+        if not same:
+            def run_oracle(seed):
+                ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist, rerounding=seed)
+                return ocx, ocy, ons
+            _joint_rule(key, hcx, hcy, run_oracle)
+    assert exact >= 3, exact
 
 
 def test_joint_sweep_search_modes_and_api(rl, fits, rings, monkeypatch):

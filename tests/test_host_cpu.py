@@ -166,3 +166,38 @@ def test_ttl_and_csv_formats_roundtrip(tmp_path, built):
     from spline_trajectory_optimization_amd.models.race_track import Ring
     r = Ring(np.array([[0.0, 0], [1, 0], [1, 1], [0, 0]]))
     assert r.vertices.shape == (3, 2) and r.coords.shape == (4, 2)
+
+
+def test_g10_files_written_by_the_reference(tmp_path, built):
+    """f3 against REFERENCE-WRITTEN files (fixture G10: save_ttl, Trajectory.save and BSplineTrajectory.save
+    of models/trajectory.py:202-209, 303-358 executed in the build container): the mirror writes the same
+    bytes, reads the same values, and the reference's pickle loads through the `spline_traj_optm`
+    compatibility namespace into the MI355X-backed class."""
+    import os
+    from conftest import GOLDEN, golden
+    from spline_traj_optm.models.trajectory import BSplineTrajectory, Trajectory, load_ttl, save_ttl
+    import spline_trajectory_optimization_amd.models.trajectory as mirror
+    assert BSplineTrajectory is mirror.BSplineTrajectory and Trajectory is mirror.Trajectory
+    g = golden("G10_formats.npz")
+    tab = Trajectory(len(g["table"]), int(g["ttl_num"]), tuple(g["origin"]))
+    tab.points = g["table"].copy()
+    save_ttl(str(tmp_path / "a.ttl"), tab)
+    Trajectory.save(str(tmp_path / "a.csv"), tab)
+    assert open(tmp_path / "a.ttl", "rb").read() == open(os.path.join(GOLDEN, "G10_ref.ttl"), "rb").read()
+    assert open(tmp_path / "a.csv", "rb").read() == open(os.path.join(GOLDEN, "G10_ref_table.csv"), "rb").read()
+    back = load_ttl(os.path.join(GOLDEN, "G10_ref.ttl"))
+    np.testing.assert_array_equal(back.points, g["ttl_loaded"])
+    assert back.ttl_num == int(g["ttl_loaded_num"]) and tuple(back.origin) == tuple(g["ttl_loaded_origin"])
+    np.testing.assert_array_equal(Trajectory.load(os.path.join(GOLDEN, "G10_ref_table.csv")).points, g["table"])
+    sp = BSplineTrajectory.load(os.path.join(GOLDEN, "G10_ref_spline.pkl"))     # pickled by the reference's class
+    assert isinstance(sp, mirror.BSplineTrajectory)
+    f = golden("G1_spline_fits.npz")
+    np.testing.assert_array_equal(sp._spl_x.t, f["c100_t"]); np.testing.assert_array_equal(sp._spl_x.c, f["c100_cx"])
+    np.testing.assert_array_equal(sp._spl_y.c, f["c100_cy"]); assert sp.get_length() == float(f["c100_length"])
+    cp = sp.copy(); cp.set_control_point(7, (1.0, 2.0))
+    assert cp.get_control_point(7) == (1.0, 2.0) and sp.get_control_point(7) != (1.0, 2.0)
+    # the other module paths of the reference resolve too
+    from spline_traj_optm.models.race_track import RaceTrack  # noqa: F401
+    from spline_traj_optm.models.vehicle import Vehicle, VehicleParams  # noqa: F401
+    from spline_traj_optm.optimization.optimizer import TrajectoryOptimizer  # noqa: F401
+    from spline_traj_optm.simulator.simulator import Simulator  # noqa: F401

@@ -299,3 +299,72 @@ def test_g5_joint_assembly(fits, rings):
         uba[0::2] = np.maximum(pts[:, 9], pts[:, 11]) - non_z[:, 0]; uba[1::2] = np.maximum(pts[:, 10], pts[:, 12]) - non_z[:, 1]
         np.testing.assert_allclose(lba, g5[f"s{st}_lba"], rtol=0, atol=1e-9)
         np.testing.assert_allclose(uba, g5[f"s{st}_uba"], rtol=0, atol=1e-9)
+
+
+def test_g8_double_track_checker_vs_reference_functions():
+    """oracle/dt_checker.py against fixture G8 = the reference's OWN models/double_track.py (dynamics,
+    add_constraints), utils/utils.py (align_yaw, align_abscissa) and min_time_optimizer.py
+    (set_up_double_track_problem: pairing of node i-1 with node i, variable scaling, cost) executed on
+    numbers through a numeric stand-in for CasADi (tests/golden/make_golden.py)."""
+    from oracle import dt_checker as dc
+    g = golden("G8_double_track.npz")
+    m = dict(zip(g["model_keys"].tolist(), g["model_vals"].tolist()))
+    xd, (Fx, Fy, Fz) = dc.dynamics(m, g["dyn_X"], g["dyn_U"], g["dyn_k"])
+    np.testing.assert_allclose(xd, g["dyn_xdot_frenet"], rtol=1e-13, atol=1e-12)
+    np.testing.assert_allclose(np.stack([Fx, Fy, Fz], axis=1), g["dyn_tyre_forces"], rtol=1e-13, atol=1e-10)
+    xd0, _ = dc.dynamics(m, g["dyn_X"], g["dyn_U"], np.zeros(len(g["dyn_k"])))   # race_track=None: no curvilinear terms
+    np.testing.assert_allclose(xd0, g["dyn_xdot_plain"], rtol=1e-13, atol=1e-12)
+    eq, ineq, cost = dc.eval_nodes(m, g["nlp_s"], g["nlp_kappa"], g["nlp_left"], g["nlp_right"], float(g["nlp_margin"]),
+                                   float(g["nlp_length"]), g["nlp_X"][None], g["nlp_U"][None], g["nlp_T"][None])
+    np.testing.assert_allclose(eq[0], g["nlp_eq"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ineq[0], g["nlp_ineq"], rtol=1e-13, atol=1e-12)
+    assert abs(cost[0] - float(g["nlp_cost"])) < 1e-12 * abs(cost[0])
+    assert abs(g["nlp_eq"][5, 7] - 0.3) < 1e-12 and np.abs(g["nlp_eq"][:, :6]).max() > 1e-3   # a point off the constraints
+
+
+def test_g9_run_joint_min_curvature_qp(fits, rings):
+    """The oracle's sliding-window driver against fixture G9 = the reference's own
+    run_joint_min_curvature_qp loop (optimizer.py:163-220; window QPs solved by the oracle's dual active-set
+    solver standing in for casadi.conic/qpOASES, simulator called per window as in the reference).  On the
+    cases flagged well-conditioned the lines agree to 1e-6 m with equal window counts; the chaotic case is
+    only required to be explained by the oracle's own re-roundings."""
+    g = golden("G9_run_joint_min_curvature_qp.npz")
+    t, cx, cy, k, length = spline(fits, "c100")
+    n_good = 0
+    for key in g["cases"]:
+        key = str(key)
+        N = int(key.split("_")[1][1:])
+        ist = g[f"{key}_i_start"]
+        ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist)
+        dev = np.hypot(ocx - g[f"{key}_cx"], ocy - g[f"{key}_cy"]).max()
+        if bool(g[f"{key}_well_conditioned"]):
+            assert dev < 1e-6 and int(ons.sum()) == int(g[f"{key}_n_ok"]), (key, dev, ons)
+            n_good += 1
+        else:
+            spread = 0.0
+            for seed in range(1, 7):
+                rcx, rcy, _, _ = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist, rerounding=seed)
+                spread = max(spread, np.hypot(rcx - ocx, rcy - ocy).max())
+            assert spread > 1e-4 and dev <= 10.0 * spread, (key, dev, spread)
+    assert n_good >= 5
+
+
+def test_replay_of_the_first_steps_equals_the_plain_pipeline(fits, rings):
+    """orc.replay_steps (the teacher-forced single-step re-derivation used by tests/test_sweep_replay.py) on
+    the initial control points equals cost + constraint + QP computed through the plain wrappers."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    N = 400
+    idx = np.arange(2, len(cx) - 3, dtype=np.int32)
+    rep = orc.replay_steps(t, k, N, rings[0], rings[1], idx, np.tile(cx, (len(idx), 1)), np.tile(cy, (len(idx), 1)), nthreads=4)
+    pts = orc.sample_along(t, cx, cy, k, length, np.linspace(0, 1, N, endpoint=False))
+    orc.fill_bounds(pts, rings[0], rings[1])
+    for j, i in enumerate(idx):
+        H, gg, M = orc.min_curvature_cost(np.array([cx[i], cy[i]]), int(i), t, cx, cy, k, N)
+        A, l, u = orc.track_constraint(int(i), t, cx, cy, k, pts)
+        st, x = orc.qp_solve_separable(H, gg, A, l, u)
+        assert st == rep[j, 0] and M == rep[j, 16]
+        assert H[0, 0] == rep[j, 1] and H[1, 1] == rep[j, 2] and gg[0] == rep[j, 3] and gg[1] == rep[j, 4]
+        if st == 0:
+            assert x[0] == rep[j, 9] and x[1] == rep[j, 10]
+            assert rep[j, 5] <= x[0] <= rep[j, 6] and rep[j, 7] <= x[1] <= rep[j, 8]
+    assert (rep[:, 11:15] > 0).all() and (rep[:, 11:15] < 1.0).all()
