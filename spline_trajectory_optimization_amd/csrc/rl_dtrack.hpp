@@ -44,28 +44,33 @@ struct DtArgs {
 };
 
 // ---- scalar types: double for the values, Dual<ND> (value + ND directional derivatives, forward
-// mode) for the Jacobian.  The model code below is written once against these overloads.
-template <int ND>
+// mode) for the Jacobian, and Dual<ND, Dual<ND>> (forward over forward) for second derivatives -- the
+// Hessian of the Lagrangian the min-time solver needs (rl_mintime.hpp).  The model code below is written
+// once against these overloads; every operation is generic in the component type T.
+template <int ND, typename T = double>
 struct Dual {
-  double v;
-  double d[ND];
+  T v;
+  T d[ND];
 };
 #define RL_DUAL_FOR for (int i_ = 0; i_ < ND; ++i_)
-template <int ND> __device__ __forceinline__ Dual<ND> mk(double v) { Dual<ND> r; r.v = v; RL_DUAL_FOR r.d[i_] = 0.0; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator+(Dual<ND> a, Dual<ND> b) { a.v += b.v; RL_DUAL_FOR a.d[i_] += b.d[i_]; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(Dual<ND> a, Dual<ND> b) { a.v -= b.v; RL_DUAL_FOR a.d[i_] -= b.d[i_]; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(Dual<ND> a) { a.v = -a.v; RL_DUAL_FOR a.d[i_] = -a.d[i_]; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(Dual<ND> a, Dual<ND> b) { Dual<ND> r; r.v = a.v * b.v; RL_DUAL_FOR r.d[i_] = a.d[i_] * b.v + a.v * b.d[i_]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator/(Dual<ND> a, Dual<ND> b) { Dual<ND> r; const double ib = 1.0 / b.v; r.v = a.v * ib; RL_DUAL_FOR r.d[i_] = (a.d[i_] - r.v * b.d[i_]) * ib; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator+(Dual<ND> a, double b) { a.v += b; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator+(double b, Dual<ND> a) { a.v += b; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(Dual<ND> a, double b) { a.v -= b; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(double b, Dual<ND> a) { a.v = b - a.v; RL_DUAL_FOR a.d[i_] = -a.d[i_]; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(Dual<ND> a, double b) { a.v *= b; RL_DUAL_FOR a.d[i_] *= b; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(double b, Dual<ND> a) { a.v *= b; RL_DUAL_FOR a.d[i_] *= b; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator/(Dual<ND> a, double b) { const double ib = 1.0 / b; a.v *= ib; RL_DUAL_FOR a.d[i_] *= ib; return a; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator/(double b, Dual<ND> a) { Dual<ND> r; r.v = b / a.v; const double f = -r.v / a.v; RL_DUAL_FOR r.d[i_] = f * a.d[i_]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> chain(Dual<ND> a, double v, double dv) { a.v = v; RL_DUAL_FOR a.d[i_] *= dv; return a; }
+#define RL_DT template <int ND, typename T> __device__ __forceinline__
+__device__ __forceinline__ double m_val(double x) { return x; }
+RL_DT double m_val(const Dual<ND, T>& x) { return m_val(x.v); }
+RL_DT Dual<ND, T> operator+(Dual<ND, T> a, const Dual<ND, T>& b) { a.v = a.v + b.v; RL_DUAL_FOR a.d[i_] = a.d[i_] + b.d[i_]; return a; }
+RL_DT Dual<ND, T> operator-(Dual<ND, T> a, const Dual<ND, T>& b) { a.v = a.v - b.v; RL_DUAL_FOR a.d[i_] = a.d[i_] - b.d[i_]; return a; }
+RL_DT Dual<ND, T> operator-(Dual<ND, T> a) { a.v = -a.v; RL_DUAL_FOR a.d[i_] = -a.d[i_]; return a; }
+RL_DT Dual<ND, T> operator*(const Dual<ND, T>& a, const Dual<ND, T>& b) { Dual<ND, T> r; r.v = a.v * b.v; RL_DUAL_FOR r.d[i_] = a.d[i_] * b.v + a.v * b.d[i_]; return r; }
+RL_DT Dual<ND, T> operator/(const Dual<ND, T>& a, const Dual<ND, T>& b) { Dual<ND, T> r; const T ib = 1.0 / b.v; r.v = a.v * ib; RL_DUAL_FOR r.d[i_] = (a.d[i_] - r.v * b.d[i_]) * ib; return r; }
+RL_DT Dual<ND, T> operator+(Dual<ND, T> a, double b) { a.v = a.v + b; return a; }
+RL_DT Dual<ND, T> operator+(double b, Dual<ND, T> a) { a.v = a.v + b; return a; }
+RL_DT Dual<ND, T> operator-(Dual<ND, T> a, double b) { a.v = a.v - b; return a; }
+RL_DT Dual<ND, T> operator-(double b, Dual<ND, T> a) { a.v = b - a.v; RL_DUAL_FOR a.d[i_] = -a.d[i_]; return a; }
+RL_DT Dual<ND, T> operator*(Dual<ND, T> a, double b) { a.v = a.v * b; RL_DUAL_FOR a.d[i_] = a.d[i_] * b; return a; }
+RL_DT Dual<ND, T> operator*(double b, Dual<ND, T> a) { a.v = a.v * b; RL_DUAL_FOR a.d[i_] = a.d[i_] * b; return a; }
+RL_DT Dual<ND, T> operator/(Dual<ND, T> a, double b) { const double ib = 1.0 / b; a.v = a.v * ib; RL_DUAL_FOR a.d[i_] = a.d[i_] * ib; return a; }
+RL_DT Dual<ND, T> operator/(double b, const Dual<ND, T>& a) { Dual<ND, T> r; r.v = b / a.v; const T f = -(r.v / a.v); RL_DUAL_FOR r.d[i_] = f * a.d[i_]; return r; }
+// f(a) with f(a.v) = v and f'(a.v) = dv given in the component type
+RL_DT Dual<ND, T> chain(Dual<ND, T> a, const T& v, const T& dv) { a.v = v; RL_DUAL_FOR a.d[i_] = a.d[i_] * dv; return a; }
 __device__ __forceinline__ double m_sin(double x) { return sin(x); }
 __device__ __forceinline__ double m_cos(double x) { return cos(x); }
 __device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
@@ -74,20 +79,19 @@ __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
 __device__ __forceinline__ double m_fmod(double x, double m) { return fmod(x, m); }
 __device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
-__device__ __forceinline__ double m_val(double x) { return x; }
-template <int ND> __device__ __forceinline__ Dual<ND> m_sin(Dual<ND> x) { return chain(x, sin(x.v), cos(x.v)); }
-template <int ND> __device__ __forceinline__ Dual<ND> m_cos(Dual<ND> x) { return chain(x, cos(x.v), -sin(x.v)); }
-template <int ND> __device__ __forceinline__ Dual<ND> m_tanh(Dual<ND> x) { const double t = tanh(x.v); return chain(x, t, 1.0 - t * t); }
-template <int ND> __device__ __forceinline__ Dual<ND> m_atan(Dual<ND> x) { return chain(x, atan(x.v), 1.0 / (1.0 + x.v * x.v)); }
-template <int ND> __device__ __forceinline__ Dual<ND> m_abs(Dual<ND> x) { return chain(x, fabs(x.v), x.v < 0.0 ? -1.0 : 1.0); }
-template <int ND> __device__ __forceinline__ Dual<ND> m_atan2(Dual<ND> y, Dual<ND> x) {
-  Dual<ND> r; r.v = atan2(y.v, x.v); const double q = 1.0 / (x.v * x.v + y.v * y.v);
+RL_DT Dual<ND, T> m_sin(const Dual<ND, T>& x) { return chain(x, m_sin(x.v), m_cos(x.v)); }
+RL_DT Dual<ND, T> m_cos(const Dual<ND, T>& x) { return chain(x, m_cos(x.v), -m_sin(x.v)); }
+RL_DT Dual<ND, T> m_tanh(const Dual<ND, T>& x) { const T t = m_tanh(x.v); return chain(x, t, 1.0 - t * t); }
+RL_DT Dual<ND, T> m_atan(const Dual<ND, T>& x) { return chain(x, m_atan(x.v), 1.0 / (1.0 + x.v * x.v)); }
+RL_DT Dual<ND, T> m_abs(Dual<ND, T> x) { const double sg = m_val(x.v) < 0.0 ? -1.0 : 1.0; x.v = m_abs(x.v); RL_DUAL_FOR x.d[i_] = x.d[i_] * sg; return x; }
+RL_DT Dual<ND, T> m_atan2(const Dual<ND, T>& y, const Dual<ND, T>& x) {
+  Dual<ND, T> r; r.v = m_atan2(y.v, x.v); const T q = 1.0 / (x.v * x.v + y.v * y.v);
   RL_DUAL_FOR r.d[i_] = (x.v * y.d[i_] - y.v * x.d[i_]) * q; return r;
 }
-template <int ND> __device__ __forceinline__ Dual<ND> m_fmod(Dual<ND> x, double m) { x.v = fmod(x.v, m); return x; }
-template <int ND> __device__ __forceinline__ Dual<ND> m_max(Dual<ND> a, Dual<ND> b) { return a.v >= b.v ? a : b; }
-template <int ND> __device__ __forceinline__ double m_val(Dual<ND> x) { return x.v; }
+RL_DT Dual<ND, T> m_fmod(Dual<ND, T> x, double m) { x.v = m_fmod(x.v, m); return x; }
+RL_DT Dual<ND, T> m_max(const Dual<ND, T>& a, const Dual<ND, T>& b) { return m_val(a) >= m_val(b) ? a : b; }
 #undef RL_DUAL_FOR
+#undef RL_DT
 
 template <typename S>
 struct DtTyres { S fx[4], fy[4], fz[4]; };  // fl, fr, rl, rr

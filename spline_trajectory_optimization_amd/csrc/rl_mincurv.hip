@@ -19,6 +19,7 @@
 #include "rl_global.hpp"
 #include "rl_global2.hpp"
 #include "rl_dtrack.hpp"
+#include "rl_mintime.hpp"
 
 namespace {
 
@@ -925,6 +926,86 @@ int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double*
   RL_HIP(hipMemcpyAsync(jac_ineq, dji.p, dji.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipMemcpyAsync(grad_cost, dgc.p, dgc.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipStreamSynchronize(ctx->stream));
+  return RL_OK;
+}
+
+int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
+                           const double* left, const double* right, int bounds_per_instance, double margin,
+                           double track_length, double average_track_width, double speed_cap, double* X, double* U,
+                           double* T, int max_iter, double tol, double* stats) {
+  if (!ctx || !model || !s || !kappa || !left || !right || !X || !U || !T || !stats) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0 || N < 4 || !(track_length > 0.0) || max_iter < 1 || !(tol > 0.0)) return fail(RL_ERR_ARG, "bad sizes");
+  if (!(average_track_width > 0.0) || !(speed_cap > 0.0)) return fail(RL_ERR_ARG, "bad scales");
+  RL_HIP(hipSetDevice(ctx->device));
+  rl::MtProblem P;
+  for (int i = 0; i < rl::DT_NPARAM; ++i) P.p[i] = model[i];
+  P.N = N; P.bounds_per_instance = bounds_per_instance ? 1 : 0;
+  P.margin = margin; P.track_length = track_length;
+  // min_time_optimizer.py:109-113: scale_x = (1, average_track_width, 1, 1, 0.5, speed_cap),
+  // scale_u = (Fd_max, |Fb_max|, delta_max, 50 mass), scale_t = 1
+  const double sx[6] = {1.0, average_track_width, 1.0, 1.0, 0.5, speed_cap};
+  const double su[4] = {model[RL_DT_FD_MAX], std::fabs(model[RL_DT_FB_MAX]), model[RL_DT_DELTA_MAX], model[RL_DT_MASS] * 50.0};
+  for (int c = 0; c < 5; ++c) P.sw[c] = sx[1 + c];
+  P.sw[5] = su[0]; P.sw[6] = su[2]; P.sw[7] = su[3]; P.sw[8] = 1.0;
+  for (int c = 0; c < 6; ++c) P.se[c] = 1.0 / sx[c];
+  P.se[6] = 1.0 / su[3];
+  const size_t bn = (size_t)B * N, nb_ = bounds_per_instance ? bn : (size_t)N;
+  for (size_t i = 0; i < nb_; ++i)
+    if (!(right[i] + margin < left[i] - margin)) return fail(RL_ERR_ARG, "track narrower than the vehicle plus margins (min_time_optimizer.py:135)");
+  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, w, sv, yv, zv, fun, jac, hes, dw, dy, blk, vec, scal;
+  RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(nb_)); RL_HIP(dr.alloc(nb_));
+  RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn));
+  RL_HIP(w.alloc(bn * rl::kMtNv)); RL_HIP(sv.alloc(bn * rl::kMtNi)); RL_HIP(yv.alloc(bn * rl::kMtNe)); RL_HIP(zv.alloc(bn * rl::kMtNi));
+  RL_HIP(fun.alloc(bn * rl::kMtNf)); RL_HIP(jac.alloc(bn * rl::kMtNf * rl::kMtLoc)); RL_HIP(hes.alloc(bn * rl::kMtLoc * rl::kMtLoc));
+  RL_HIP(dw.alloc(bn * rl::kMtNv)); RL_HIP(dy.alloc(bn * rl::kMtNe)); RL_HIP(blk.alloc(bn * 3 * 256)); RL_HIP(vec.alloc(bn * 16));
+  RL_HIP(scal.alloc((size_t)B * 16));
+  auto up = [&](DevBuf<double>& d, const double* h) { return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream); };
+  RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
+  RL_HIP(up(dX, X)); RL_HIP(up(dU, U)); RL_HIP(up(dT, T));
+  P.s = ds.p; P.kappa = dk.p; P.left = dl.p; P.right = dr.p;
+  rl::MtState st;
+  st.B = B; st.N = N; st.w = w.p; st.s = sv.p; st.y = yv.p; st.z = zv.p; st.fun = fun.p; st.jac = jac.p; st.hes = hes.p;
+  st.dw = dw.p; st.dy = dy.p; st.blk = blk.p; st.vec = vec.p; st.scal = scal.p; st.tol = tol;
+  RL_HIP(hipMemsetAsync(scal.p, 0, scal.n * sizeof(double), ctx->stream));
+  RL_HIP(hipMemsetAsync(hes.p, 0, hes.n * sizeof(double), ctx->stream));
+  const dim3 gn((N + 63) / 64, B), bn64(64);
+  hipLaunchKernelGGL(rl::k_mt_pack, gn, bn64, 0, ctx->stream, P, st, (const double*)dX.p, (const double*)dU.p, (const double*)dT.p);
+  hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, ctx->stream, P, st);
+  hipLaunchKernelGGL(rl::k_mt_init, dim3((N * rl::kMtNi + 255) / 256, B), dim3(256), 0, ctx->stream, P, st, 1e-1, 1e-4);
+  RL_HIP(hipGetLastError());
+  for (int it = 0; it < max_iter; ++it) {
+    hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, ctx->stream, P, st);
+    hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, B, rl::kMtJacSlices), bn64, 0, ctx->stream, P, st);
+    hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, B, rl::kMtHesSlices), bn64, 0, ctx->stream, P, st);
+    hipLaunchKernelGGL(rl::k_mt_kkt, dim3(B), dim3(64), 0, ctx->stream, P, st);
+    hipLaunchKernelGGL(rl::k_mt_step, dim3(B), dim3(256), 0, ctx->stream, P, st);
+    if ((it & 7) == 7) {   // every 8 iterations: stop early once every instance has finished
+      std::vector<double> h((size_t)B * 16);
+      RL_HIP(hipMemcpyAsync(h.data(), scal.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      RL_HIP(hipStreamSynchronize(ctx->stream));
+      bool all = true;
+      for (int b = 0; b < B; ++b) all = all && h[(size_t)b * 16 + 5] != 0.0;
+      if (all) break;
+    }
+  }
+  // final residuals of the instances still running (status 0 = iteration limit)
+  hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, ctx->stream, P, st);
+  hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, B, rl::kMtJacSlices), bn64, 0, ctx->stream, P, st);
+  hipLaunchKernelGGL(rl::k_mt_residuals, dim3(B), dim3(64), 0, ctx->stream, P, st);
+  hipLaunchKernelGGL(rl::k_mt_unpack, gn, bn64, 0, ctx->stream, P, st, dX.p, dU.p, dT.p);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(X, dX.p, dX.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(U, dU.p, dU.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(T, dT.p, dT.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<double> h((size_t)B * 16);
+  RL_HIP(hipMemcpyAsync(h.data(), scal.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < B; ++b) {
+    const double* q = &h[(size_t)b * 16];
+    double* o = stats + (size_t)b * 12;
+    o[0] = q[6]; o[1] = q[2]; o[2] = q[3]; o[3] = q[4]; o[4] = q[11]; o[5] = q[5]; o[6] = q[0]; o[7] = q[1];
+    o[8] = q[7]; o[9] = q[10]; o[10] = 0.0; o[11] = 0.0;
+  }
   return RL_OK;
 }
 

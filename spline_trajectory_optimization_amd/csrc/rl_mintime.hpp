@@ -1,0 +1,730 @@
+// rl_mintime.hpp -- the SOLVE of the min-time double-track NLP (BASELINE config 5):
+// a batched primal-dual interior-point SQP-type iteration, one QP subproblem per iteration.
+//
+// The NLP is the reference's: min_time_optm/min_time_optimizer.py:93-163 (variables, scaling :109-113,
+// objective :119-123, node pairing, bounds) with models/double_track.py:10-204 (dynamics, Hermite-Simpson
+// defect, tyre ellipses, load transfer, actuator limits).  The reference gives it to IPOPT through
+// casadi.Opti (:158-161); IPOPT is a third-party solver absent from this image, so what is built here is
+// the same kind of method written for the GPU (CPU twin: oracle/sqp_twin.py, same iteration, independent
+// derivatives and linear algebra):
+//
+//   per node j, 9 scaled unknowns  w_j = (n, xi, omega, beta, v | F, delta, gamma | t) / scale
+//       (the abscissa is pinned by an equality, u[1] only enters the objective: both eliminated)
+//   7 equalities    Hermite-Simpson defect with node j+1 (6), load-transfer residual          c_j(w_j, w_j+1) = 0
+//   17 inequalities tyre ellipses (4), power, v >= 1, force / steer limits, force / steer RATE limits
+//       (two rows each), lateral limits, t >= 0                                   g_j(w_j, w_j+1) + s_j = 0, s_j > 0
+//
+//   every iteration:  k_mt_derivs   functions, Jacobians (forward duals) and the EXACT Hessian of the pair
+//                                   Lagrangians (forward over forward duals) through the templated model code
+//                     k_mt_kkt      the barrier QP  [K  A'; A  -eps I] [dw; dy] = rhs  with
+//                                   K = H_cost + Hess + G' S^-1 Z G + delta I: block tridiagonal and CYCLIC
+//                                   (closed lap), 16 x 16 blocks (9 unknowns + 7 multipliers per node),
+//                                   factorised node by node (block LDL' without pivoting; the lap closure is
+//                                   a border block row carried along); the count of negative pivots
+//                                   (7 N of 16 N) is the inertia test that drives delta
+//                     k_mt_step     fraction-to-the-boundary rule, backtracking against a filter on
+//                                   (infeasibility, barrier objective), update of w, s, y, z, delta
+//   One wave per instance in k_mt_kkt (every 16 x 16 block lives in LDS, 4 entries per lane; the block
+//   products run on the matrix cores: v_mfma_f64_16x16x4_f64), one thread per (instance, node, slice) in
+//   k_mt_derivs, one workgroup per instance in k_mt_step.
+#pragma once
+#include "rl_dtrack.hpp"
+#include "rl_device.hpp"
+
+namespace rl {
+
+constexpr int kMtNv = 9, kMtNe = 7, kMtNi = 17, kMtNf = kMtNe + kMtNi, kMtNb = kMtNv + kMtNe;  // 16
+constexpr int kMtLoc = 2 * kMtNv;  // 18 local unknowns of a pair: own 9 + next node's 9
+constexpr int kMtJacSlices = kMtLoc / 3, kMtHesGroups = kMtLoc / 3;
+constexpr int kMtHesSlices = kMtHesGroups * (kMtHesGroups + 1) / 2;   // 21 pairs of direction groups
+constexpr int kMtSlices = 1 + kMtJacSlices + kMtHesSlices;            // 28
+constexpr double kMtEpsReg = 1e-8;  // dual regularisation of the KKT system
+constexpr double kMtCostDiag = 2e-4 + 4e-1, kMtCostOff = -2e-1;  // Hessian of 1e-4 |U|^2 + 1e-1 |dU|^2 (:119-123)
+
+struct MtProblem {
+  double p[DT_NPARAM];
+  int N;
+  const double* s; const double* kappa; const double* left; const double* right;  // [N]
+  int bounds_per_instance;   // left / right are [B,N] instead of [N]
+  double margin, track_length;
+  double sw[kMtNv];   // scale of the unknowns: scale_x[1..5], scale_u[0,2,3], 1
+  double se[kMtNe];   // row scale of the equalities: 1 / scale_x (6), 1 / scale_u[3]
+};
+
+template <typename S> struct MtLift;
+template <> struct MtLift<double> { static __device__ __forceinline__ double make(double v) { return v; } };
+template <int ND, typename T> struct MtLift<Dual<ND, T>> {
+  static __device__ __forceinline__ Dual<ND, T> make(double v) {
+    Dual<ND, T> r; r.v = MtLift<T>::make(v);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = MtLift<T>::make(0.0);
+    return r;
+  }
+};
+
+// eq (7, row-scaled) and g (17, row-scaled) of the pair (j, j+1) from the scaled unknowns of both nodes
+template <typename S>
+__device__ __forceinline__ void mt_pair(const MtProblem& P, int j, const S (&wo)[kMtNv], const S (&wn)[kMtNv],
+                                        S (&eq)[kMtNe], S (&g)[kMtNi]) {
+  const double* p = P.p;
+  const int jn = j + 1 == P.N ? 0 : j + 1;
+  S x[6], xn[6], u[4], un[4];
+  x[0] = MtLift<S>::make(P.s[j]); xn[0] = MtLift<S>::make(P.s[jn]);
+#pragma unroll
+  for (int c = 0; c < 5; ++c) { x[1 + c] = wo[c] * P.sw[c]; xn[1 + c] = wn[c] * P.sw[c]; }
+  u[0] = wo[5] * P.sw[5]; u[1] = MtLift<S>::make(0.0); u[2] = wo[6] * P.sw[6]; u[3] = wo[7] * P.sw[7];
+  un[0] = wn[5] * P.sw[5]; un[1] = MtLift<S>::make(0.0); un[2] = wn[6] * P.sw[6]; un[3] = wn[7] * P.sw[7];
+  const S t = wo[8] * P.sw[8];
+  const double k = P.kappa[j];
+  {  // utils/utils.py:10-18
+    const S d = xn[2] - x[2];
+    xn[2] = m_atan2(m_sin(d), m_cos(d)) + x[2];
+    const S ds = x[0] - xn[0], kk = m_abs(ds) + P.track_length / 2.0;
+    xn[0] = xn[0] + (kk - m_fmod(kk, P.track_length)) * dt_sign(m_val(ds));
+  }
+  S f1[6], f2[6], fm[6], xm[6];
+  DtTyres<S> ty, ty2;
+  dt_dynamics(p, x, u, k, f1, ty);
+  dt_dynamics(p, xn, u, k, f2, ty2);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) xm[c] = 0.5 * (x[c] + xn[c]) + (t / 8.0) * (f1[c] - f2[c]);
+  dt_dynamics(p, xm, u, k, fm, ty2);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) eq[c] = (x[c] + (t / 6.0) * (f1[c] + 4.0 * fm[c] + f2[c]) - xn[c]) * P.se[c];
+  const S delta = u[2], gam = u[3], v = x[5];
+  eq[6] = (gam - p[DT_HCOG] / (0.5 * (p[DT_TWF] + p[DT_TWR])) *
+                     (ty.fy[2] + ty.fy[3] + (ty.fx[0] + ty.fx[1]) * m_sin(delta) + (ty.fy[0] + ty.fy[1]) * m_cos(delta))) * P.se[6];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const S qx = ty.fx[w] / (p[DT_MU] * ty.fz[w]), qy = ty.fy[w] / (p[DT_MU] * ty.fz[w]);
+    g[w] = qx * qx + qy * qy - 1.0;
+  }
+  const S fd = u[0] * (m_tanh(u[0]) * 0.5 + 0.5);
+  const double su0 = P.sw[5], su2 = P.sw[6], sx1 = P.sw[0], sx5 = P.sw[4];
+  g[4] = (v * fd - p[DT_PMAX]) / p[DT_PMAX];
+  g[5] = (1.0 - v) / sx5;
+  g[6] = (p[DT_FB_MAX] - u[0]) / su0; g[7] = (u[0] - p[DT_FD_MAX]) / su0;
+  g[8] = (-p[DT_DELTA_MAX] - delta) / su2; g[9] = (delta - p[DT_DELTA_MAX]) / su2;
+  const S ru = (un[0] - u[0]) / t, rd = (un[2] - delta) / t;
+  g[10] = (p[DT_FB_MAX] / p[DT_TB] - ru) / su0; g[11] = (ru - p[DT_FD_MAX] / p[DT_TD]) / su0;
+  g[12] = (-p[DT_DELTA_MAX] / p[DT_TDELTA] - rd) / su2; g[13] = (rd - p[DT_DELTA_MAX] / p[DT_TDELTA]) / su2;
+  g[14] = ((P.right[j] + P.margin) - x[1]) / sx1; g[15] = (x[1] - (P.left[j] - P.margin)) / sx1;
+  g[16] = -t;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct MtState {       // per-batch device arrays, instance-major
+  int B, N;
+  double* w;      // [B,N,9]  scaled unknowns
+  double* s;      // [B,N,17] slacks
+  double* y;      // [B,N,7]  equality multipliers
+  double* z;      // [B,N,17] inequality multipliers
+  double* fun;    // [B,N,24] eq | g at w
+  double* jac;    // [B,N,24,18]
+  double* hes;    // [B,N,18,18] Hessian of y.eq + z.g of the pair
+  double* dw;     // [B,N,9]
+  double* dy;     // [B,N,7]
+  double* blk;    // [B,N,3,256] factor blocks: S^-1, P, Q
+  double* vec;    // [B,N,16] right-hand side / solution scratch
+  double* scal;   // [B,16] per-instance scalars: 0 mu, 1 delta, 2 kkt, 3 viol, 4 compl, 5 status (0 run, 1 converged,
+                  //        2 failed), 6 iterations, 7 last alpha, 8 theta0, 9 phi0, 10 refactorisations, 11 lap time
+  double tol;
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mt_instance(MtProblem& P, int b) {
+  if (P.bounds_per_instance) { P.left += (size_t)b * P.N; P.right += (size_t)b * P.N; }
+}
+
+// k_mt_derivs<KIND>: one thread per (node, instance, slice).  KIND 0: functions (1 slice), 1: Jacobian (6 slices
+// of three directions), 2: Hessian (21 slices = pairs of direction groups) -- three kernels, so that the cheap
+// ones do not inherit the register budget of the forward-over-forward one.
+template <int KIND>
+__global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  const int slice = KIND == 0 ? 0 : (KIND == 1 ? 1 + (int)blockIdx.z : 1 + kMtJacSlices + (int)blockIdx.z);
+  if (j >= P.N) return;
+  if (st.scal[(size_t)b * 16 + 5] != 0.0) return;   // instance finished
+  mt_instance(P, b);
+  const int N = P.N, jn = j + 1 == N ? 0 : j + 1;
+  const double* wo_ = st.w + ((size_t)b * N + j) * kMtNv;
+  const double* wn_ = st.w + ((size_t)b * N + jn) * kMtNv;
+  const size_t o = (size_t)b * N + j;
+  if (KIND == 0) {
+    double wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
+#pragma unroll
+    for (int a = 0; a < kMtNv; ++a) { wo[a] = wo_[a]; wn[a] = wn_[a]; }
+    mt_pair<double>(P, j, wo, wn, eq, g);
+#pragma unroll
+    for (int c = 0; c < kMtNe; ++c) st.fun[o * kMtNf + c] = eq[c];
+#pragma unroll
+    for (int c = 0; c < kMtNi; ++c) st.fun[o * kMtNf + kMtNe + c] = g[c];
+  } else if (KIND == 1) {
+    using D = Dual<3>;
+    const int v0 = 3 * (slice - 1);
+    D wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
+#pragma unroll
+    for (int a = 0; a < kMtNv; ++a) {
+      wo[a].v = wo_[a]; wn[a].v = wn_[a];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { wo[a].d[i] = (a == v0 + i) ? 1.0 : 0.0; wn[a].d[i] = (kMtNv + a == v0 + i) ? 1.0 : 0.0; }
+    }
+    mt_pair<D>(P, j, wo, wn, eq, g);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int c = 0; c < kMtNe; ++c) st.jac[(o * kMtNf + c) * kMtLoc + v0 + i] = eq[c].d[i];
+#pragma unroll
+      for (int c = 0; c < kMtNi; ++c) st.jac[(o * kMtNf + kMtNe + c) * kMtLoc + v0 + i] = g[c].d[i];
+    }
+  } else {
+    // Hessian of L = y . eq + z . g: direction groups (ga <= gb) of three unknowns each
+    int q = slice - 1 - kMtJacSlices, ga = 0;
+    while (q >= kMtHesGroups - ga) { q -= kMtHesGroups - ga; ++ga; }
+    const int gb = ga + q;
+    using D1 = Dual<3>;
+    using D2 = Dual<3, D1>;
+    D2 wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
+    auto seed = [&](D2& r, double val, int var) {
+      r.v.v = val;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        r.v.d[i] = (var == 3 * ga + i) ? 1.0 : 0.0;          // inner directions: group a
+        r.d[i].v = (var == 3 * gb + i) ? 1.0 : 0.0;          // outer directions: group b
+#pragma unroll
+        for (int q2 = 0; q2 < 3; ++q2) r.d[i].d[q2] = 0.0;
+      }
+    };
+#pragma unroll
+    for (int a = 0; a < kMtNv; ++a) { seed(wo[a], wo_[a], a); seed(wn[a], wn_[a], kMtNv + a); }
+    mt_pair<D2>(P, j, wo, wn, eq, g);
+    double h[3][3] = {};
+    const double* y = st.y + o * kMtNe;
+    const double* z = st.z + o * kMtNi;
+#pragma unroll
+    for (int c = 0; c < kMtNe; ++c) {
+      const double m = y[c];
+#pragma unroll
+      for (int ib = 0; ib < 3; ++ib)
+#pragma unroll
+        for (int ia = 0; ia < 3; ++ia) h[ib][ia] += m * eq[c].d[ib].d[ia];
+    }
+#pragma unroll
+    for (int c = 0; c < kMtNi; ++c) {
+      const double m = z[c];
+#pragma unroll
+      for (int ib = 0; ib < 3; ++ib)
+#pragma unroll
+        for (int ia = 0; ia < 3; ++ia) h[ib][ia] += m * g[c].d[ib].d[ia];
+    }
+    double* H = st.hes + o * kMtLoc * kMtLoc;
+#pragma unroll
+    for (int ib = 0; ib < 3; ++ib)
+#pragma unroll
+      for (int ia = 0; ia < 3; ++ia) {
+        H[(3 * gb + ib) * kMtLoc + 3 * ga + ia] = h[ib][ia];
+        H[(3 * ga + ia) * kMtLoc + 3 * gb + ib] = h[ib][ia];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16 x 16 blocks in LDS, row major, one wave: entry e = lane + 64 r, r = 0..3
+__device__ __forceinline__ void mt_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// C (+)= sign * A * B^T  (TB = true)  or  sign * A * B (TB = false); all 16 x 16 in LDS.  On the matrix cores:
+// four v_mfma_f64_16x16x4_f64, lane l supplies A[l & 15][4 kk + (l >> 4)] and B'[4 kk + (l >> 4)][l & 15];
+// its four results are rows (l >> 4) + 4 r of column l & 15.
+template <bool TB, bool ACC>
+__device__ __forceinline__ void mt_gemm(double* C, const double* A, const double* B, double sign, int lane) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const int r16 = lane & 15, q = lane >> 4;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int k = 4 * kk + q;
+    const double a = A[r16 * 16 + k];
+    const double bb = TB ? B[r16 * 16 + k] : B[k * 16 + r16];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = (q + 4 * r) * 16 + r16;
+    C[idx] = (ACC ? C[idx] : 0.0) + sign * acc[r];
+  }
+}
+
+// In-place inverse of a symmetric 16 x 16 block by Gauss-Jordan elimination WITHOUT pivoting.  Returns the
+// number of negative pivots (they are the LDL' pivots of the block: their signs, summed over the whole
+// elimination, are the inertia of the KKT matrix), or -1 when a pivot is negligible / not finite.
+__device__ __forceinline__ int mt_invert(double* S, int lane) {
+  int neg = 0;
+  bool bad = false;
+  for (int k = 0; k < kMtNb; ++k) {
+    const double piv = S[k * 16 + k];
+    if (piv < 0.0) ++neg;
+    if (!(fabs(piv) >= 1e-11) || !isfinite(piv)) bad = true;
+    const double ip = 1.0 / piv;
+    double nv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane + 64 * r, i = e >> 4, j = e & 15;
+      const double sik = S[i * 16 + k], skj = S[k * 16 + j], sij = S[e];
+      double v;
+      if (i == k && j == k) v = ip;
+      else if (i == k) v = skj * ip;
+      else if (j == k) v = -sik * ip;
+      else v = sij - sik * skj * ip;
+      nv[r] = v;
+    }
+    mt_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[lane + 64 * r] = nv[r];
+    mt_wave_sync();
+  }
+  return bad ? -1 : neg;
+}
+
+// y (+)= sign * M x  or  sign * M^T x  for a 16 x 16 block in LDS and 16-vectors in LDS; lanes 0..15 each own a row
+template <bool TR>
+__device__ __forceinline__ void mt_gemv_acc(double* y, const double* M, const double* x, double sign, int lane) {
+  if (lane < 16) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += (TR ? M[k * 16 + lane] : M[lane * 16 + k]) * x[k];
+    y[lane] += sign * a;
+  }
+}
+
+struct MtKktLds {
+  double S[256], E[256], F[256], Pm[256], Qm[256], Sl[256], Ct[256], T1[256];
+  double r[16], rl[16], x[16], xl[16], xn[16];
+  double Do[81], Dn[81];      // D_next of the previous pair carried to this node
+  double red[64];
+};
+
+// cost gradient of node j (scaled unknowns)
+__device__ __forceinline__ double mt_cost_grad(const double* w, int N, int j, int a) {
+  if (a == 8) return 1.0;
+  if (a < 5) return 0.0;
+  const int jp = j == 0 ? N - 1 : j - 1, jn = j + 1 == N ? 0 : j + 1;
+  const double u = w[(size_t)j * kMtNv + a];
+  return 2e-4 * u + 2e-1 * (2.0 * u - w[(size_t)jn * kMtNv + a] - w[(size_t)jp * kMtNv + a]);
+}
+
+// max |r_d|, max constraint violation, max s z, max |s z - mu|, lap time [s] of one instance (one wave)
+//   r_d[j][a] = gc + Ao(j)' y_j + An(j-1)' y_{j-1} + Go(j)' z_j + Gn(j-1)' z_{j-1}
+__device__ __forceinline__ void mt_residuals(const MtProblem& P, const double* w, const double* sv, const double* yv,
+                                             const double* zv, const double* fun, const double* jac, double mu, int lane,
+                                             double& kkt, double& viol, double& compl_, double& errmu, double& lap) {
+  const int N = P.N;
+  kkt = 0.0; viol = 0.0; compl_ = 0.0; errmu = 0.0; lap = 0.0;
+  for (int idx = lane; idx < N * kMtNv; idx += 64) {
+    const int j = idx / kMtNv, a = idx - j * kMtNv, jp = j == 0 ? N - 1 : j - 1;
+    double r = mt_cost_grad(w, N, j, a);
+    const double* Jo = jac + (size_t)j * kMtNf * kMtLoc;
+    const double* Jp = jac + (size_t)jp * kMtNf * kMtLoc;
+    for (int c = 0; c < kMtNe; ++c) r += Jo[c * kMtLoc + a] * yv[j * kMtNe + c] + Jp[c * kMtLoc + kMtNv + a] * yv[jp * kMtNe + c];
+    for (int c = 0; c < kMtNi; ++c)
+      r += Jo[(kMtNe + c) * kMtLoc + a] * zv[j * kMtNi + c] + Jp[(kMtNe + c) * kMtLoc + kMtNv + a] * zv[jp * kMtNi + c];
+    kkt = fmax(kkt, fabs(r));
+    if (a == 8) lap += w[idx] * P.sw[8];
+  }
+  for (int idx = lane; idx < N * kMtNe; idx += 64) {
+    const int j = idx / kMtNe, c = idx - j * kMtNe;
+    viol = fmax(viol, fabs(fun[j * kMtNf + c]));
+  }
+  for (int idx = lane; idx < N * kMtNi; idx += 64) {
+    const int j = idx / kMtNi, c = idx - j * kMtNi;
+    const double s_ = sv[idx], z_ = zv[idx];
+    viol = fmax(viol, fabs(fun[j * kMtNf + kMtNe + c] + s_));
+    compl_ = fmax(compl_, s_ * z_);
+    errmu = fmax(errmu, fabs(s_ * z_ - mu));
+  }
+  kkt = wave_max(kkt); viol = wave_max(viol); compl_ = wave_max(compl_); errmu = wave_max(errmu); lap = wave_sum(lap);
+}
+
+// k_mt_kkt: one wave per instance.
+//   1. residuals r_d, r_c, r_g at the current point -> kkt / viol / compl, convergence test, barrier update
+//   2. block elimination of the cyclic block-tridiagonal KKT system (retry with a larger delta until the
+//      pivot signs are right), solution dw, dy
+__global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
+  __shared__ MtKktLds L;
+  const int b = blockIdx.x, lane = threadIdx.x, N = P.N;
+  double* scal = st.scal + (size_t)b * 16;
+  if (scal[5] != 0.0) return;
+  mt_instance(P, b);
+  const double* w = st.w + (size_t)b * N * kMtNv;
+  const double* sv = st.s + (size_t)b * N * kMtNi;
+  const double* yv = st.y + (size_t)b * N * kMtNe;
+  const double* zv = st.z + (size_t)b * N * kMtNi;
+  const double* fun = st.fun + (size_t)b * N * kMtNf;
+  const double* jac = st.jac + (size_t)b * N * kMtNf * kMtLoc;
+  const double* hes = st.hes + (size_t)b * N * kMtLoc * kMtLoc;
+  double* blk = st.blk + (size_t)b * N * 3 * 256;
+  double* vec = st.vec + (size_t)b * N * 16;
+  double mu = scal[0], delta = scal[1];
+
+  // ---- 1. residuals
+  double kkt, viol, compl_, errmu, lap;
+  mt_residuals(P, w, sv, yv, zv, fun, jac, mu, lane, kkt, viol, compl_, errmu, lap);
+  if (lane == 0) { scal[2] = kkt; scal[3] = viol; scal[4] = compl_; scal[11] = lap; }
+  if (fmax(kkt, fmax(viol, compl_)) <= st.tol) {
+    if (lane == 0) scal[5] = 1.0;
+    return;
+  }
+  if (fmax(fmax(kkt, viol), errmu) <= 10.0 * mu) mu = fmax(fmin(0.2 * mu, mu * sqrt(mu)), 1e-9);
+  if (lane == 0) scal[0] = mu;
+
+  // ---- 2. elimination.  Per pair j the 9 x 9 pieces
+  //   Do(j) = Hess_oo + Go' W Go      -> K[j][j]        Dn(j) = Hess_nn + Gn' W Gn -> K[j+1][j+1]
+  //   C(j)  = Hess_no + Gn' W Go      -> K[j+1][j]      (W = z / s)
+  auto pair_pieces = [&](int j, double* Do, double* Dn, double* Cno) {
+    const double* Jj = jac + (size_t)j * kMtNf * kMtLoc;
+    const double* Hj = hes + (size_t)j * kMtLoc * kMtLoc;
+    for (int e = lane; e < 81; e += 64) {
+      const int a = e / 9, c = e - 9 * a;
+      double doo = Hj[a * kMtLoc + c], dnn = Hj[(9 + a) * kMtLoc + 9 + c], cno = Hj[(9 + a) * kMtLoc + c];
+      for (int i = 0; i < kMtNi; ++i) {
+        const double wgt = zv[j * kMtNi + i] / sv[j * kMtNi + i];
+        const double goa = Jj[(kMtNe + i) * kMtLoc + a], goc = Jj[(kMtNe + i) * kMtLoc + c];
+        const double gna = Jj[(kMtNe + i) * kMtLoc + 9 + a], gnc = Jj[(kMtNe + i) * kMtLoc + 9 + c];
+        doo += goa * wgt * goc; dnn += gna * wgt * gnc; cno += gna * wgt * goc;
+      }
+      if (Do) Do[e] = doo;
+      if (Dn) Dn[e] = dnn;
+      if (Cno) Cno[e] = cno;
+    }
+  };
+  // diagonal block of node j into dst (needs Do(j) in L.Do and Dn(j-1) in L.Dn), coupling E_j into L.E
+  auto build_diag = [&](int j, double* dst) {
+    const double* Jj = jac + (size_t)j * kMtNf * kMtLoc;
+    for (int e = lane; e < 256; e += 64) {
+      const int i = e >> 4, c = e & 15;
+      double v = 0.0;
+      if (i < 9 && c < 9) {
+        v = L.Do[i * 9 + c] + L.Dn[i * 9 + c];
+        if (i == c) { v += delta; if (i >= 5 && i < 8) v += kMtCostDiag; }
+      } else if (i < 9) v = Jj[(c - 9) * kMtLoc + i];        // Ao(j)'
+      else if (c < 9) v = Jj[(i - 9) * kMtLoc + c];          // Ao(j)
+      else if (i == c) v = -kMtEpsReg;
+      dst[e] = v;
+    }
+  };
+  auto build_coupling = [&](int j, double* dst) {   // E_j = M[j+1][j]: [[C(j) + cost, An(j)'], [0, 0]]
+    const double* Jj = jac + (size_t)j * kMtNf * kMtLoc;
+    for (int e = lane; e < 256; e += 64) {
+      const int i = e >> 4, c = e & 15;
+      double v = 0.0;
+      if (i < 9 && c < 9) { v = L.Ct[i * 9 + c]; if (i == c && i >= 5 && i < 8) v += kMtCostOff; }
+      else if (i < 9) v = Jj[(c - 9) * kMtLoc + 9 + i];      // An(j)'
+      dst[e] = v;
+    }
+  };
+  auto build_rhs = [&](int j, double* dst) {
+    const int jp = j == 0 ? N - 1 : j - 1;
+    const double* Jo = jac + (size_t)j * kMtNf * kMtLoc;
+    const double* Jp = jac + (size_t)jp * kMtNf * kMtLoc;
+    if (lane < 16) {
+      double r;
+      if (lane < 9) {
+        const int a = lane;
+        r = mt_cost_grad(w, N, j, a);
+        for (int c = 0; c < kMtNe; ++c) r += Jo[c * kMtLoc + a] * yv[j * kMtNe + c] + Jp[c * kMtLoc + 9 + a] * yv[jp * kMtNe + c];
+        for (int c = 0; c < kMtNi; ++c) {
+          const double so = sv[j * kMtNi + c], sp = sv[jp * kMtNi + c];
+          const double zo = mu / so + zv[j * kMtNi + c] / so * (fun[j * kMtNf + kMtNe + c] + so);
+          const double zp = mu / sp + zv[jp * kMtNi + c] / sp * (fun[jp * kMtNf + kMtNe + c] + sp);
+          r += Jo[(kMtNe + c) * kMtLoc + a] * zo + Jp[(kMtNe + c) * kMtLoc + 9 + a] * zp;
+        }
+      } else {
+        r = fun[j * kMtNf + (lane - 9)];
+      }
+      dst[lane] = -r;
+    }
+  };
+
+  int attempt = 0;
+  bool ok = false;
+  for (; attempt < 12 && !ok; ++attempt) {
+    bool bad = false;
+    int n_neg = 0;
+    // S_last accumulates in L.Sl, its right-hand side in L.rl; F = border block M[N-1][j] (fill-in)
+    pair_pieces(N - 1, L.Do, nullptr, nullptr);            // Do(N-1)
+    pair_pieces(N - 2, nullptr, L.Dn, nullptr);            // Dn(N-2) -> K[N-1][N-1]
+    mt_wave_sync();
+    build_diag(N - 1, L.Sl);
+    build_rhs(N - 1, L.rl);
+    // node 0: S_0 = M[0][0]; F_0 = M[N-1][0] = E_{N-1}'  (pair N-1 couples node N-1 (own) with node 0 (next))
+    pair_pieces(N - 1, nullptr, L.Dn, L.Ct);               // Dn(N-1) -> K[0][0], C(N-1) = K[0][N-1]
+    mt_wave_sync();
+    build_coupling(N - 1, L.T1);                           // E_{N-1} = M[0][N-1]
+    mt_wave_sync();
+    for (int e = lane; e < 256; e += 64) L.F[e] = L.T1[(e & 15) * 16 + (e >> 4)];   // F_0 = E_{N-1}'
+    pair_pieces(0, L.Do, nullptr, nullptr);
+    mt_wave_sync();
+    build_diag(0, L.S);
+    build_rhs(0, L.r);
+    mt_wave_sync();
+    for (int j = 0; j < N - 1 && !bad; ++j) {
+      // pieces of pair j: coupling to node j+1
+      pair_pieces(j, nullptr, L.Dn, L.Ct);                 // Dn(j) -> K[j+1][j+1], C(j)
+      mt_wave_sync();
+      build_coupling(j, L.E);                              // E_j = M[j+1][j]
+      if (j == N - 2) {                                    // the regular coupling of the last node joins the border
+        mt_wave_sync();
+        for (int e = lane; e < 256; e += 64) L.F[e] += L.E[e];
+      }
+      mt_wave_sync();
+      const int neg = mt_invert(L.S, lane);                // S_j^-1
+      if (neg < 0) { bad = true; break; }
+      n_neg += neg;
+      double* Bj = blk + (size_t)j * 3 * 256;
+      for (int e = lane; e < 256; e += 64) Bj[e] = L.S[e];
+      if (j < N - 2) {
+        mt_gemm<false, false>(L.Pm, L.E, L.S, 1.0, lane);  // P_j = E_j S_j^-1
+      }
+      mt_gemm<false, false>(L.Qm, L.F, L.S, 1.0, lane);    // Q_j = F_j S_j^-1
+      mt_wave_sync();
+      for (int e = lane; e < 256; e += 64) { Bj[256 + e] = (j < N - 2) ? L.Pm[e] : 0.0; Bj[512 + e] = L.Qm[e]; }
+      // right-hand sides
+      if (lane < 16) vec[(size_t)j * 16 + lane] = L.r[lane];
+      mt_gemv_acc<false>(L.rl, L.Qm, L.r, -1.0, lane);     // r_last -= Q_j r_j
+      // S_last -= Q_j F_j'
+      mt_gemm<true, true>(L.Sl, L.Qm, L.F, -1.0, lane);
+      if (j < N - 2) {
+        // next node: S_{j+1} = M[j+1][j+1] - P_j E_j' ; F_{j+1} = -Q_j E_j' ; r_{j+1} -= P_j r_j
+        pair_pieces(j + 1, L.Do, nullptr, nullptr);
+        mt_wave_sync();
+        build_diag(j + 1, L.T1);
+        build_rhs(j + 1, L.xn);
+        mt_wave_sync();
+        mt_gemm<true, true>(L.T1, L.Pm, L.E, -1.0, lane);
+        mt_gemv_acc<false>(L.xn, L.Pm, L.r, -1.0, lane);
+        mt_gemm<true, false>(L.F, L.Qm, L.E, -1.0, lane);  // reads Qm, E; writes F (not an input)
+        mt_wave_sync();
+        for (int e = lane; e < 256; e += 64) L.S[e] = L.T1[e];
+        if (lane < 16) L.r[lane] = L.xn[lane];
+        mt_wave_sync();
+      }
+    }
+    if (!bad) {
+      mt_wave_sync();
+      const int neg = mt_invert(L.Sl, lane);
+      // inertia (9N, 7N, 0): the reduced Hessian is positive definite (Sylvester's law on the LDL' pivots)
+      if (neg < 0 || n_neg + neg != N * kMtNe) bad = true;
+    }
+    if (bad) {
+      delta = fmax(10.0 * delta, 1e-4);
+      if (delta > 1e8) break;
+      continue;
+    }
+    ok = true;
+  }
+  if (lane == 0) { scal[1] = delta; scal[10] += (double)(attempt - 1); }
+  if (!ok) {
+    if (lane == 0) scal[5] = 2.0;
+    return;
+  }
+  // ---- back substitution: x_last = S_last^-1 r_last; x_j = S_j^-1 r_j - P_j' x_{j+1} - Q_j' x_last
+  if (lane < 16) {
+    double a = 0.0;
+    for (int k = 0; k < 16; ++k) a += L.Sl[lane * 16 + k] * L.rl[k];
+    L.xl[lane] = a;
+  }
+  mt_wave_sync();
+  double* dw = st.dw + (size_t)b * N * kMtNv;
+  double* dy = st.dy + (size_t)b * N * kMtNe;
+  if (lane < 9) dw[(size_t)(N - 1) * kMtNv + lane] = L.xl[lane];
+  else if (lane < 16) dy[(size_t)(N - 1) * kMtNe + lane - 9] = L.xl[lane];
+  if (lane < 16) L.xn[lane] = L.xl[lane];    // x_{j+1} for j = N-2 (its P is zero: the coupling sits in Q)
+  mt_wave_sync();
+  for (int j = N - 2; j >= 0; --j) {
+    const double* Bj = blk + (size_t)j * 3 * 256;
+    if (lane < 16) {
+      double a = 0.0;
+      for (int k = 0; k < 16; ++k) {
+        a += Bj[lane * 16 + k] * vec[(size_t)j * 16 + k];                   // S_j^-1 r_j
+        a -= Bj[256 + k * 16 + lane] * L.xn[k];                             // P_j' x_{j+1}
+        a -= Bj[512 + k * 16 + lane] * L.xl[k];                             // Q_j' x_last
+      }
+      L.x[lane] = a;
+    }
+    mt_wave_sync();
+    if (lane < 9) dw[(size_t)j * kMtNv + lane] = L.x[lane];
+    else if (lane < 16) dy[(size_t)j * kMtNe + lane - 9] = L.x[lane];
+    if (lane < 16) L.xn[lane] = L.x[lane];
+    mt_wave_sync();
+  }
+}
+
+// residuals only (final report of the instances that ran into the iteration limit)
+__global__ void __launch_bounds__(64) k_mt_residuals(MtProblem P, MtState st) {
+  const int b = blockIdx.x, lane = threadIdx.x, N = P.N;
+  double* scal = st.scal + (size_t)b * 16;
+  if (scal[5] == 1.0) return;
+  mt_instance(P, b);
+  double kkt, viol, compl_, errmu, lap;
+  mt_residuals(P, st.w + (size_t)b * N * kMtNv, st.s + (size_t)b * N * kMtNi, st.y + (size_t)b * N * kMtNe,
+               st.z + (size_t)b * N * kMtNi, st.fun + (size_t)b * N * kMtNf, st.jac + (size_t)b * N * kMtNf * kMtLoc,
+               scal[0], lane, kkt, viol, compl_, errmu, lap);
+  if (lane == 0) { scal[2] = kkt; scal[3] = viol; scal[4] = compl_; scal[11] = lap; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mt_step: one workgroup (256 threads) per instance.
+template <int BLOCK>
+__device__ __forceinline__ double mt_block_reduce(double v, double* red, int op /*0 sum, 1 min*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = op == 0 ? wave_sum(v) : wave_min(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int q = 1; q < BLOCK / 64; ++q) r = op == 0 ? r + red[q] : fmin(r, red[q]);
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
+  __shared__ double red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
+  double* scal = st.scal + (size_t)b * 16;
+  if (scal[5] != 0.0) return;
+  mt_instance(P, b);
+  double* w = st.w + (size_t)b * N * kMtNv;
+  double* sv = st.s + (size_t)b * N * kMtNi;
+  double* yv = st.y + (size_t)b * N * kMtNe;
+  double* zv = st.z + (size_t)b * N * kMtNi;
+  const double* fun = st.fun + (size_t)b * N * kMtNf;
+  const double* jac = st.jac + (size_t)b * N * kMtNf * kMtLoc;
+  const double* dw = st.dw + (size_t)b * N * kMtNv;
+  const double* dy = st.dy + (size_t)b * N * kMtNe;
+  double* dsv = st.vec + (size_t)b * N * 16;      // reuse: ds [N,17] does not fit 16 -> use blk scratch instead
+  double* ds = st.blk + (size_t)b * N * 3 * 256;  // [N,17] ds, then [N,17] dz (the factor blocks are dead now)
+  double* dz = ds + (size_t)N * kMtNi;
+  (void)dsv;
+  const double mu = scal[0];
+  // ds = -r_g - G dw ; dz = -(s z - mu + z ds) / s ; fraction to the boundary
+  double ap = 1.0, ad = 1.0, theta0 = 0.0, phi0 = 0.0;
+  for (int idx = tid; idx < N * kMtNi; idx += 256) {
+    const int j = idx / kMtNi, c = idx - j * kMtNi, jn = j + 1 == N ? 0 : j + 1;
+    const double* Jr = jac + ((size_t)j * kMtNf + kMtNe + c) * kMtLoc;
+    double gd = 0.0;
+    for (int a = 0; a < kMtNv; ++a) gd += Jr[a] * dw[(size_t)j * kMtNv + a] + Jr[9 + a] * dw[(size_t)jn * kMtNv + a];
+    const double s_ = sv[idx], z_ = zv[idx], rg = fun[j * kMtNf + kMtNe + c] + s_;
+    const double d_s = -rg - gd;
+    const double d_z = -(s_ * z_ - mu + z_ * d_s) / s_;
+    ds[idx] = d_s; dz[idx] = d_z;
+    if (d_s < 0.0) ap = fmin(ap, -0.995 * s_ / d_s);
+    if (d_z < 0.0) ad = fmin(ad, -0.995 * z_ / d_z);
+    theta0 += fabs(rg);
+    phi0 -= mu * log(s_);
+  }
+  for (int idx = tid; idx < N * kMtNe; idx += 256) {
+    const int j = idx / kMtNe, c = idx - j * kMtNe;
+    theta0 += fabs(fun[j * kMtNf + c]);
+  }
+  for (int idx = tid; idx < N; idx += 256) {
+    const double* wj = w + (size_t)idx * kMtNv;
+    const double* wn = w + (size_t)(idx + 1 == N ? 0 : idx + 1) * kMtNv;
+    double c = wj[8];
+    for (int a = 5; a < 8; ++a) c += 1e-4 * wj[a] * wj[a] + 1e-1 * (wn[a] - wj[a]) * (wn[a] - wj[a]);
+    phi0 += c;
+  }
+  ap = mt_block_reduce<256>(ap, red, 1); ad = mt_block_reduce<256>(ad, red, 1);
+  theta0 = mt_block_reduce<256>(theta0, red, 0); phi0 = mt_block_reduce<256>(phi0, red, 0);
+  // backtracking against the filter {(theta0, phi0)}
+  double a = ap;
+  bool ok = false;
+  for (int trial = 0; trial < 12; ++trial) {
+    double theta = 0.0, phi = 0.0;
+    bool fin = true;
+    for (int j = tid; j < N; j += 256) {
+      const int jn = j + 1 == N ? 0 : j + 1;
+      double wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
+#pragma unroll
+      for (int q = 0; q < kMtNv; ++q) {
+        wo[q] = w[(size_t)j * kMtNv + q] + a * dw[(size_t)j * kMtNv + q];
+        wn[q] = w[(size_t)jn * kMtNv + q] + a * dw[(size_t)jn * kMtNv + q];
+      }
+      mt_pair<double>(P, j, wo, wn, eq, g);
+      double c = wo[8];
+#pragma unroll
+      for (int q = 5; q < 8; ++q) c += 1e-4 * wo[q] * wo[q] + 1e-1 * (wn[q] - wo[q]) * (wn[q] - wo[q]);
+      phi += c;
+#pragma unroll
+      for (int q = 0; q < kMtNe; ++q) theta += fabs(eq[q]);
+#pragma unroll
+      for (int q = 0; q < kMtNi; ++q) {
+        const double s_ = sv[(size_t)j * kMtNi + q] + a * ds[(size_t)j * kMtNi + q];
+        theta += fabs(g[q] + s_);
+        phi -= mu * log(s_);
+      }
+    }
+    theta = mt_block_reduce<256>(theta, red, 0); phi = mt_block_reduce<256>(phi, red, 0);
+    fin = isfinite(theta) && isfinite(phi);
+    if (fin && (theta <= (1.0 - 1e-5) * theta0 || phi <= phi0 - 1e-5 * theta0)) { ok = true; break; }
+    a *= 0.5;
+  }
+  double delta = scal[1];
+  if (!ok) {
+    // no acceptable step: more damping, same point (the next iteration re-solves with the larger delta)
+    delta = fmax(10.0 * delta, 1e-4);
+    if (tid == 0) { scal[1] = delta; scal[7] = 0.0; scal[6] += 1.0; if (delta > 1e6) scal[5] = 2.0; }
+    return;
+  }
+  const double az = fmin(ad, 1.0);
+  for (int idx = tid; idx < N * kMtNv; idx += 256) w[idx] += a * dw[idx];
+  for (int idx = tid; idx < N * kMtNe; idx += 256) yv[idx] += a * dy[idx];
+  for (int idx = tid; idx < N * kMtNi; idx += 256) {
+    const double s_ = sv[idx] + a * ds[idx];
+    double z_ = zv[idx] + az * dz[idx];
+    z_ = fmin(fmax(z_, mu / (1e10 * s_)), 1e10 * mu / s_);
+    sv[idx] = s_; zv[idx] = z_;
+  }
+  delta = fmin(fmax(delta * (a > 0.9 ? 0.4 : (a > 0.3 ? 1.0 : 5.0)), 1e-6), 1e3);
+  if (tid == 0) { scal[1] = delta; scal[7] = a; scal[6] += 1.0; scal[8] = theta0; scal[9] = phi0; }
+}
+
+// physical X [B,N,6], U [B,N,4], T [B,N]  <->  scaled unknowns w [B,N,9]
+__global__ void k_mt_pack(MtProblem P, MtState st, const double* X, const double* U, const double* T) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x, N = P.N;
+  if (j >= N) return;
+  const size_t o = (size_t)b * N + j;
+  double* w = st.w + o * kMtNv;
+  for (int c = 0; c < 5; ++c) w[c] = X[o * 6 + 1 + c] / P.sw[c];
+  w[5] = U[o * 4 + 0] / P.sw[5]; w[6] = U[o * 4 + 2] / P.sw[6]; w[7] = U[o * 4 + 3] / P.sw[7];
+  w[8] = T[o] / P.sw[8];
+}
+__global__ void k_mt_unpack(MtProblem P, MtState st, double* X, double* U, double* T) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x, N = P.N;
+  if (j >= N) return;
+  const size_t o = (size_t)b * N + j;
+  const double* w = st.w + o * kMtNv;
+  X[o * 6 + 0] = P.s[j];
+  for (int c = 0; c < 5; ++c) X[o * 6 + 1 + c] = w[c] * P.sw[c];
+  U[o * 4 + 0] = w[5] * P.sw[5]; U[o * 4 + 1] = 0.0; U[o * 4 + 2] = w[6] * P.sw[6]; U[o * 4 + 3] = w[7] * P.sw[7];
+  T[o] = w[8] * P.sw[8];
+}
+
+// initial slacks / multipliers from the functions at w0:  s = max(-g, 1e-2), z = mu0 / s, y = 0
+__global__ void k_mt_init(MtProblem P, MtState st, double mu0, double delta0) {
+  const int b = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x, N = P.N;
+  if (idx < N * kMtNi) {
+    const int j = idx / kMtNi, c = idx - j * kMtNi;
+    const double g = st.fun[((size_t)b * N + j) * kMtNf + kMtNe + c];
+    const double s = fmax(-g, 1e-2);
+    st.s[(size_t)b * N * kMtNi + idx] = s;
+    st.z[(size_t)b * N * kMtNi + idx] = mu0 / s;
+  }
+  if (idx < N * kMtNe) st.y[(size_t)b * N * kMtNe + idx] = 0.0;
+  if (idx < 16) st.scal[(size_t)b * 16 + idx] = idx == 0 ? mu0 : (idx == 1 ? delta0 : 0.0);
+}
+
+}  // namespace rl

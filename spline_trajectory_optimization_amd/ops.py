@@ -269,3 +269,26 @@ def dt_eval_jac(model, s, kappa, left, right, margin, track_length, X, U, T, dev
     check(ctx.lib.rl_dt_eval_jac(ctx.h, mp, B, N, sp, kp, lp, rp, float(margin), float(track_length), Xp, Up, Tp,
                                  je.ctypes.data_as(_dp), ji.ctypes.data_as(_dp), gc.ctypes.data_as(_dp)))
     return je, ji, gc
+
+
+def mintime_solve_batch(model, s, kappa, left, right, margin, track_length, X0, U0, T0, average_track_width=7.0,
+                        speed_cap=30.0, max_iter=120, tol=1e-6, device=None):
+    """The solve of the min-time double-track NLP (include/rl_mincurv.h: rl_mintime_solve_batch; stands in for
+    `opti.solve()` with IPOPT, entrypoints/traj_opt_double_track.py:61-65) for B instances.
+    left/right: [N] shared or [B,N] per instance.  X0 [B,N,6], U0 [B,N,4], T0 [B,N]: initial guess (physical).
+    Returns (X, U, T, stats [B,12])."""
+    ctx = Context.get(device)
+    mv, mp = as_d([float(model[k]) for k in DT_PARAMS])
+    X = np.array(X0, dtype=np.float64, copy=True, order="C"); U = np.array(U0, dtype=np.float64, copy=True, order="C")
+    T = np.array(T0, dtype=np.float64, copy=True, order="C")
+    B, N = T.shape
+    assert X.shape == (B, N, 6) and U.shape == (B, N, 4)
+    s, sp = as_d(s); kappa, kp = as_d(kappa); left, lp = as_d(left); right, rp = as_d(right)
+    per = left.ndim == 2
+    assert left.shape == right.shape == ((B, N) if per else (N,)) and len(s) == len(kappa) == N
+    stats = np.zeros((B, 12))
+    check(ctx.lib.rl_mintime_solve_batch(ctx.h, mp, B, N, sp, kp, lp, rp, int(per), float(margin), float(track_length),
+                                         float(average_track_width), float(speed_cap), X.ctypes.data_as(_dp),
+                                         U.ctypes.data_as(_dp), T.ctypes.data_as(_dp), int(max_iter), float(tol),
+                                         stats.ctypes.data_as(_dp)))
+    return X, U, T, stats
