@@ -1,8 +1,10 @@
 """Host-side mirror of `spline_traj_optm.models.race_track.RaceTrack` (models/race_track.py:8-104).
 
-Only the part on the min-curvature path is built: the k=3 boundary/centre splines, their
-discretisations, the rings and `fill_trajectory_boundaries` (race_track.py:23-37, 98-104).  The
-CasADi interpolants of race_track.py:39-96 belong to the min-time NLP (out of scope).
+The k=3 boundary/centre splines, their discretisations, the rings and `fill_trajectory_boundaries`
+(race_track.py:23-37, 98-104) are the min-curvature path.  The interpolants of x, y, yaw, curvature and
+boundary distance against the abscissa (race_track.py:39-96, CasADi `interpolant('bspline')` + `hessian`
+there) serve the min-time NLP; they are the build's OWN implementation -- periodic cubic splines through the
+same samples (scipy, host-side set-up like the spline fits) -- with the reference's attribute names.
 """
 import numpy as np
 
@@ -55,6 +57,42 @@ class RaceTrack:
 
         self.name = name
         self.fill_trajectory_boundaries(self.center_d)
+        self._build_interpolants()
+
+    # ---- race_track.py:39-96: interpolants against the abscissa (distance from the start / finish line)
+    def _build_interpolants(self):
+        from scipy.interpolate import CubicSpline
+        cd = self.center_d
+        length = self.center_s.get_length()
+        self.abscissa = cd[:, Trajectory.DIST_TO_SF_BWD].copy()                                    # :56
+        xy = cd[:, Trajectory.X:Trajectory.Y + 1]
+        dist_l = np.linalg.norm(xy - cd[:, Trajectory.LEFT_BOUND_X:Trajectory.LEFT_BOUND_Y + 1], axis=1)   # :51
+        dist_r = np.linalg.norm(xy - cd[:, Trajectory.RIGHT_BOUND_X:Trajectory.RIGHT_BOUND_Y + 1], axis=1)  # :52
+        ss = np.r_[self.abscissa, length]
+
+        def periodic(v):
+            return CubicSpline(ss, np.r_[v, v[0]], bc_type="periodic")
+        self._sx, self._sy = periodic(xy[:, 0]), periodic(xy[:, 1])
+        self._sl, self._sr = periodic(dist_l), periodic(-dist_r)                                  # right distances are negative (:58-59)
+        wrap = lambda s_: np.mod(np.asarray(s_, dtype=np.float64), length)  # noqa: E731  (s_mod, :65)
+        self.x_intp = lambda s_: self._sx(wrap(s_))
+        self.y_intp = lambda s_: self._sy(wrap(s_))
+        self.left_intp = lambda s_: self._sl(wrap(s_))
+        self.right_intp = lambda s_: self._sr(wrap(s_))
+        self.yaw_intp = lambda s_: np.arctan2(self._sy(wrap(s_), 1), self._sx(wrap(s_), 1))       # :73
+        def curvature(s_):                                                                        # :74
+            q = wrap(s_)
+            dx, dy, d2x, d2y = self._sx(q, 1), self._sy(q, 1), self._sx(q, 2), self._sy(q, 2)
+            return (dx * d2y - dy * d2x) / np.sqrt((dx ** 2 + dy ** 2) ** 3)
+        self.curvature_intp = curvature
+        self.fast_curvature_intp = lambda s_: np.interp(wrap(s_), ss, np.r_[curvature(self.abscissa), curvature(self.abscissa[:1])])
+
+    def frenet_to_global(self, s, t, xi):
+        """(abscissa, lateral offset, relative heading) -> (x, y, heading)  (race_track.py:87-96)."""
+        yaw0 = self.yaw_intp(s)
+        phi = yaw0 + np.asarray(xi, dtype=np.float64)
+        phi = np.arctan2(np.sin(phi), np.cos(phi))                                                # align_yaw(., 0)
+        return np.stack([self.x_intp(s) - np.sin(yaw0) * t, self.y_intp(s) + np.cos(yaw0) * t, phi], axis=-1)
 
     def fill_trajectory_boundaries(self, traj: Trajectory):
         """Fills the boundary properties of a trajectory in place (race_track.py:98-104)."""

@@ -124,3 +124,43 @@ def test_mintime_batch_with_per_instance_widths(coarse):
     assert st[3, 4] <= st[2, 4] + 1e-6 <= st[0, 4] + 2e-6 <= st[1, 4] + 3e-6   # wider is not slower
     with pytest.raises(Exception):
         ops.mintime_solve_batch(P.m, P.s, P.kappa, P.left * 0.2, P.right * 0.2, P.margin, P.L, X0[None], U0[None], T0[None])
+
+
+@pytest.mark.gpu
+def test_reference_pipeline_on_the_example_track():
+    """The reference CLI's pipeline (entrypoints/traj_opt_double_track.py:24-86) through the mirror classes at the
+    example's own resolution (MGKT, interval 1 m, yaml defaults): RaceTrack + interpolants -> QSS warm start on
+    the GPU -> NLP solve on the GPU -> TTL-ready table."""
+    import os
+    import time
+    from mintime_problem import MGKT, _load
+    from spline_traj_optm.min_time_optm.min_time_optimizer import set_up_double_track_problem
+    from spline_trajectory_optimization_amd.min_time_optm.min_time_optimizer import optimise_track
+    from spline_trajectory_optimization_amd.models.race_track import RaceTrack
+    from spline_trajectory_optimization_amd.models.trajectory import Trajectory, load_ttl, save_ttl
+    from spline_trajectory_optimization_amd.models.vehicle import Vehicle, VehicleParams
+    est = defaults.ESTIMATES
+    rt = RaceTrack("Test track", _load("MGKT_OUT_BOUND_enu.csv"), _load("MGKT_IN_BOUND_enu.csv"), _load("MGKT_CENTER_enu.csv"),
+                   s=1.0, interval=defaults.SOLVER["interval"])
+    veh = Vehicle(VehicleParams(np.array(est["acc_speed_loopup"]), np.array(est["dcc_speed_lookup"]), est["max_lon_acc_mpss"],
+                                est["max_lon_dcc_mpss"], est["max_left_acc_mpss"], est["max_right_acc_mpss"],
+                                est["max_speed_mps"], est["max_jerk_mpsc"]))
+    assert abs(rt.left_intp(rt.abscissa[5]) - np.hypot(*(rt.center_d[5, 0:2] - rt.center_d[5, 9:11]))) < 1e-9
+    assert callable(set_up_double_track_problem)
+    t0 = time.time()
+    out, X, U, T, st = optimise_track(rt, veh, defaults.MODEL, defaults.SOLVER["average_track_width"],
+                                      defaults.SOLVER["speed_cap"], max_iter=300, tol=1e-6)
+    N = len(out)
+    print(f"MGKT interval 1 m: N={N} iterations {st[0]:.0f} status {st[5]:.0f} kkt {st[1]:.1e} viol {st[2]:.1e} "
+          f"lap {st[4]:.4f} s, wall {time.time() - t0:.2f} s (set-up + QSS + solve)")
+    assert st[5] == 1.0 and max(st[1], st[2], st[3]) <= 1e-6
+    assert isinstance(out, Trajectory) and np.isfinite(out.points).all()
+    # the optimised line stays between the boundaries with the vehicle margin, and is faster than the QSS profile
+    margin = defaults.MODEL["vehicle_width"] / 2 + defaults.MODEL["safety_margin"]
+    assert (X[:, 1] <= rt.left_intp(rt.abscissa) - margin + 1e-6).all() and (X[:, 1] >= rt.right_intp(rt.abscissa) + margin - 1e-6).all()
+    assert T.sum() < 56.0 and X[:, 5].max() <= defaults.SOLVER["speed_cap"]
+    p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mgkt_optm.ttl")
+    out.ttl_num, out.origin = 1, (0.0, 0.0, 0.0)
+    save_ttl(p, out)
+    back = load_ttl(p)
+    np.testing.assert_allclose(back.points[:, :17], out.points[:, :17], rtol=0, atol=0)
