@@ -38,6 +38,7 @@ import scipy.sparse.linalg as spla
 from . import dt_checker as dc
 
 NV, NE, NI = 9, 7, 17
+THETA_GROWTH = 2.0   # a step may not more than double the l1 infeasibility, whatever it does to the objective
 # reduced variable a -> (array, column): X cols 1..5, U cols 0,2,3, T
 _XCOL = [1, 2, 3, 4, 5]
 _UCOL = [0, 2, 3]
@@ -314,7 +315,7 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
             break
         # barrier parameter: monotone (Fiacco-McCormick): lowered once the barrier problem is solved to ~10 mu
         if max(kkt, viol, np.abs(sz * zz - mu).max()) <= 10.0 * mu:
-            mu = max(min(0.2 * mu, mu ** 1.5), 1e-9)
+            mu = max(min(0.2 * mu, mu ** 1.5), tol / 10.0)     # no lower than needed for compl <= tol
         Hk = H + lagrangian_hessian(P, w, y, z)
         W = sp.diags(zz / sz)
         Kww0 = (Hk + G.T @ W @ G).tocsr()
@@ -347,7 +348,8 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
             eqt, gt = P.functions(wt)
             tht = np.abs(eqt).sum() + np.abs(gt.ravel() + stt).sum()
             pht = P.cost(wt) - mu * np.log(stt).sum()
-            if np.isfinite(pht) and np.isfinite(tht) and (tht <= (1 - 1e-5) * th0 or pht <= ph0 - 1e-5 * th0):
+            if np.isfinite(pht) and np.isfinite(tht) and tht <= THETA_GROWTH * th0 + 1e-9 and \
+                    (tht <= (1 - 1e-5) * th0 or pht <= ph0 - 1e-5 * th0):
                 ok = True
                 break
             a *= 0.5

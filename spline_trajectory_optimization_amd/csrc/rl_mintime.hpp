@@ -39,6 +39,7 @@ constexpr int kMtJacSlices = kMtLoc / 3, kMtHesGroups = kMtLoc / 3;
 constexpr int kMtHesSlices = kMtHesGroups * (kMtHesGroups + 1) / 2;   // 21 pairs of direction groups
 constexpr int kMtSlices = 1 + kMtJacSlices + kMtHesSlices;            // 28
 constexpr double kMtEpsReg = 1e-8;  // dual regularisation of the KKT system
+constexpr double kMtThetaGrowth = 2.0;
 constexpr double kMtCostDiag = 2e-4 + 4e-1, kMtCostOff = -2e-1;  // Hessian of 1e-4 |U|^2 + 1e-1 |dU|^2 (:119-123)
 
 struct MtProblem {
@@ -378,7 +379,8 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
     if (lane == 0) scal[5] = 1.0;
     return;
   }
-  if (fmax(fmax(kkt, viol), errmu) <= 10.0 * mu) mu = fmax(fmin(0.2 * mu, mu * sqrt(mu)), 1e-9);
+  // monotone barrier update once the barrier problem is solved to 10 mu; no lower than compl <= tol needs
+  if (fmax(fmax(kkt, viol), errmu) <= 10.0 * mu) mu = fmax(fmin(0.2 * mu, mu * sqrt(mu)), st.tol / 10.0);
   if (lane == 0) scal[0] = mu;
 
   // ---- 2. elimination.  Per pair j the 9 x 9 pieces
@@ -669,7 +671,8 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
     }
     theta = mt_block_reduce<256>(theta, red, 0); phi = mt_block_reduce<256>(phi, red, 0);
     fin = isfinite(theta) && isfinite(phi);
-    if (fin && (theta <= (1.0 - 1e-5) * theta0 || phi <= phi0 - 1e-5 * theta0)) { ok = true; break; }
+    // a step may not more than double the l1 infeasibility, whatever it does to the objective
+    if (fin && theta <= kMtThetaGrowth * theta0 + 1e-9 && (theta <= (1.0 - 1e-5) * theta0 || phi <= phi0 - 1e-5 * theta0)) { ok = true; break; }
     a *= 0.5;
   }
   double delta = scal[1];
