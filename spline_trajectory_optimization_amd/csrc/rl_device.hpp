@@ -215,14 +215,16 @@ __device__ __forceinline__ void scan_edges_batched(RingPtr ring, int nr, int j0,
 // per edge, where the line changes side; pass 2 runs the exact edge test (with its division) on
 // the recorded edges -- all lanes work on their own first candidate at the same time, so the
 // expensive block runs once or twice per window instead of once per distinct candidate position.
-#ifndef RL_WIN
-#define RL_WIN 12
-#endif
-constexpr int kWin = RL_WIN;              // window = hint +- kWin edges
-constexpr int kNear = 2;                  // chunks ce-kNear..ce+kNear are checked one by one
-constexpr int kWinEdges = 2 * kWin + 1;   // rings must be longer than twice this
-constexpr int kRingPad = kWinEdges + 1;   // vertices repeated behind the ring
-constexpr int kWinBatch = kWinEdges % 5 == 0 ? 5 : (kWinEdges % 7 == 0 ? 7 : 3);
+// The window is CHUNK ALIGNED: the three whole chunks around the chunk of the hint (the edge of the last
+// crossing).  A crossing found in the middle chunk then has both neighbouring chunks fully scanned, and the
+// certificate below reduces to one table look-up (plus one circle test when the crossing moved into an outer
+// chunk of the window).
+constexpr int kChunk = 8;
+constexpr int kWinChunks = 3;
+constexpr int kNear = 1;                        // chunks ce-kNear..ce+kNear are checked one by one
+constexpr int kWinEdges = kWinChunks * kChunk;  // 24; rings must be longer than twice this
+constexpr int kRingPad = kWinEdges + 1;         // vertices repeated behind the ring
+constexpr int kWinBatch = 6;
 
 template <typename RingPtr>
 __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, double px, double py,
@@ -272,7 +274,6 @@ __device__ __forceinline__ Hit search_ring_brute(RingPtr ring, int nr, double px
 // within r of its centre and the centre's projection is within max_dist + r of p; every chunk that
 // passes is scanned exactly like the brute-force loop, so the result (including tie-breaking) is
 // identical to search_ring_brute.
-constexpr int kChunk = 8;
 
 template <typename RingPtr, typename CirclePtr>
 __device__ __forceinline__ Hit search_ring_culled(RingPtr ring, int nr, CirclePtr circ, int nchunk,
@@ -353,8 +354,9 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
   const int lane = threadIdx.x & (kWave - 1);
   Hit h{INFINITY, 0.0, kNoEdge};
   const bool windowed = active && hint >= 0 && hint < nr;
-  int lo = hint - kWin;  // first edge of the window (consecutive lanes -> consecutive addresses)
-  if (lo < 0) lo += nr;
+  int cs = hint / kChunk - 1;  // first chunk of the window
+  if (cs < 0) cs += nchunk;
+  const int lo = cs * kChunk;  // first edge of the window (the lanes of one chunk read the same addresses)
   if (windowed) scan_window(ring, nr, lo, px, py, dx, dy, h);
   if (skip_guard) return h;
   const bool found = h.best <= 1.0;
@@ -365,7 +367,7 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
     const int cnt = min(kChunk, nr - e0);
     int off = e0 - lo;
     if (off < 0) off += nr;
-    return off + cnt - 1 <= 2 * kWin;
+    return off + cnt - 1 <= kWinEdges - 1;
   };
   bool slow = active;
   if (windowed && found && nchunk > 2 * kNear + 1) {

@@ -320,7 +320,7 @@ struct SweepLds {
   size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, off_joint, total;
 };
 
-__host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds) {
+__host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds, bool sigma_in_lds) {
   SweepLds L;
   L.cpad = (n + 1) & ~1;
   L.nLp = nL; L.nRp = nR;
@@ -336,13 +336,14 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   L.off_pR = o; o += (size_t)((L.ncR + 1) & ~1);
   L.off_joint = o; o += 128 + (size_t)((N + 15) / 16) * 2;  // joint variant: QP scratch + 1 byte per sample
   L.off_hint = o; o += (size_t)(((size_t)2 * ((N + 3) & ~3) * sizeof(unsigned short) + 15) / 16) * 2;  // u16 [2][Npad]
-  if (rings_in_lds) {
+  L.off_sL = L.off_sR = L.off_rL = L.off_rR = 0;
+  if (sigma_in_lds) {
     L.off_sL = o; o += (size_t)((N + 1) & ~1);
     L.off_sR = o; o += (size_t)((N + 1) & ~1);
+  }
+  if (rings_in_lds) {
     L.off_rL = o; o += (size_t)2 * (nL + kRingPad);
     L.off_rR = o; o += (size_t)2 * (nR + kRingPad);
-  } else {
-    L.off_sL = L.off_sR = L.off_rL = L.off_rR = 0;
   }
   L.total = o;
   return L;
@@ -354,7 +355,7 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
 //   11,12 the new control point (when accepted)
 constexpr int kSweepDumpHead = 16;
 
-template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false>
+template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false, bool SIGMA_LDS = RINGS_LDS>
 __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid % kWave, wave = tid / kWave;
   constexpr int NW = BLOCK / kWave;
-  const SweepLds L = sweep_lds_layout(n, N, a.nL, a.nR, RINGS_LDS);
+  const SweepLds L = sweep_lds_layout(n, N, a.nL, a.nR, RINGS_LDS, SIGMA_LDS);
   double* cx = smem + L.off_cx;
   double* cy = smem + L.off_cy;
   double* red = smem + L.off_red;
@@ -375,15 +376,19 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   unsigned short* hints = reinterpret_cast<unsigned short*>(smem + L.off_hint);  // [2][Npad]
   const int Npad = (N + 3) & ~3;
   double* sL; double* sR; double2* rL; double2* rR;
-  if (RINGS_LDS) {
-    sL = smem + L.off_sL; sR = smem + L.off_sR;
-    rL = reinterpret_cast<double2*>(smem + L.off_rL);
-    rR = reinterpret_cast<double2*>(smem + L.off_rR);
-  } else {
+  {
+    // three residencies of the per-instance state: crossings sL/sR and ring vertices each either in LDS or
+    // in the instance's global scratch (rl_mincurv.hip: plan_sweep)
     double* g = a.gscratch + (size_t)b * a.gscratch_stride;
-    sL = g; sR = sL + ((N + 1) & ~1);
-    rL = reinterpret_cast<double2*>(sR + ((N + 1) & ~1));
-    rR = rL + a.nL + kRingPad;
+    if (SIGMA_LDS) { sL = smem + L.off_sL; sR = smem + L.off_sR; }
+    else { sL = g; sR = sL + ((N + 1) & ~1); g = sR + ((N + 1) & ~1); }
+    if (RINGS_LDS) {
+      rL = reinterpret_cast<double2*>(smem + L.off_rL);
+      rR = reinterpret_cast<double2*>(smem + L.off_rR);
+    } else {
+      rL = reinterpret_cast<double2*>(g);
+      rR = rL + a.nL + kRingPad;
+    }
   }
   const int nL = a.nL, nR = a.nR;
 

@@ -121,40 +121,45 @@ int check_spline(const double* t, int nt, const double* cx, const double* cy, in
 
 struct SweepPlan {
   bool rings_in_lds;
+  bool sigma_in_lds;
   size_t lds_bytes;
-  size_t gscratch_doubles;  // per instance, 0 if rings_in_lds
+  size_t gscratch_doubles;  // per instance
   int block;
 };
 
 SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B) {
   SweepPlan p;
-  rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true);
   p.block = 256;
-  // Two residencies for the per-instance rings / crossings:
-  //   LDS    : lowest latency per step, but ~120 KB at N = 2000 -> one workgroup per CU;
-  //   global : ~25 KB of LDS -> four workgroups per CU (VGPR-limited), rings served by L1/L2.
+  // Residency of the per-instance state (ring vertices 16 B x (nL + nR), crossings 8 B x 2N):
+  //   all in LDS      : lowest latency per step, but ~120 KB at N = 2000 -> one workgroup per CU;
+  //   all in global   : ~31 KB of LDS -> four workgroups per CU (VGPR-limited), state served by L1/L2;
+  //   crossings in LDS, rings in global (RL_FORCE_RESIDENCY=2 only): ~63 KB -> two workgroups per CU, no
+  //                     global writes inside the sweep (measured slower than all-global).
   // The kernel is FP64-issue / latency bound, so once a batch offers more than ~2 workgroups per
   // CU the occupancy wins (measured: 12.5 ms vs 20.2 ms for 1024 instances, N = 2000).
-  // RL_FORCE_GLOBAL_RINGS=0/1 overrides (tests cover both variants).
+  // RL_FORCE_GLOBAL_RINGS=0/1 and RL_FORCE_RESIDENCY=0/1/2 override (tests cover the variants).
   const char* force = getenv("RL_FORCE_GLOBAL_RINGS");
-  bool want_global = B >= 2 * ctx->num_cu;
-  if (force && (force[0] == '0' || force[0] == '1')) want_global = force[0] == '1';
-  if (in.total * sizeof(double) <= (size_t)ctx->max_lds && !want_global) {
-    p.rings_in_lds = true;
-    p.lds_bytes = in.total * sizeof(double);
-    p.gscratch_doubles = 0;
-  } else {
-    rl::SweepLds out = rl::sweep_lds_layout(n, N, nL, nR, false);
-    p.rings_in_lds = false;
-    p.lds_bytes = out.total * sizeof(double);
-    p.gscratch_doubles = (size_t)2 * ((N + 1) & ~1) + (size_t)2 * (nL + rl::kRingPad) + (size_t)2 * (nR + rl::kRingPad);
+  int want = B >= 2 * ctx->num_cu ? 0 : 1;    // 0 all global, 1 all LDS, 2 crossings in LDS
+  if (force && (force[0] == '0' || force[0] == '1')) want = force[0] == '1' ? 0 : 1;
+  if (const char* r = getenv("RL_FORCE_RESIDENCY")) if (r[0] >= '0' && r[0] <= '2') want = r[0] - '0';
+  rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true, true);
+  if (want == 1 && in.total * sizeof(double) > (size_t)ctx->max_lds) want = 0;
+  if (want == 2) {
+    rl::SweepLds mid = rl::sweep_lds_layout(n, N, nL, nR, false, true);
+    if (mid.total * sizeof(double) > (size_t)ctx->max_lds) want = 0;
   }
+  p.rings_in_lds = want == 1;
+  p.sigma_in_lds = want != 0;
+  rl::SweepLds L = rl::sweep_lds_layout(n, N, nL, nR, p.rings_in_lds, p.sigma_in_lds);
+  p.lds_bytes = L.total * sizeof(double);
+  p.gscratch_doubles = (p.sigma_in_lds ? 0 : (size_t)2 * ((N + 1) & ~1)) +
+                       (p.rings_in_lds ? 0 : (size_t)2 * (nL + rl::kRingPad) + (size_t)2 * (nR + rl::kRingPad));
   return p;
 }
 
-template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false>
+template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL>
 int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
-  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP>;
+  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL>;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
@@ -168,6 +173,8 @@ int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepAr
     return p.rings_in_lds ? launch_sweep_t<5, 256, true, true>(ctx, a, p.lds_bytes)
                           : launch_sweep_t<5, 256, false, true>(ctx, a, p.lds_bytes);
   }
+  if (k == 5 && !joint && !p.rings_in_lds && p.sigma_in_lds)
+    return launch_sweep_t<5, 256, false, false, false, true>(ctx, a, p.lds_bytes);
   if (k == 5) {
     if (a.dbg)  // recording instantiation (test aid): same source, one extra store block per step
       return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, true>(ctx, a, p.lds_bytes)
@@ -560,7 +567,12 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   RL_HIP(hipSetDevice(ctx->device));
   SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR, B);
   if (p.lds_bytes > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "problem does not fit LDS");
-  if (!p.rings_in_lds) {
+  if (p.sigma_in_lds && !p.rings_in_lds && (joint || k != 5 || a.dbg)) {   // the mixed residency exists for the k = 5 sweep only
+    p.sigma_in_lds = false;
+    p.lds_bytes = rl::sweep_lds_layout(n, N, a.nL, a.nR, false, false).total * sizeof(double);
+    p.gscratch_doubles += (size_t)2 * ((N + 1) & ~1);
+  }
+  if (p.gscratch_doubles) {
     const size_t need = p.gscratch_doubles * (size_t)B;
     if (trk->gscratch.n < need) RL_HIP(trk->gscratch.alloc(need));
     a.gscratch = trk->gscratch.p;
@@ -569,7 +581,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   if (stats) {
     stats->lds_bytes = (int)p.lds_bytes;
     stats->block_threads = p.block;
-    stats->rings_in_lds = p.rings_in_lds ? 1 : 0;
+    stats->rings_in_lds = p.rings_in_lds ? 1 : (p.sigma_in_lds ? 2 : 0);
   }
   if (plan_out) *plan_out = p;
   return launch_sweep(ctx, k, p, a, joint);

@@ -238,21 +238,23 @@ def test_search_modes_bitwise_equal(rl, fits, rings):
 
 
 def test_ring_residency_variants_agree(rl, fits, rings, monkeypatch):
-    """Rings + crossings LDS-resident (1 workgroup/CU) vs in global scratch (4 workgroups/CU): same
-    kernel template, different address spaces -> bit-identical results."""
+    """The per-instance state in LDS (1 workgroup/CU), in global scratch (4 workgroups/CU), or split -- crossings
+    in LDS, ring vertices global (2 workgroups/CU): same kernel template, different address spaces ->
+    bit-identical results."""
     t, cx, cy, k, length = spline(fits, "c100")
     N, B = 600, 5
     widths = monza_like_widths(rl, fits, rings, "c100", N, B, seed=21)
     i_start = rl.batch.default_i_start(len(cx), k, 2, seed=3)
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
     res = {}
-    for v in ("0", "1"):
-        monkeypatch.setenv("RL_FORCE_GLOBAL_RINGS", v)
+    for v in ("0", "1", "2"):
+        monkeypatch.setenv("RL_FORCE_RESIDENCY", v)
         res[v] = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
-        assert res[v][4].rings_in_lds == (1 if v == "0" else 0)
-    np.testing.assert_array_equal(res["0"][0], res["1"][0])
-    np.testing.assert_array_equal(res["0"][1], res["1"][1])
-    np.testing.assert_array_equal(res["0"][2], res["1"][2])
+        assert res[v][4].rings_in_lds == int(v)
+    for v in ("1", "2"):
+        np.testing.assert_array_equal(res["0"][0], res[v][0])
+        np.testing.assert_array_equal(res["0"][1], res[v][1])
+        np.testing.assert_array_equal(res["0"][2], res[v][2])
 
 
 def test_bound_points_form_matches_widths_form(rl, fits):
