@@ -73,6 +73,11 @@ _SIGNATURES = {
     "rl_mintime_solve_batch": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, ctypes.c_int,
                                               ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp,
                                               _dp, ctypes.c_int, ctypes.c_double, _dp]),
+    "rl_mintime_solve_batch_dev": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                                  ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp,
+                                                  _vp, ctypes.c_int, ctypes.c_double, _vp]),
+    "rl_qss_sim_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp,
+                                      ctypes.c_int, _dp, _vp]),
     "rl_mincurv_global_batch_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                                    _vp, _vp, _vp, _vp, ctypes.POINTER(Stats)]),
     "rl_mincurv_global_batch_host": (ctypes.c_int, [_vp, _vp, _dp, ctypes.c_int, ctypes.c_double,

@@ -27,6 +27,7 @@ thread_local std::string g_err;
 double* g_dbg_buf = nullptr;   // rl_debug_dump_enable: step / window dump of the sweep kernels (tests)
 size_t g_dbg_len = 0;
 int g_dbg_instances = 0;
+thread_local bool g_mt_poll = false;   // set by the host entry point of the min-time solve: poll for early exit
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -71,7 +72,35 @@ struct rl_ctx {
   int max_lds = 65536;
   int num_cu = 0;
   bool force_global_v1 = false;  // test hook: RL_GLOBAL_V1=1 keeps the generic kernel
+  // Device scratch owned by the context (grow-only): the *_dev entry points of the QSS simulator and the
+  // min-time solve carve their work arrays out of it, so that steady-state calls allocate nothing.
+  void* arena = nullptr;
+  size_t arena_cap = 0;
 };
+
+namespace {
+// sequential carve-out of the context's scratch arena; reserve() first with the total
+struct Arena {
+  rl_ctx* ctx; size_t off = 0;
+  explicit Arena(rl_ctx* c) : ctx(c) {}
+  static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= ctx->arena_cap) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(ctx->stream);          // nothing in flight may still use the old block
+    if (e != hipSuccess) return e;
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    ctx->arena = nullptr; ctx->arena_cap = 0;
+    e = hipMalloc(&ctx->arena, bytes);
+    if (e == hipSuccess) ctx->arena_cap = bytes;
+    return e;
+  }
+  template <typename T> T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(static_cast<char*>(ctx->arena) + off);
+    off += pad(count * sizeof(T));
+    return p;
+  }
+};
+}  // namespace
 
 struct rl_track {
   rl_ctx* ctx = nullptr;
@@ -243,6 +272,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
 
 void rl_ctx_destroy(rl_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
@@ -825,41 +855,55 @@ int rl_mincurv_sweep_joint(rl_ctx* ctx, rl_track* trk, const int* i_start, int m
   return sweep_single(ctx, trk, i_start, max_iter, cx, cy, points, n_success, stats, true);
 }
 
-int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, const double* acc_c,
-               int acc_m, const double* dcc_x, const double* dcc_c, int dcc_m, const double* params,
-               int* iters) {
+int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, const double* acc_c,
+                   int acc_m, const double* dcc_x, const double* dcc_c, int dcc_m, const double* params,
+                   int* iters) {
   if (!ctx || !points || !acc_x || !acc_c || !dcc_x || !dcc_c || !params || !iters)
     return fail(RL_ERR_ARG, "null argument");
   if (B <= 0 || N < 2 || acc_m < 1 || dcc_m < 1) return fail(RL_ERR_ARG, "bad sizes");
+  if (N >= 65535) return fail(RL_ERR_UNSUPPORTED, "qss: owner indices are 16 bits");
   RL_HIP(hipSetDevice(ctx->device));
   const int cap = 4 * N + 16;
-  DevBuf<double> dpts, dax, dac, ddx, ddc;
-  DevBuf<int> dfl, dnw, dit;
-  DevBuf<double> dcst;
-  RL_HIP(dpts.alloc((size_t)B * N * RL_NCOL));
-  RL_HIP(dax.alloc(acc_m + 1)); RL_HIP(dac.alloc((size_t)4 * acc_m));
-  RL_HIP(ddx.alloc(dcc_m + 1)); RL_HIP(ddc.alloc((size_t)4 * dcc_m));
-  RL_HIP(dfl.alloc((size_t)B * cap * 5)); RL_HIP(dnw.alloc((size_t)B * cap)); RL_HIP(dit.alloc(B));
-  RL_HIP(dcst.alloc((size_t)B * 3 * N));
-  if (N >= 65535) return fail(RL_ERR_UNSUPPORTED, "qss: owner indices are 16 bits");
   const size_t lds = ((size_t)2 * N + 5 * (acc_m + dcc_m) + 2) * sizeof(double) + (size_t)rl::kQssStamp * sizeof(int) +
                      (((size_t)N * sizeof(unsigned short) + 7) & ~(size_t)7);  // speed, lon acc, tables, stamp buckets, owner
   if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "qss: trajectory too long for the LDS-resident profile");
-  RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RL_HIP(hipMemcpyAsync(dax.p, acc_x, dax.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RL_HIP(hipMemcpyAsync(dac.p, acc_c, dac.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RL_HIP(hipMemcpyAsync(ddx.p, dcc_x, ddx.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RL_HIP(hipMemcpyAsync(ddc.p, dcc_c, ddc.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  Arena ar(ctx);
+  RL_HIP(ar.reserve(Arena::pad((acc_m + 1) * 8) + Arena::pad((size_t)4 * acc_m * 8) + Arena::pad((dcc_m + 1) * 8) +
+                    Arena::pad((size_t)4 * dcc_m * 8) + Arena::pad((size_t)B * cap * 5 * 4) + Arena::pad((size_t)B * cap * 4) +
+                    Arena::pad((size_t)B * 3 * N * 8)));
+  double* dax = ar.take<double>(acc_m + 1); double* dac = ar.take<double>((size_t)4 * acc_m);
+  double* ddx = ar.take<double>(dcc_m + 1); double* ddc = ar.take<double>((size_t)4 * dcc_m);
+  int* dfl = ar.take<int>((size_t)B * cap * 5); int* dnw = ar.take<int>((size_t)B * cap);
+  double* dcst = ar.take<double>((size_t)B * 3 * N);
+  // the lookup tables are tiny host arrays (scipy CubicSpline pieces): pageable copies are staged by the runtime
+  RL_HIP(hipMemcpyAsync(dax, acc_x, (acc_m + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(dac, acc_c, (size_t)4 * acc_m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(ddx, dcc_x, (dcc_m + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(ddc, dcc_c, (size_t)4 * dcc_m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   rl::QssArgs a;
-  a.points = dpts.p; a.B = B; a.N = N;
-  a.acc_x = dax.p; a.acc_c = dac.p; a.acc_m = acc_m;
-  a.dcc_x = ddx.p; a.dcc_c = ddc.p; a.dcc_m = dcc_m;
+  a.points = points; a.B = B; a.N = N;
+  a.acc_x = dax; a.acc_c = dac; a.acc_m = acc_m;
+  a.dcc_x = ddx; a.dcc_c = ddc; a.dcc_m = dcc_m;
   a.max_lon_acc = params[0]; a.max_lon_dcc = params[1]; a.max_left_acc = params[2];
   a.max_right_acc = params[3]; a.max_speed = params[4]; a.max_jerk = params[5];
-  a.flags = dfl.p; a.fresh = dnw.p; a.cst = dcst.p; a.cap = cap; a.iters = dit.p;
+  a.flags = dfl; a.fresh = dnw; a.cst = dcst; a.cap = cap; a.iters = iters;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_sim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(rl::k_qss_sim, dim3(B), dim3(64), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
+  return RL_OK;
+}
+
+int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, const double* acc_c,
+               int acc_m, const double* dcc_x, const double* dcc_c, int dcc_m, const double* params,
+               int* iters) {
+  if (!ctx || !points || !iters) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0 || N < 2) return fail(RL_ERR_ARG, "bad sizes");
+  RL_HIP(hipSetDevice(ctx->device));
+  DevBuf<double> dpts;
+  DevBuf<int> dit;
+  RL_HIP(dpts.alloc((size_t)B * N * RL_NCOL)); RL_HIP(dit.alloc(B));
+  RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = rl_qss_sim_dev(ctx, dpts.p, B, N, acc_x, acc_c, acc_m, dcc_x, dcc_c, dcc_m, params, dit.p)) return rc;
   RL_HIP(hipMemcpyAsync(points, dpts.p, dpts.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipMemcpyAsync(iters, dit.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipStreamSynchronize(ctx->stream));
@@ -941,10 +985,10 @@ int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double*
   return RL_OK;
 }
 
-int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
-                           const double* left, const double* right, int bounds_per_instance, double margin,
-                           double track_length, double average_track_width, double speed_cap, double* X, double* U,
-                           double* T, int max_iter, double tol, double* stats) {
+int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
+                               const double* left, const double* right, int bounds_per_instance, double margin,
+                               double track_length, double average_track_width, double speed_cap, double* X, double* U,
+                               double* T, int max_iter, double tol, double* stats) {
   if (!ctx || !model || !s || !kappa || !left || !right || !X || !U || !T || !stats) return fail(RL_ERR_ARG, "null argument");
   if (B <= 0 || N < 4 || !(track_length > 0.0) || max_iter < 1 || !(tol > 0.0)) return fail(RL_ERR_ARG, "bad sizes");
   if (!(average_track_width > 0.0) || !(speed_cap > 0.0)) return fail(RL_ERR_ARG, "bad scales");
@@ -961,39 +1005,38 @@ int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const
   P.sw[5] = su[0]; P.sw[6] = su[2]; P.sw[7] = su[3]; P.sw[8] = 1.0;
   for (int c = 0; c < 6; ++c) P.se[c] = 1.0 / sx[c];
   P.se[6] = 1.0 / su[3];
-  const size_t bn = (size_t)B * N, nb_ = bounds_per_instance ? bn : (size_t)N;
-  for (size_t i = 0; i < nb_; ++i)
-    if (!(right[i] + margin < left[i] - margin)) return fail(RL_ERR_ARG, "track narrower than the vehicle plus margins (min_time_optimizer.py:135)");
-  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, w, sv, yv, zv, fun, jac, hes, dw, dy, blk, vec, scal;
-  RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(nb_)); RL_HIP(dr.alloc(nb_));
-  RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn));
-  RL_HIP(w.alloc(bn * rl::kMtNv)); RL_HIP(sv.alloc(bn * rl::kMtNi)); RL_HIP(yv.alloc(bn * rl::kMtNe)); RL_HIP(zv.alloc(bn * rl::kMtNi));
-  RL_HIP(fun.alloc(bn * rl::kMtNf)); RL_HIP(jac.alloc(bn * rl::kMtNf * rl::kMtLoc)); RL_HIP(hes.alloc(bn * rl::kMtLoc * rl::kMtLoc));
-  RL_HIP(dw.alloc(bn * rl::kMtNv)); RL_HIP(dy.alloc(bn * rl::kMtNe)); RL_HIP(blk.alloc(bn * 3 * 256)); RL_HIP(vec.alloc(bn * 16));
-  RL_HIP(scal.alloc((size_t)B * 16));
-  auto up = [&](DevBuf<double>& d, const double* h) { return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream); };
-  RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
-  RL_HIP(up(dX, X)); RL_HIP(up(dU, U)); RL_HIP(up(dT, T));
-  P.s = ds.p; P.kappa = dk.p; P.left = dl.p; P.right = dr.p;
+  P.s = s; P.kappa = kappa; P.left = left; P.right = right;
+  const size_t bn = (size_t)B * N;
+  const size_t counts[] = {bn * rl::kMtNv, bn * rl::kMtNi, bn * rl::kMtNe, bn * rl::kMtNi, bn * rl::kMtNf,
+                           bn * rl::kMtNf * rl::kMtLoc, bn * rl::kMtLoc * rl::kMtLoc, bn * rl::kMtNv, bn * rl::kMtNe,
+                           bn * 3 * 256, bn * 16, (size_t)B * 16};
+  size_t total = 0;
+  for (size_t c : counts) total += Arena::pad(c * sizeof(double));
+  Arena ar(ctx);
+  RL_HIP(ar.reserve(total));
   rl::MtState st;
-  st.B = B; st.N = N; st.w = w.p; st.s = sv.p; st.y = yv.p; st.z = zv.p; st.fun = fun.p; st.jac = jac.p; st.hes = hes.p;
-  st.dw = dw.p; st.dy = dy.p; st.blk = blk.p; st.vec = vec.p; st.scal = scal.p; st.tol = tol;
-  RL_HIP(hipMemsetAsync(scal.p, 0, scal.n * sizeof(double), ctx->stream));
-  RL_HIP(hipMemsetAsync(hes.p, 0, hes.n * sizeof(double), ctx->stream));
+  st.B = B; st.N = N;
+  st.w = ar.take<double>(counts[0]); st.s = ar.take<double>(counts[1]); st.y = ar.take<double>(counts[2]);
+  st.z = ar.take<double>(counts[3]); st.fun = ar.take<double>(counts[4]); st.jac = ar.take<double>(counts[5]);
+  st.hes = ar.take<double>(counts[6]); st.dw = ar.take<double>(counts[7]); st.dy = ar.take<double>(counts[8]);
+  st.blk = ar.take<double>(counts[9]); st.vec = ar.take<double>(counts[10]); st.scal = ar.take<double>(counts[11]);
+  st.tol = tol;
+  RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
+  RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
   const dim3 gn((N + 63) / 64, B), bn64(64);
-  hipLaunchKernelGGL(rl::k_mt_pack, gn, bn64, 0, ctx->stream, P, st, (const double*)dX.p, (const double*)dU.p, (const double*)dT.p);
+  hipLaunchKernelGGL(rl::k_mt_pack, gn, bn64, 0, ctx->stream, P, st, (const double*)X, (const double*)U, (const double*)T);
   hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, ctx->stream, P, st);
   hipLaunchKernelGGL(rl::k_mt_init, dim3((N * rl::kMtNi + 255) / 256, B), dim3(256), 0, ctx->stream, P, st, 1e-1, 1e-4);
   RL_HIP(hipGetLastError());
-  for (int it = 0; it < max_iter; ++it) {
+  for (int it = 0; it < max_iter; ++it) {   // finished instances return at once from every kernel
     hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, B, rl::kMtJacSlices), bn64, 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, B, rl::kMtHesSlices), bn64, 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_kkt, dim3(B), dim3(64), 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_step, dim3(B), dim3(256), 0, ctx->stream, P, st);
-    if ((it & 7) == 7) {   // every 8 iterations: stop early once every instance has finished
+    if (g_mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
       std::vector<double> h((size_t)B * 16);
-      RL_HIP(hipMemcpyAsync(h.data(), scal.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      RL_HIP(hipMemcpyAsync(h.data(), st.scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       RL_HIP(hipStreamSynchronize(ctx->stream));
       bool all = true;
       for (int b = 0; b < B; ++b) all = all && h[(size_t)b * 16 + 5] != 0.0;
@@ -1004,20 +1047,38 @@ int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const
   hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, ctx->stream, P, st);
   hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, B, rl::kMtJacSlices), bn64, 0, ctx->stream, P, st);
   hipLaunchKernelGGL(rl::k_mt_residuals, dim3(B), dim3(64), 0, ctx->stream, P, st);
-  hipLaunchKernelGGL(rl::k_mt_unpack, gn, bn64, 0, ctx->stream, P, st, dX.p, dU.p, dT.p);
+  hipLaunchKernelGGL(rl::k_mt_unpack, gn, bn64, 0, ctx->stream, P, st, X, U, T);
+  hipLaunchKernelGGL(rl::k_mt_stats, dim3((B + 63) / 64), bn64, 0, ctx->stream, st, stats);
   RL_HIP(hipGetLastError());
+  return RL_OK;
+}
+
+int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
+                           const double* left, const double* right, int bounds_per_instance, double margin,
+                           double track_length, double average_track_width, double speed_cap, double* X, double* U,
+                           double* T, int max_iter, double tol, double* stats) {
+  if (!ctx || !model || !s || !kappa || !left || !right || !X || !U || !T || !stats) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0 || N < 4) return fail(RL_ERR_ARG, "bad sizes");
+  RL_HIP(hipSetDevice(ctx->device));
+  const size_t bn = (size_t)B * N, nb_ = bounds_per_instance ? bn : (size_t)N;
+  for (size_t i = 0; i < nb_; ++i)
+    if (!(right[i] + margin < left[i] - margin)) return fail(RL_ERR_ARG, "track narrower than the vehicle plus margins (min_time_optimizer.py:135)");
+  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, dst;
+  RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(nb_)); RL_HIP(dr.alloc(nb_));
+  RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn)); RL_HIP(dst.alloc((size_t)B * 12));
+  auto up = [&](DevBuf<double>& d, const double* h) { return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream); };
+  RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
+  RL_HIP(up(dX, X)); RL_HIP(up(dU, U)); RL_HIP(up(dT, T));
+  g_mt_poll = true;
+  const int rc = rl_mintime_solve_batch_dev(ctx, model, B, N, ds.p, dk.p, dl.p, dr.p, bounds_per_instance, margin, track_length,
+                                            average_track_width, speed_cap, dX.p, dU.p, dT.p, max_iter, tol, dst.p);
+  g_mt_poll = false;
+  if (rc) return rc;
   RL_HIP(hipMemcpyAsync(X, dX.p, dX.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipMemcpyAsync(U, dU.p, dU.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipMemcpyAsync(T, dT.p, dT.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  std::vector<double> h((size_t)B * 16);
-  RL_HIP(hipMemcpyAsync(h.data(), scal.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(stats, dst.p, dst.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipStreamSynchronize(ctx->stream));
-  for (int b = 0; b < B; ++b) {
-    const double* q = &h[(size_t)b * 16];
-    double* o = stats + (size_t)b * 12;
-    o[0] = q[6]; o[1] = q[2]; o[2] = q[3]; o[3] = q[4]; o[4] = q[11]; o[5] = q[5]; o[6] = q[0]; o[7] = q[1];
-    o[8] = q[7]; o[9] = q[10]; o[10] = 0.0; o[11] = 0.0;
-  }
   return RL_OK;
 }
 

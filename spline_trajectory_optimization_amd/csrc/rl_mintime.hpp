@@ -716,6 +716,16 @@ __global__ void k_mt_unpack(MtProblem P, MtState st, double* X, double* U, doubl
   T[o] = w[8] * P.sw[8];
 }
 
+// per-instance report [B,12] (include/rl_mincurv.h: rl_mintime_solve_batch)
+__global__ void k_mt_stats(MtState st, double* stats) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= st.B) return;
+  const double* q = st.scal + (size_t)b * 16;
+  double* o = stats + (size_t)b * 12;
+  o[0] = q[6]; o[1] = q[2]; o[2] = q[3]; o[3] = q[4]; o[4] = q[11]; o[5] = q[5]; o[6] = q[0]; o[7] = q[1];
+  o[8] = q[7]; o[9] = q[10]; o[10] = 0.0; o[11] = 0.0;
+}
+
 // initial slacks / multipliers from the functions at w0:  s = max(-g, 1e-2), z = mu0 / s, y = 0
 __global__ void k_mt_init(MtProblem P, MtState st, double mu0, double delta0) {
   const int b = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x, N = P.N;

@@ -292,3 +292,41 @@ def mintime_solve_batch(model, s, kappa, left, right, margin, track_length, X0, 
                                          U.ctypes.data_as(_dp), T.ctypes.data_as(_dp), int(max_iter), float(tol),
                                          stats.ctypes.data_as(_dp)))
     return X, U, T, stats
+
+
+def qss_sim_torch(points, acc_x, acc_c, dcc_x, dcc_c, params):
+    """Simulator.run_simulation on a DEVICE table batch [B,N,19] (float64 cuda tensor), in place; enqueues on
+    torch's current stream, no sync (rl_qss_sim_dev).  Returns the iterations tensor [B] (int32, cuda)."""
+    import torch
+    assert points.is_cuda and points.dtype == torch.float64 and points.is_contiguous() and points.shape[-1] == _lib.NCOL
+    B, N = points.shape[0], points.shape[1]
+    ctx = Context.get(points.device.index)
+    ctx.set_stream(torch.cuda.current_stream(points.device).cuda_stream)
+    ax, axp = as_d(acc_x); ac, acp = as_d(acc_c); dx, dxp = as_d(dcc_x); dc, dcp = as_d(dcc_c); pr, prp = as_d(params)
+    it = torch.empty((B,), dtype=torch.int32, device=points.device)
+    check(ctx.lib.rl_qss_sim_dev(ctx.h, ctypes.c_void_p(points.data_ptr()), B, N, axp, acp, ac.shape[1], dxp, dcp,
+                                 dc.shape[1], prp, ctypes.c_void_p(it.data_ptr())))
+    return it
+
+
+def mintime_solve_torch(model, s, kappa, left, right, margin, track_length, X, U, T, average_track_width=7.0,
+                        speed_cap=30.0, max_iter=120, tol=1e-6):
+    """rl_mintime_solve_batch_dev on DEVICE tensors (float64, cuda, contiguous): s, kappa [N]; left, right [N] or
+    [B,N]; X [B,N,6], U [B,N,4], T [B,N] are updated in place.  Enqueues on torch's current stream, no sync.
+    Returns the stats tensor [B,12]."""
+    import torch
+    dev = X.device
+    for t_ in (s, kappa, left, right, X, U, T):
+        assert t_.is_cuda and t_.dtype == torch.float64 and t_.is_contiguous()
+    B, N = T.shape
+    assert tuple(X.shape) == (B, N, 6) and tuple(U.shape) == (B, N, 4) and s.shape[0] == kappa.shape[0] == N
+    per = left.dim() == 2
+    ctx = Context.get(dev.index)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    mv, mp = as_d([float(model[k]) for k in DT_PARAMS])
+    stats = torch.empty((B, 12), dtype=torch.float64, device=dev)
+    p = lambda t_: ctypes.c_void_p(t_.data_ptr())  # noqa: E731
+    check(ctx.lib.rl_mintime_solve_batch_dev(ctx.h, mp, B, N, p(s), p(kappa), p(left), p(right), int(per), float(margin),
+                                             float(track_length), float(average_track_width), float(speed_cap), p(X), p(U),
+                                             p(T), int(max_iter), float(tol), p(stats)))
+    return stats
