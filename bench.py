@@ -400,8 +400,10 @@ def run_rank(args):
                          "traffic_source": prof.get("source") if prof else None, "traffic_measured_in_run": False,
                          "kernel": "k_sweep", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
-                         "actual_limiter": "FP64 VALU instruction issue (state is on-chip; the HBM roofline is the "
-                                           "one north_star designates, the kernel is not HBM bound)",
+                         "actual_limiter": "latency of one step's dependent chain at the occupancy the batch allows (4 "
+                                           "workgroups per CU; VALU ~59 % active, 61 % of wave cycles waiting); the solver "
+                                           "state is on chip: the HBM roofline is the one north_star designates, the kernel "
+                                           "is not HBM bound (DESIGN.md section 3)",
                          "valu": valu_block(prof, kernel_ms)},
         }
         if world == 1 and args.workload == "monza" and not args.no_global:

@@ -306,6 +306,15 @@ struct SweepArgs {
   int debug;            // timing ablations, only in -DRL_ABLATION builds (results are WRONG when non-zero)
 };
 
+// In-kernel stamps (diagnostic build -DRL_STAMPS only, tools/stamp_sweep.py): where a wave's cycles go, per phase.
+#ifdef RL_STAMPS
+#define RL_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RL_STAMP_ADD(slot, t1, t0) st_acc[slot] += (t1) - (t0)
+#else
+#define RL_STAMP(var) do { } while (0)
+#define RL_STAMP_ADD(slot, t1, t0) do { } while (0)
+#endif
+
 // Timing-ablation switches exist only in a diagnostic build (hipcc -DRL_ABLATION, tools/profile_bench.sh):
 // the shipped library has no way to skip a phase.
 #ifdef RL_ABLATION
@@ -563,6 +572,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     refresh(0, N, 0, 0, mode == 2 ? 1 : mode);  // first fill also seeds the hints
   }
   __syncthreads();
+#ifdef RL_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0, st_begin = 0;
+  RL_STAMP(st_begin);
+#endif
   const int ignore_front = K / 2, ignore_rear = K - ignore_front;  // optimizer.py:297-302
   const int i_max = n - ignore_rear, i_min = ignore_front;
   const double* __restrict__ D0 = tr.D;
@@ -867,6 +880,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
         const double zx = cx[idx], zy = cy[idx];
 
+        RL_STAMP(st_t0);
         // ---- phase 1: cost sums (a7) and the clamp interval of the box constraints (a8)
         double hxx = 0.0, hyy = 0.0, gx = 0.0, gy = 0.0;
         double lox = -INFINITY, hix = INFINITY, loy = -INFINITY, hiy = INFINITY;
@@ -922,7 +936,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = 0.0;
           r[4] = -INFINITY; r[5] = INFINITY; r[6] = -INFINITY; r[7] = INFINITY; r[8] = 0.0;
         }
+        RL_STAMP(st_t1); RL_STAMP_ADD(0, st_t1, st_t0);
         __syncthreads();
+        RL_STAMP(st_t0); RL_STAMP_ADD(1, st_t0, st_t1);
         // ---- phase 2: closed-form QP (a11) on wave 0 only; the verdict goes through LDS
         if (wave == 0) {
           double s[9];
@@ -969,7 +985,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
             red[NW * 12] = okw ? 1.0 : 0.0;
           }
         }
+        RL_STAMP(st_t1); RL_STAMP_ADD(2, st_t1, st_t0);
         __syncthreads();
+        RL_STAMP(st_t0); RL_STAMP_ADD(3, st_t0, st_t1);
         const bool ok = red[NW * 12] != 0.0;
         if (ok) {
           // ---- phase 3: re-sample (a3) and re-intersect (a5) what moved
@@ -985,7 +1003,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
             // every update (optimizer.py:286-288) and so does this instantiation.
             refresh(0, N, 0, 0, mode);
           } else if (!RL_ABLATE(a, 1)) refresh(s0, s1, j0, j1, mode);
+          RL_STAMP(st_t1); RL_STAMP_ADD(4, st_t1, st_t0);
           __syncthreads();
+          RL_STAMP(st_t0); RL_STAMP_ADD(5, st_t0, st_t1);
           ++ok_count;
         } else {
           ++n_skipped;
@@ -995,6 +1015,14 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     }
   }
 
+#ifdef RL_STAMPS
+  RL_STAMP(st_t1);
+  if (a.dbg && lane == 0) {
+    double* o = a.dbg + ((size_t)b * NW + wave) * 8;
+    for (int q = 0; q < 6; ++q) o[q] = (double)st_acc[q];
+    o[6] = (double)(st_t1 - st_begin);
+  }
+#endif
   // ---- epilogue
   if (tid == 0 && a.status) a.status[b] = n_skipped;
   for (int j = tid; j < n; j += BLOCK) {

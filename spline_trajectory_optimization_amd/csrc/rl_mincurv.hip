@@ -204,6 +204,9 @@ int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepAr
   }
   if (k == 5 && !joint && !p.rings_in_lds && p.sigma_in_lds)
     return launch_sweep_t<5, 256, false, false, false, true>(ctx, a, p.lds_bytes);
+#ifdef RL_STAMPS
+  if (k == 5 && !p.rings_in_lds && !p.sigma_in_lds) return launch_sweep_t<5, 256, false>(ctx, a, p.lds_bytes);  // stamps go to a.dbg
+#endif
   if (k == 5) {
     if (a.dbg)  // recording instantiation (test aid): same source, one extra store block per step
       return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, true>(ctx, a, p.lds_bytes)
@@ -581,8 +584,11 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
 #endif
   if (g_dbg_instances > 0 && (joint || k == 5)) {
     const int ninst = std::min(g_dbg_instances, B);
-    const size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256)
-                              : (size_t)ninst * max_iter * 2 * (size_t)(i_max - i_min) * (rl::kSweepDumpHead + 2 * n);
+    size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256)
+                        : (size_t)ninst * max_iter * 2 * (size_t)(i_max - i_min) * (rl::kSweepDumpHead + 2 * n);
+#ifdef RL_STAMPS
+    need = std::max(need, (size_t)B * 4 * 8);   // diagnostic build: per-wave phase stamps of every instance
+#endif
     a.dbg_instances = ninst;
     if (g_dbg_len < need) {
       if (g_dbg_buf) (void)hipFree(g_dbg_buf);
