@@ -1015,7 +1015,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   const size_t bn = (size_t)B * N;
   const size_t counts[] = {bn * rl::kMtNv, bn * rl::kMtNi, bn * rl::kMtNe, bn * rl::kMtNi, bn * rl::kMtNf,
                            bn * rl::kMtNf * rl::kMtLoc, bn * rl::kMtLoc * rl::kMtLoc, bn * rl::kMtNv, bn * rl::kMtNe,
-                           bn * 3 * 256, bn * 16, (size_t)B * 16};
+                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16};
   size_t total = 0;
   for (size_t c : counts) total += Arena::pad(c * sizeof(double));
   Arena ar(ctx);
@@ -1026,6 +1026,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.z = ar.take<double>(counts[3]); st.fun = ar.take<double>(counts[4]); st.jac = ar.take<double>(counts[5]);
   st.hes = ar.take<double>(counts[6]); st.dw = ar.take<double>(counts[7]); st.dy = ar.take<double>(counts[8]);
   st.blk = ar.take<double>(counts[9]); st.vec = ar.take<double>(counts[10]); st.scal = ar.take<double>(counts[11]);
+  st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
   st.tol = tol;
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
   RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
@@ -1038,6 +1039,8 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, B, rl::kMtJacSlices), bn64, 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, B, rl::kMtHesSlices), bn64, 0, ctx->stream, P, st);
+    hipLaunchKernelGGL(rl::k_mt_prepare, dim3(B), dim3(64), 0, ctx->stream, P, st);
+    hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, B), dim3(64), 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_kkt, dim3(B), dim3(64), 0, ctx->stream, P, st);
     hipLaunchKernelGGL(rl::k_mt_step, dim3(B), dim3(256), 0, ctx->stream, P, st);
     if (g_mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished

@@ -127,6 +127,9 @@ struct MtState {       // per-batch device arrays, instance-major
   double* dy;     // [B,N,7]
   double* blk;    // [B,N,3,256] factor blocks: S^-1, P, Q
   double* vec;    // [B,N,16] right-hand side / solution scratch
+  double* dblk;   // [B,N,256] assembled diagonal blocks D_j (without delta)
+  double* eblk;   // [B,N,256] assembled coupling blocks E_j = M[j+1][j]
+  double* rhs;    // [B,N,16]  assembled right-hand sides
   double* scal;   // [B,16] per-instance scalars: 0 mu, 1 delta, 2 kkt, 3 viol, 4 compl, 5 status (0 run, 1 converged,
                   //        2 failed), 6 iterations, 7 last alpha, 8 theta0, 9 phi0, 10 refactorisations, 11 lap time
   double tol;
@@ -302,12 +305,6 @@ __device__ __forceinline__ void mt_gemv_acc(double* y, const double* M, const do
   }
 }
 
-struct MtKktLds {
-  double S[256], E[256], F[256], Pm[256], Qm[256], Sl[256], Ct[256], T1[256];
-  double r[16], rl[16], x[16], xl[16], xn[16];
-  double Do[81], Dn[81];      // D_next of the previous pair carried to this node
-  double red[64];
-};
 
 // cost gradient of node j (scaled unknowns)
 __device__ __forceinline__ double mt_cost_grad(const double* w, int N, int j, int a) {
@@ -350,30 +347,18 @@ __device__ __forceinline__ void mt_residuals(const MtProblem& P, const double* w
   kkt = wave_max(kkt); viol = wave_max(viol); compl_ = wave_max(compl_); errmu = wave_max(errmu); lap = wave_sum(lap);
 }
 
-// k_mt_kkt: one wave per instance.
-//   1. residuals r_d, r_c, r_g at the current point -> kkt / viol / compl, convergence test, barrier update
-//   2. block elimination of the cyclic block-tridiagonal KKT system (retry with a larger delta until the
-//      pivot signs are right), solution dw, dy
-__global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
-  __shared__ MtKktLds L;
+// k_mt_prepare: one wave per instance: residuals r_d, r_c, r_g at the current point -> kkt / viol / compl,
+// convergence test, barrier update (everything the assembly of the right-hand side needs to know)
+__global__ void __launch_bounds__(64) k_mt_prepare(MtProblem P, MtState st) {
   const int b = blockIdx.x, lane = threadIdx.x, N = P.N;
   double* scal = st.scal + (size_t)b * 16;
   if (scal[5] != 0.0) return;
   mt_instance(P, b);
-  const double* w = st.w + (size_t)b * N * kMtNv;
-  const double* sv = st.s + (size_t)b * N * kMtNi;
-  const double* yv = st.y + (size_t)b * N * kMtNe;
-  const double* zv = st.z + (size_t)b * N * kMtNi;
-  const double* fun = st.fun + (size_t)b * N * kMtNf;
-  const double* jac = st.jac + (size_t)b * N * kMtNf * kMtLoc;
-  const double* hes = st.hes + (size_t)b * N * kMtLoc * kMtLoc;
-  double* blk = st.blk + (size_t)b * N * 3 * 256;
-  double* vec = st.vec + (size_t)b * N * 16;
-  double mu = scal[0], delta = scal[1];
-
-  // ---- 1. residuals
+  double mu = scal[0];
   double kkt, viol, compl_, errmu, lap;
-  mt_residuals(P, w, sv, yv, zv, fun, jac, mu, lane, kkt, viol, compl_, errmu, lap);
+  mt_residuals(P, st.w + (size_t)b * N * kMtNv, st.s + (size_t)b * N * kMtNi, st.y + (size_t)b * N * kMtNe,
+               st.z + (size_t)b * N * kMtNi, st.fun + (size_t)b * N * kMtNf, st.jac + (size_t)b * N * kMtNf * kMtLoc,
+               mu, lane, kkt, viol, compl_, errmu, lap);
   if (lane == 0) { scal[2] = kkt; scal[3] = viol; scal[4] = compl_; scal[11] = lap; }
   if (fmax(kkt, fmax(viol, compl_)) <= st.tol) {
     if (lane == 0) scal[5] = 1.0;
@@ -382,129 +367,159 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
   // monotone barrier update once the barrier problem is solved to 10 mu; no lower than compl <= tol needs
   if (fmax(fmax(kkt, viol), errmu) <= 10.0 * mu) mu = fmax(fmin(0.2 * mu, mu * sqrt(mu)), st.tol / 10.0);
   if (lane == 0) scal[0] = mu;
+}
 
-  // ---- 2. elimination.  Per pair j the 9 x 9 pieces
-  //   Do(j) = Hess_oo + Go' W Go      -> K[j][j]        Dn(j) = Hess_nn + Gn' W Gn -> K[j+1][j+1]
-  //   C(j)  = Hess_no + Gn' W Go      -> K[j+1][j]      (W = z / s)
-  auto pair_pieces = [&](int j, double* Do, double* Dn, double* Cno) {
-    const double* Jj = jac + (size_t)j * kMtNf * kMtLoc;
-    const double* Hj = hes + (size_t)j * kMtLoc * kMtLoc;
-    for (int e = lane; e < 81; e += 64) {
-      const int a = e / 9, c = e - 9 * a;
-      double doo = Hj[a * kMtLoc + c], dnn = Hj[(9 + a) * kMtLoc + 9 + c], cno = Hj[(9 + a) * kMtLoc + c];
-      for (int i = 0; i < kMtNi; ++i) {
-        const double wgt = zv[j * kMtNi + i] / sv[j * kMtNi + i];
-        const double goa = Jj[(kMtNe + i) * kMtLoc + a], goc = Jj[(kMtNe + i) * kMtLoc + c];
-        const double gna = Jj[(kMtNe + i) * kMtLoc + 9 + a], gnc = Jj[(kMtNe + i) * kMtLoc + 9 + c];
-        doo += goa * wgt * goc; dnn += gna * wgt * gnc; cno += gna * wgt * goc;
-      }
-      if (Do) Do[e] = doo;
-      if (Dn) Dn[e] = dnn;
-      if (Cno) Cno[e] = cno;
+// k_mt_assemble: one wave per (node, instance) -- the blocks of the KKT matrix and the right-hand side, all
+// nodes in parallel (this is where the Jacobians / Hessians are read; the sequential elimination then streams
+// ready-made 16 x 16 blocks).  Per pair j the 9 x 9 pieces (W = z / s)
+//   Do(j) = Hess_oo + Go' W Go -> K[j][j]    Dn(j) = Hess_nn + Gn' W Gn -> K[j+1][j+1]    C(j) = Hess_no + Gn' W Go -> K[j+1][j]
+//   D_j = M[j][j]   = [[Do(j) + Dn(j-1) + H_cost (+ delta I, added by the elimination), Ao(j)'], [Ao(j), -eps I]]
+//   E_j = M[j+1][j] = [[C(j) + H_cost off-diagonal, An(j)'], [0, 0]]
+//   r_j = -[ gc_j + Ao(j)' y_j + An(j-1)' y_{j-1} + Go(j)' zeta_j + Gn(j-1)' zeta_{j-1} ;  eq_j ],
+//         zeta = mu / s + W (g + s)
+struct MtAsmLds { double Do[81], Dn[81], Ct[81], w[2][kMtNi], zeta[2][kMtNi]; };
+
+__global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
+  __shared__ MtAsmLds L;
+  const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, N = P.N;
+  const double* scal = st.scal + (size_t)b * 16;
+  if (scal[5] != 0.0) return;
+  const int jp = j == 0 ? N - 1 : j - 1;
+  const double* w = st.w + (size_t)b * N * kMtNv;
+  const double* sv = st.s + (size_t)b * N * kMtNi;
+  const double* yv = st.y + (size_t)b * N * kMtNe;
+  const double* zv = st.z + (size_t)b * N * kMtNi;
+  const double* fun = st.fun + (size_t)b * N * kMtNf;
+  const double* Jo = st.jac + ((size_t)b * N + j) * kMtNf * kMtLoc;
+  const double* Jp = st.jac + ((size_t)b * N + jp) * kMtNf * kMtLoc;
+  const double* Ho = st.hes + ((size_t)b * N + j) * kMtLoc * kMtLoc;
+  const double* Hp = st.hes + ((size_t)b * N + jp) * kMtLoc * kMtLoc;
+  const double mu = scal[0];
+  if (lane < 2 * kMtNi) {
+    const int which = lane / kMtNi, i = lane - which * kMtNi, jj = which ? jp : j;
+    const double s_ = sv[jj * kMtNi + i], z_ = zv[jj * kMtNi + i];
+    const double wgt = z_ / s_;
+    L.w[which][i] = wgt;
+    L.zeta[which][i] = mu / s_ + wgt * (fun[jj * kMtNf + kMtNe + i] + s_);
+  }
+  __syncthreads();
+  for (int e = lane; e < 81; e += 64) {
+    const int a = e / 9, c = e - 9 * a;
+    double doo = Ho[a * kMtLoc + c], cno = Ho[(9 + a) * kMtLoc + c], dnn = Hp[(9 + a) * kMtLoc + 9 + c];
+    for (int i = 0; i < kMtNi; ++i) {
+      const double goa = Jo[(kMtNe + i) * kMtLoc + a], goc = Jo[(kMtNe + i) * kMtLoc + c];
+      const double gna = Jo[(kMtNe + i) * kMtLoc + 9 + a];
+      const double pna = Jp[(kMtNe + i) * kMtLoc + 9 + a], pnc = Jp[(kMtNe + i) * kMtLoc + 9 + c];
+      doo += goa * L.w[0][i] * goc; cno += gna * L.w[0][i] * goc; dnn += pna * L.w[1][i] * pnc;
     }
-  };
-  // diagonal block of node j into dst (needs Do(j) in L.Do and Dn(j-1) in L.Dn), coupling E_j into L.E
-  auto build_diag = [&](int j, double* dst) {
-    const double* Jj = jac + (size_t)j * kMtNf * kMtLoc;
-    for (int e = lane; e < 256; e += 64) {
-      const int i = e >> 4, c = e & 15;
-      double v = 0.0;
-      if (i < 9 && c < 9) {
-        v = L.Do[i * 9 + c] + L.Dn[i * 9 + c];
-        if (i == c) { v += delta; if (i >= 5 && i < 8) v += kMtCostDiag; }
-      } else if (i < 9) v = Jj[(c - 9) * kMtLoc + i];        // Ao(j)'
-      else if (c < 9) v = Jj[(i - 9) * kMtLoc + c];          // Ao(j)
-      else if (i == c) v = -kMtEpsReg;
-      dst[e] = v;
+    L.Do[e] = doo; L.Ct[e] = cno; L.Dn[e] = dnn;
+  }
+  __syncthreads();
+  double* Dg = st.dblk + ((size_t)b * N + j) * 256;
+  double* Eg = st.eblk + ((size_t)b * N + j) * 256;
+  for (int e = lane; e < 256; e += 64) {
+    const int i = e >> 4, c = e & 15;
+    double d = 0.0, ev = 0.0;
+    if (i < 9 && c < 9) {
+      d = L.Do[i * 9 + c] + L.Dn[i * 9 + c];
+      ev = L.Ct[i * 9 + c];
+      if (i == c && i >= 5 && i < 8) { d += kMtCostDiag; ev += kMtCostOff; }
+    } else if (i < 9) {
+      d = Jo[(c - 9) * kMtLoc + i];          // Ao(j)'
+      ev = Jo[(c - 9) * kMtLoc + 9 + i];     // An(j)'
+    } else if (c < 9) {
+      d = Jo[(i - 9) * kMtLoc + c];          // Ao(j)
+    } else if (i == c) {
+      d = -kMtEpsReg;
     }
-  };
-  auto build_coupling = [&](int j, double* dst) {   // E_j = M[j+1][j]: [[C(j) + cost, An(j)'], [0, 0]]
-    const double* Jj = jac + (size_t)j * kMtNf * kMtLoc;
-    for (int e = lane; e < 256; e += 64) {
-      const int i = e >> 4, c = e & 15;
-      double v = 0.0;
-      if (i < 9 && c < 9) { v = L.Ct[i * 9 + c]; if (i == c && i >= 5 && i < 8) v += kMtCostOff; }
-      else if (i < 9) v = Jj[(c - 9) * kMtLoc + 9 + i];      // An(j)'
-      dst[e] = v;
+    Dg[e] = d; Eg[e] = ev;
+  }
+  if (lane < 16) {
+    double r;
+    if (lane < 9) {
+      const int a = lane;
+      r = mt_cost_grad(w, N, j, a);
+      for (int c = 0; c < kMtNe; ++c) r += Jo[c * kMtLoc + a] * yv[j * kMtNe + c] + Jp[c * kMtLoc + 9 + a] * yv[jp * kMtNe + c];
+      for (int c = 0; c < kMtNi; ++c)
+        r += Jo[(kMtNe + c) * kMtLoc + a] * L.zeta[0][c] + Jp[(kMtNe + c) * kMtLoc + 9 + a] * L.zeta[1][c];
+    } else {
+      r = fun[j * kMtNf + (lane - 9)];
     }
-  };
-  auto build_rhs = [&](int j, double* dst) {
-    const int jp = j == 0 ? N - 1 : j - 1;
-    const double* Jo = jac + (size_t)j * kMtNf * kMtLoc;
-    const double* Jp = jac + (size_t)jp * kMtNf * kMtLoc;
-    if (lane < 16) {
-      double r;
-      if (lane < 9) {
-        const int a = lane;
-        r = mt_cost_grad(w, N, j, a);
-        for (int c = 0; c < kMtNe; ++c) r += Jo[c * kMtLoc + a] * yv[j * kMtNe + c] + Jp[c * kMtLoc + 9 + a] * yv[jp * kMtNe + c];
-        for (int c = 0; c < kMtNi; ++c) {
-          const double so = sv[j * kMtNi + c], sp = sv[jp * kMtNi + c];
-          const double zo = mu / so + zv[j * kMtNi + c] / so * (fun[j * kMtNf + kMtNe + c] + so);
-          const double zp = mu / sp + zv[jp * kMtNi + c] / sp * (fun[jp * kMtNf + kMtNe + c] + sp);
-          r += Jo[(kMtNe + c) * kMtLoc + a] * zo + Jp[(kMtNe + c) * kMtLoc + 9 + a] * zp;
-        }
-      } else {
-        r = fun[j * kMtNf + (lane - 9)];
-      }
-      dst[lane] = -r;
-    }
-  };
+    st.rhs[((size_t)b * N + j) * 16 + lane] = -r;
+  }
+}
+
+struct MtKktLds {
+  double S[256], E[256], F[256], Pm[256], Qm[256], Sl[256], T1[256];
+  double r[16], rl[16], x[16], xl[16], xn[16];
+};
+
+// k_mt_kkt: one wave per instance: block elimination of the cyclic block-tridiagonal KKT system from the
+// assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.  The blocks of the
+// next node are fetched into registers (4 + 4 + 1 doubles per lane) while the current node is eliminated.
+__global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
+  __shared__ MtKktLds L;
+  const int b = blockIdx.x, lane = threadIdx.x, N = P.N;
+  double* scal = st.scal + (size_t)b * 16;
+  if (scal[5] != 0.0) return;
+  const double* Dg = st.dblk + (size_t)b * N * 256;
+  const double* Eg = st.eblk + (size_t)b * N * 256;
+  const double* Rg = st.rhs + (size_t)b * N * 16;
+  double* blk = st.blk + (size_t)b * N * 3 * 256;
+  double* vec = st.vec + (size_t)b * N * 16;
+  double delta = scal[1];
+  // entry e = lane + 64 r of a block is on the diagonal of the unknowns' part iff row == col < 9
+  auto dshift = [&](int r) { const int e = lane + 64 * r; return ((e >> 4) == (e & 15) && (e >> 4) < 9) ? delta : 0.0; };
 
   int attempt = 0;
   bool ok = false;
   for (; attempt < 12 && !ok; ++attempt) {
     bool bad = false;
     int n_neg = 0;
-    // S_last accumulates in L.Sl, its right-hand side in L.rl; F = border block M[N-1][j] (fill-in)
-    pair_pieces(N - 1, L.Do, nullptr, nullptr);            // Do(N-1)
-    pair_pieces(N - 2, nullptr, L.Dn, nullptr);            // Dn(N-2) -> K[N-1][N-1]
-    mt_wave_sync();
-    build_diag(N - 1, L.Sl);
-    build_rhs(N - 1, L.rl);
-    // node 0: S_0 = M[0][0]; F_0 = M[N-1][0] = E_{N-1}'  (pair N-1 couples node N-1 (own) with node 0 (next))
-    pair_pieces(N - 1, nullptr, L.Dn, L.Ct);               // Dn(N-1) -> K[0][0], C(N-1) = K[0][N-1]
-    mt_wave_sync();
-    build_coupling(N - 1, L.T1);                           // E_{N-1} = M[0][N-1]
-    mt_wave_sync();
-    for (int e = lane; e < 256; e += 64) L.F[e] = L.T1[(e & 15) * 16 + (e >> 4)];   // F_0 = E_{N-1}'
-    pair_pieces(0, L.Do, nullptr, nullptr);
-    mt_wave_sync();
-    build_diag(0, L.S);
-    build_rhs(0, L.r);
+    // S_last and its right-hand side; F = border block M[N-1][j] (fill-in), F_0 = M[N-1][0] = E_{N-1}'
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane + 64 * r;
+      L.Sl[e] = Dg[(size_t)(N - 1) * 256 + e] + dshift(r);
+      L.S[e] = Dg[e] + dshift(r);
+      L.F[(e & 15) * 16 + (e >> 4)] = Eg[(size_t)(N - 1) * 256 + e];
+    }
+    if (lane < 16) { L.rl[lane] = Rg[(size_t)(N - 1) * 16 + lane]; L.r[lane] = Rg[lane]; }
+    double eN[4], dN[4], rN = 0.0;     // blocks of the next step, in flight
+    for (int r = 0; r < 4; ++r) { eN[r] = Eg[lane + 64 * r]; dN[r] = N > 2 ? Dg[256 + lane + 64 * r] : 0.0; }
+    if (lane < 16) rN = N > 2 ? Rg[16 + lane] : 0.0;
     mt_wave_sync();
     for (int j = 0; j < N - 1 && !bad; ++j) {
-      // pieces of pair j: coupling to node j+1
-      pair_pieces(j, nullptr, L.Dn, L.Ct);                 // Dn(j) -> K[j+1][j+1], C(j)
-      mt_wave_sync();
-      build_coupling(j, L.E);                              // E_j = M[j+1][j]
-      if (j == N - 2) {                                    // the regular coupling of the last node joins the border
-        mt_wave_sync();
-        for (int e = lane; e < 256; e += 64) L.F[e] += L.E[e];
+      // this node's coupling block and the next node's diagonal block / right-hand side arrive in registers
+      double dC[4], rC = rN;
+      for (int r = 0; r < 4; ++r) { L.E[lane + 64 * r] = eN[r]; dC[r] = dN[r]; }
+      if (j + 1 < N - 1) {               // prefetch for step j + 1: E_{j+1}, D_{j+2}, r_{j+2}
+        for (int r = 0; r < 4; ++r) {
+          eN[r] = Eg[(size_t)(j + 1) * 256 + lane + 64 * r];
+          dN[r] = j + 2 < N - 1 ? Dg[(size_t)(j + 2) * 256 + lane + 64 * r] : 0.0;
+        }
+        if (lane < 16) rN = j + 2 < N - 1 ? Rg[(size_t)(j + 2) * 16 + lane] : 0.0;
       }
       mt_wave_sync();
+      if (j == N - 2) {                  // the regular coupling of the last node joins the border
+        for (int r = 0; r < 4; ++r) L.F[lane + 64 * r] += L.E[lane + 64 * r];
+        mt_wave_sync();
+      }
       const int neg = mt_invert(L.S, lane);                // S_j^-1
       if (neg < 0) { bad = true; break; }
       n_neg += neg;
       double* Bj = blk + (size_t)j * 3 * 256;
       for (int e = lane; e < 256; e += 64) Bj[e] = L.S[e];
-      if (j < N - 2) {
-        mt_gemm<false, false>(L.Pm, L.E, L.S, 1.0, lane);  // P_j = E_j S_j^-1
-      }
-      mt_gemm<false, false>(L.Qm, L.F, L.S, 1.0, lane);    // Q_j = F_j S_j^-1
+      if (j < N - 2) mt_gemm<false, false>(L.Pm, L.E, L.S, 1.0, lane);  // P_j = E_j S_j^-1
+      mt_gemm<false, false>(L.Qm, L.F, L.S, 1.0, lane);                 // Q_j = F_j S_j^-1
       mt_wave_sync();
       for (int e = lane; e < 256; e += 64) { Bj[256 + e] = (j < N - 2) ? L.Pm[e] : 0.0; Bj[512 + e] = L.Qm[e]; }
-      // right-hand sides
       if (lane < 16) vec[(size_t)j * 16 + lane] = L.r[lane];
       mt_gemv_acc<false>(L.rl, L.Qm, L.r, -1.0, lane);     // r_last -= Q_j r_j
-      // S_last -= Q_j F_j'
-      mt_gemm<true, true>(L.Sl, L.Qm, L.F, -1.0, lane);
+      mt_gemm<true, true>(L.Sl, L.Qm, L.F, -1.0, lane);    // S_last -= Q_j F_j'
       if (j < N - 2) {
-        // next node: S_{j+1} = M[j+1][j+1] - P_j E_j' ; F_{j+1} = -Q_j E_j' ; r_{j+1} -= P_j r_j
-        pair_pieces(j + 1, L.Do, nullptr, nullptr);
-        mt_wave_sync();
-        build_diag(j + 1, L.T1);
-        build_rhs(j + 1, L.xn);
+        // next node: S_{j+1} = D_{j+1} + delta - P_j E_j' ; F_{j+1} = -Q_j E_j' ; r_{j+1} -= P_j r_j
+        for (int r = 0; r < 4; ++r) L.T1[lane + 64 * r] = dC[r] + dshift(r);
+        if (lane < 16) L.xn[lane] = rC;
         mt_wave_sync();
         mt_gemm<true, true>(L.T1, L.Pm, L.E, -1.0, lane);
         mt_gemv_acc<false>(L.xn, L.Pm, L.r, -1.0, lane);
