@@ -24,8 +24,9 @@
 //                                   (7 N of 16 N) is the inertia test that drives delta
 //                     k_mt_step     fraction-to-the-boundary rule, backtracking against a filter on
 //                                   (infeasibility, barrier objective), update of w, s, y, z, delta
-//   One wave per instance in k_mt_kkt (every 16 x 16 block lives in LDS, 4 entries per lane; the block
-//   products run on the matrix cores: v_mfma_f64_16x16x4_f64), one thread per (instance, node, slice) in
+//   One wave per instance in k_mt_kkt (every 16 x 16 block lives in registers, 4 entries per lane, in the
+//   operand layout of v_mfma_f64_16x16x4_f64: the block products run on the matrix cores, the block
+//   inverse on cross-lane moves), one thread per (instance, node, slice) in
 //   k_mt_derivs, one workgroup per instance in k_mt_step.
 #pragma once
 #include "rl_dtrack.hpp"
@@ -234,77 +235,86 @@ __global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 16 x 16 blocks in LDS, row major, one wave: entry e = lane + 64 r, r = 0..3
+// 16 x 16 blocks in REGISTERS, one wave.  Lane l = (i = l & 15, q = l >> 4) holds the four entries
+// (i, 4 r + q), r = 0..3, of a block ("A-layout") -- exactly what v_mfma_f64_16x16x4_f64 wants from BOTH
+// operands of a product X Y' (the r-th instruction consumes columns 4 r .. 4 r + 3), and its result,
+// rows 4 r + q of column i, is the A-layout of (X Y')' = Y X'.  Every product of the elimination has the form
+// Y X' (S^-1 symmetric), so the blocks never leave the registers and never change layout.
+// Vectors: "i-layout" (lane holds v[i], the same in the four q groups) or "k-layout" (lane holds v[4 r + q]).
 __device__ __forceinline__ void mt_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// C (+)= sign * A * B^T  (TB = true)  or  sign * A * B (TB = false); all 16 x 16 in LDS.  On the matrix cores:
-// four v_mfma_f64_16x16x4_f64, lane l supplies A[l & 15][4 kk + (l >> 4)] and B'[4 kk + (l >> 4)][l & 15];
-// its four results are rows (l >> 4) + 4 r of column l & 15.
-template <bool TB, bool ACC>
-__device__ __forceinline__ void mt_gemm(double* C, const double* A, const double* B, double sign, int lane) {
-  typedef double v4d __attribute__((ext_vector_type(4)));
-  const int r16 = lane & 15, q = lane >> 4;
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int k = 4 * kk + q;
-    const double a = A[r16 * 16 + k];
-    const double bb = TB ? B[r16 * 16 + k] : B[k * 16 + r16];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int idx = (q + 4 * r) * 16 + r16;
-    C[idx] = (ACC ? C[idx] : 0.0) + sign * acc[r];
-  }
+struct MtBlk { double v[4]; };
+
+__device__ __forceinline__ double mt_bcast(double v, int l) {  // l wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// In-place inverse of a symmetric 16 x 16 block by Gauss-Jordan elimination WITHOUT pivoting.  Returns the
-// number of negative pivots (they are the LDL' pivots of the block: their signs, summed over the whole
-// elimination, are the inertia of the KKT matrix), or -1 when a pivot is negligible / not finite.
-__device__ __forceinline__ int mt_invert(double* S, int lane) {
+// A-layout of Y X'
+__device__ __forceinline__ MtBlk mt_mul_t(const MtBlk& X, const MtBlk& Y) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X.v[kk], Y.v[kk], acc, 0, 0, 0);
+  MtBlk C;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) C.v[r] = acc[r];
+  return C;
+}
+
+// M v: M in A-layout, v in k-layout -> i-layout
+__device__ __forceinline__ double mt_gemv(const MtBlk& M, const double (&vk)[4]) {
+  double p = M.v[0] * vk[0];
+#pragma unroll
+  for (int r = 1; r < 4; ++r) p = fma(M.v[r], vk[r], p);
+  p += __shfl_xor(p, 16, 64);
+  p += __shfl_xor(p, 32, 64);
+  return p;
+}
+
+__device__ __forceinline__ void mt_to_k(double vi, int q, double (&vk)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vk[r] = __shfl(vi, 4 * r + q, 64);
+}
+
+// In-place inverse of a symmetric 16 x 16 block by Gauss-Jordan elimination WITHOUT pivoting, in registers: per
+// pivot k one v_readlane pair (the pivot), five ds_bpermute pairs (column k for the lane's row, row k for the
+// lane's four columns) and four lane-local updates.  Returns the number of negative pivots (they are the LDL'
+// pivots of the block: their signs, summed over the whole elimination, are the inertia of the KKT matrix), or
+// -1 when a pivot is negligible / not finite.
+__device__ __forceinline__ int mt_invert(MtBlk& S, int lane) {
+  const int i = lane & 15, q = lane >> 4;
   int neg = 0;
   bool bad = false;
+#pragma unroll
   for (int k = 0; k < kMtNb; ++k) {
-    const double piv = S[k * 16 + k];
+    const int kr = k >> 2, kq = k & 3;  // column k: register kr of the lanes with q == kq
+    const double piv = mt_bcast(S.v[kr], 16 * kq + k);
     if (piv < 0.0) ++neg;
     if (!(fabs(piv) >= 1e-11) || !isfinite(piv)) bad = true;
-    const double ip = 1.0 / piv;
-    double nv[4];
+    double ip = __builtin_amdgcn_rcp(piv);
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
+    const double colk = __shfl(S.v[kr], 16 * kq + i, 64);
+    double rowk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowk[r] = __shfl(S.v[r], (lane & 48) + k, 64);
+    const bool ik = i == k;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int e = lane + 64 * r, i = e >> 4, j = e & 15;
-      const double sik = S[i * 16 + k], skj = S[k * 16 + j], sij = S[e];
-      double v;
-      if (i == k && j == k) v = ip;
-      else if (i == k) v = skj * ip;
-      else if (j == k) v = -sik * ip;
-      else v = sij - sik * skj * ip;
-      nv[r] = v;
+      const bool jk = r == kr && q == kq;
+      double v = S.v[r] - colk * rowk[r] * ip;
+      v = jk ? -colk * ip : v;
+      v = ik ? rowk[r] * ip : v;
+      v = (ik && jk) ? ip : v;
+      S.v[r] = v;
     }
-    mt_wave_sync();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) S[lane + 64 * r] = nv[r];
-    mt_wave_sync();
   }
   return bad ? -1 : neg;
 }
-
-// y (+)= sign * M x  or  sign * M^T x  for a 16 x 16 block in LDS and 16-vectors in LDS; lanes 0..15 each own a row
-template <bool TR>
-__device__ __forceinline__ void mt_gemv_acc(double* y, const double* M, const double* x, double sign, int lane) {
-  if (lane < 16) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a += (TR ? M[k * 16 + lane] : M[lane * 16 + k]) * x[k];
-    y[lane] += sign * a;
-  }
-}
-
 
 // cost gradient of node j (scaled unknowns)
 __device__ __forceinline__ double mt_cost_grad(const double* w, int N, int j, int a) {
@@ -449,90 +459,95 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
   }
 }
 
-struct MtKktLds {
-  double S[256], E[256], F[256], Pm[256], Qm[256], Sl[256], T1[256];
-  double r[16], rl[16], x[16], xl[16], xn[16];
-};
-
 // k_mt_kkt: one wave per instance: block elimination of the cyclic block-tridiagonal KKT system from the
-// assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.  The blocks of the
-// next node are fetched into registers (4 + 4 + 1 doubles per lane) while the current node is eliminated.
+// assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.  All blocks stay in
+// registers (MtBlk); the blocks of the next node are fetched while the current node is eliminated.  Kept for
+// the back substitution, per node: P_j = E_j S_j^-1, Q_j = F_j S_j^-1 (row major) and a_j = S_j^-1 r_j.
 __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
-  __shared__ MtKktLds L;
+  __shared__ double xs[2][16];
   const int b = blockIdx.x, lane = threadIdx.x, N = P.N;
+  const int i = lane & 15, q = lane >> 4;
   double* scal = st.scal + (size_t)b * 16;
   if (scal[5] != 0.0) return;
   const double* Dg = st.dblk + (size_t)b * N * 256;
   const double* Eg = st.eblk + (size_t)b * N * 256;
   const double* Rg = st.rhs + (size_t)b * N * 16;
-  double* blk = st.blk + (size_t)b * N * 3 * 256;
+  double* blk = st.blk + (size_t)b * N * 3 * 256;   // per node: P [256], Q [256], a' [16]
   double* vec = st.vec + (size_t)b * N * 16;
   double delta = scal[1];
-  // entry e = lane + 64 r of a block is on the diagonal of the unknowns' part iff row == col < 9
-  auto dshift = [&](int r) { const int e = lane + 64 * r; return ((e >> 4) == (e & 15) && (e >> 4) < 9) ? delta : 0.0; };
+  auto ld = [&](const double* G) { MtBlk X;      // row-major block -> A-layout
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X.v[r] = G[i * 16 + 4 * r + q];
+    return X; };
+  auto ld_t = [&](const double* G) { MtBlk X;    // its transpose (a symmetric block: the coalesced way to read it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X.v[r] = G[(4 * r + q) * 16 + i];
+    return X; };
+  auto st_rm = [&](double* G, const MtBlk& X) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[i * 16 + 4 * r + q] = X.v[r]; };
+  // delta I on the unknowns' part of a diagonal block
+  auto shift = [&](MtBlk& X) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X.v[r] += (i == 4 * r + q && i < kMtNv) ? delta : 0.0; };
+  const MtBlk zero = {{0.0, 0.0, 0.0, 0.0}};
 
   int attempt = 0;
   bool ok = false;
+  MtBlk Sl = zero;
+  double rl = 0.0;
   for (; attempt < 12 && !ok; ++attempt) {
     bool bad = false;
     int n_neg = 0;
     // S_last and its right-hand side; F = border block M[N-1][j] (fill-in), F_0 = M[N-1][0] = E_{N-1}'
-    for (int r = 0; r < 4; ++r) {
-      const int e = lane + 64 * r;
-      L.Sl[e] = Dg[(size_t)(N - 1) * 256 + e] + dshift(r);
-      L.S[e] = Dg[e] + dshift(r);
-      L.F[(e & 15) * 16 + (e >> 4)] = Eg[(size_t)(N - 1) * 256 + e];
-    }
-    if (lane < 16) { L.rl[lane] = Rg[(size_t)(N - 1) * 16 + lane]; L.r[lane] = Rg[lane]; }
-    double eN[4], dN[4], rN = 0.0;     // blocks of the next step, in flight
-    for (int r = 0; r < 4; ++r) { eN[r] = Eg[lane + 64 * r]; dN[r] = N > 2 ? Dg[256 + lane + 64 * r] : 0.0; }
-    if (lane < 16) rN = N > 2 ? Rg[16 + lane] : 0.0;
-    mt_wave_sync();
+    Sl = ld_t(Dg + (size_t)(N - 1) * 256); shift(Sl);
+    MtBlk S = ld_t(Dg); shift(S);
+    MtBlk F = ld_t(Eg + (size_t)(N - 1) * 256);
+    rl = Rg[(size_t)(N - 1) * 16 + i];
+    double rk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rk[r] = Rg[4 * r + q];
+    MtBlk eN = ld(Eg), dN = N > 2 ? ld_t(Dg + 256) : zero;   // blocks of the next step, in flight
+    double rN = N > 2 ? Rg[16 + i] : 0.0;
     for (int j = 0; j < N - 1 && !bad; ++j) {
-      // this node's coupling block and the next node's diagonal block / right-hand side arrive in registers
-      double dC[4], rC = rN;
-      for (int r = 0; r < 4; ++r) { L.E[lane + 64 * r] = eN[r]; dC[r] = dN[r]; }
+      const MtBlk E = eN, dC = dN;
+      const double rC = rN;
       if (j + 1 < N - 1) {               // prefetch for step j + 1: E_{j+1}, D_{j+2}, r_{j+2}
-        for (int r = 0; r < 4; ++r) {
-          eN[r] = Eg[(size_t)(j + 1) * 256 + lane + 64 * r];
-          dN[r] = j + 2 < N - 1 ? Dg[(size_t)(j + 2) * 256 + lane + 64 * r] : 0.0;
-        }
-        if (lane < 16) rN = j + 2 < N - 1 ? Rg[(size_t)(j + 2) * 16 + lane] : 0.0;
+        eN = ld(Eg + (size_t)(j + 1) * 256);
+        dN = j + 2 < N - 1 ? ld_t(Dg + (size_t)(j + 2) * 256) : zero;
+        rN = j + 2 < N - 1 ? Rg[(size_t)(j + 2) * 16 + i] : 0.0;
       }
-      mt_wave_sync();
       if (j == N - 2) {                  // the regular coupling of the last node joins the border
-        for (int r = 0; r < 4; ++r) L.F[lane + 64 * r] += L.E[lane + 64 * r];
-        mt_wave_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) F.v[r] += E.v[r];
       }
-      const int neg = mt_invert(L.S, lane);                // S_j^-1
+      const int neg = mt_invert(S, lane);                   // S_j^-1
       if (neg < 0) { bad = true; break; }
       n_neg += neg;
+      const double aj = mt_gemv(S, rk);                     // a_j = S_j^-1 r_j
+      if (q == 0) vec[(size_t)j * 16 + i] = aj;
+      const MtBlk Pm = j < N - 2 ? mt_mul_t(S, E) : zero;   // P_j = E_j S_j^-1
+      const MtBlk Qm = mt_mul_t(S, F);                      // Q_j = F_j S_j^-1
       double* Bj = blk + (size_t)j * 3 * 256;
-      for (int e = lane; e < 256; e += 64) Bj[e] = L.S[e];
-      if (j < N - 2) mt_gemm<false, false>(L.Pm, L.E, L.S, 1.0, lane);  // P_j = E_j S_j^-1
-      mt_gemm<false, false>(L.Qm, L.F, L.S, 1.0, lane);                 // Q_j = F_j S_j^-1
-      mt_wave_sync();
-      for (int e = lane; e < 256; e += 64) { Bj[256 + e] = (j < N - 2) ? L.Pm[e] : 0.0; Bj[512 + e] = L.Qm[e]; }
-      if (lane < 16) vec[(size_t)j * 16 + lane] = L.r[lane];
-      mt_gemv_acc<false>(L.rl, L.Qm, L.r, -1.0, lane);     // r_last -= Q_j r_j
-      mt_gemm<true, true>(L.Sl, L.Qm, L.F, -1.0, lane);    // S_last -= Q_j F_j'
+      st_rm(Bj, Pm); st_rm(Bj + 256, Qm);
+      rl -= mt_gemv(Qm, rk);                                // r_last -= Q_j r_j
+      {
+        const MtBlk U = mt_mul_t(F, Qm);                    // S_last -= Q_j F_j'
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sl.v[r] -= U.v[r];
+      }
       if (j < N - 2) {
         // next node: S_{j+1} = D_{j+1} + delta - P_j E_j' ; F_{j+1} = -Q_j E_j' ; r_{j+1} -= P_j r_j
-        for (int r = 0; r < 4; ++r) L.T1[lane + 64 * r] = dC[r] + dshift(r);
-        if (lane < 16) L.xn[lane] = rC;
-        mt_wave_sync();
-        mt_gemm<true, true>(L.T1, L.Pm, L.E, -1.0, lane);
-        mt_gemv_acc<false>(L.xn, L.Pm, L.r, -1.0, lane);
-        mt_gemm<true, false>(L.F, L.Qm, L.E, -1.0, lane);  // reads Qm, E; writes F (not an input)
-        mt_wave_sync();
-        for (int e = lane; e < 256; e += 64) L.S[e] = L.T1[e];
-        if (lane < 16) L.r[lane] = L.xn[lane];
-        mt_wave_sync();
+        const MtBlk M = mt_mul_t(E, Pm), Fn = mt_mul_t(E, Qm);
+        S = dC; shift(S);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { S.v[r] -= M.v[r]; F.v[r] = -Fn.v[r]; }
+        const double rn = rC - mt_gemv(Pm, rk);
+        mt_to_k(rn, q, rk);
       }
     }
     if (!bad) {
-      mt_wave_sync();
-      const int neg = mt_invert(L.Sl, lane);
+      const int neg = mt_invert(Sl, lane);
       // inertia (9N, 7N, 0): the reduced Hessian is positive definite (Sylvester's law on the LDL' pivots)
       if (neg < 0 || n_neg + neg != N * kMtNe) bad = true;
     }
@@ -548,35 +563,71 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
     if (lane == 0) scal[5] = 2.0;
     return;
   }
-  // ---- back substitution: x_last = S_last^-1 r_last; x_j = S_j^-1 r_j - P_j' x_{j+1} - Q_j' x_last
-  if (lane < 16) {
-    double a = 0.0;
-    for (int k = 0; k < 16; ++k) a += L.Sl[lane * 16 + k] * L.rl[k];
-    L.xl[lane] = a;
-  }
-  mt_wave_sync();
+  // ---- back substitution: x_last = S_last^-1 r_last; x_j = a_j - Q_j' x_last - P_j' x_{j+1}
   double* dw = st.dw + (size_t)b * N * kMtNv;
   double* dy = st.dy + (size_t)b * N * kMtNe;
-  if (lane < 9) dw[(size_t)(N - 1) * kMtNv + lane] = L.xl[lane];
-  else if (lane < 16) dy[(size_t)(N - 1) * kMtNe + lane - 9] = L.xl[lane];
-  if (lane < 16) L.xn[lane] = L.xl[lane];    // x_{j+1} for j = N-2 (its P is zero: the coupling sits in Q)
-  mt_wave_sync();
-  for (int j = N - 2; j >= 0; --j) {
-    const double* Bj = blk + (size_t)j * 3 * 256;
-    if (lane < 16) {
-      double a = 0.0;
-      for (int k = 0; k < 16; ++k) {
-        a += Bj[lane * 16 + k] * vec[(size_t)j * 16 + k];                   // S_j^-1 r_j
-        a -= Bj[256 + k * 16 + lane] * L.xn[k];                             // P_j' x_{j+1}
-        a -= Bj[512 + k * 16 + lane] * L.xl[k];                             // Q_j' x_last
-      }
-      L.x[lane] = a;
+  {
+    double rlk[4];
+    mt_to_k(rl, q, rlk);
+    const double xl = mt_gemv(Sl, rlk);
+    if (q == 0) {
+      xs[0][i] = xl; xs[1][i] = xl;      // x_{j+1} for j = N-2 is x_last too (its P is zero: the coupling sits in Q)
+      if (i < kMtNv) dw[(size_t)(N - 1) * kMtNv + i] = xl;
+      else dy[(size_t)(N - 1) * kMtNe + i - kMtNv] = xl;
     }
-    mt_wave_sync();
-    if (lane < 9) dw[(size_t)j * kMtNv + lane] = L.x[lane];
-    else if (lane < 16) dy[(size_t)j * kMtNe + lane - 9] = L.x[lane];
-    if (lane < 16) L.xn[lane] = L.x[lane];
-    mt_wave_sync();
+  }
+  mt_wave_sync();
+  // a'_j = a_j - Q_j' x_last for every node, four nodes at a time (lane = node q of the four, component i);
+  // written to the node's third slot, which nothing has read before (no stale line in the vector L1)
+  {
+    double xl[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xl[k] = xs[0][k];
+    for (int j0 = 0; j0 < N - 1; j0 += 4) {
+      const int j = j0 + q;
+      if (j < N - 1) {
+        const double* Qg = blk + (size_t)j * 3 * 256 + 256;
+        double acc = vec[(size_t)j * 16 + i];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(-Qg[k * 16 + i], xl[k], acc);
+        blk[(size_t)j * 3 * 256 + 512 + i] = acc;
+      }
+    }
+  }
+  mt_wave_sync();
+  // the chain: lanes 0..15 own one component each; P_{j-1} and a'_{j-1} are fetched while x_j is formed
+  if (lane < 16) {
+    double pj[16], aj;
+    {
+      const double* Bj = blk + (size_t)(N - 2) * 3 * 256;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pj[k] = Bj[k * 16 + lane];
+      aj = Bj[512 + lane];
+    }
+    int cur = 1;
+    for (int j = N - 2; j >= 0; --j) {
+      double pn[16], an = 0.0;
+      if (j > 0) {
+        const double* Bn = blk + (size_t)(j - 1) * 3 * 256;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pn[k] = Bn[k * 16 + lane];
+        an = Bn[512 + lane];
+      }
+      double x0 = aj, x1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) { x0 = fma(-pj[k], xs[cur][k], x0); x1 = fma(-pj[k + 1], xs[cur][k + 1], x1); }
+      const double x = x0 + x1;
+      if (lane < kMtNv) dw[(size_t)j * kMtNv + lane] = x;
+      else dy[(size_t)j * kMtNe + lane - kMtNv] = x;
+      xs[cur ^ 1][lane] = x;
+      mt_wave_sync();
+      cur ^= 1;
+      if (j > 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pj[k] = pn[k];
+        aj = an;
+      }
+    }
   }
 }
 

@@ -443,6 +443,20 @@ def test_drop_in_api(rl, fits, rings):
     assert dev < TOL_M
     # the input spline is not modified (optimizer.py:257)
     np.testing.assert_array_equal(traj_spline._spl_x.c, cx)
+    # the table the sweep hands back is the reference's final traj_out_d (optimizer.py:286-288): the
+    # optimised spline sampled on the same grid -- positions, heading, radius AND the arc-length columns
+    # (trajectory.py:283-289; the length is the copied input spline's, as in the reference) -- with its bounds
+    tab = optm.last_table
+    again = out.sample_along(ts=np.linspace(0.0, 1.0, N, endpoint=False))
+    for col, tol in ((Trajectory.X, 1e-9), (Trajectory.Y, 1e-9), (Trajectory.YAW, 1e-12),
+                     (Trajectory.DIST_TO_SF_BWD, 1e-8), (Trajectory.DIST_TO_SF_FWD, 1e-8)):
+        np.testing.assert_allclose(tab[:, col], again[:, col], rtol=0, atol=tol)
+    np.testing.assert_allclose(tab[:, Trajectory.CURVATURE], again[:, Trajectory.CURVATURE], rtol=1e-9)
+    assert tab[1:, Trajectory.DIST_TO_SF_BWD].min() > 0.0 and abs(tab[0, Trajectory.DIST_TO_SF_BWD]) == 0.0
+    np.testing.assert_allclose(tab[:, Trajectory.DIST_TO_SF_BWD] + tab[:, Trajectory.DIST_TO_SF_FWD], out.get_length(), rtol=0, atol=1e-9)
+    track.fill_trajectory_boundaries(again)
+    for col in (Trajectory.LEFT_BOUND_X, Trajectory.LEFT_BOUND_Y, Trajectory.RIGHT_BOUND_X, Trajectory.RIGHT_BOUND_Y):
+        np.testing.assert_allclose(tab[:, col], again[:, col], rtol=0, atol=1e-8)
 
 
 def _sim_inputs():
