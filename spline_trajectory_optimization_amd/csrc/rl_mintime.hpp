@@ -36,9 +36,27 @@ namespace rl {
 
 constexpr int kMtNv = 9, kMtNe = 7, kMtNi = 17, kMtNf = kMtNe + kMtNi, kMtNb = kMtNv + kMtNe;  // 16
 constexpr int kMtLoc = 2 * kMtNv;  // 18 local unknowns of a pair: own 9 + next node's 9
-constexpr int kMtJacSlices = kMtLoc / 3, kMtHesGroups = kMtLoc / 3;
-constexpr int kMtHesSlices = kMtHesGroups * (kMtHesGroups + 1) / 2;   // 21 pairs of direction groups
-constexpr int kMtSlices = 1 + kMtJacSlices + kMtHesSlices;            // 28
+constexpr int kMtJacSlices = kMtLoc / 3;
+// Hessian slices: inner direction groups of kMtHesNA unknowns x outer groups of kMtHesNB unknowns; a slice is
+// kept when it holds an entry (a, b) with a <= b.  Nested duals carry (1 + NA)(1 + NB) doubles per value, and the
+// model keeps ~50 values alive: measured on MI355X (MGKT, 256 instances, whole solve) 1 x 1 (171 slices, 0.5 KB
+// of spills per lane) 4.7 s, 1 x 2 8.4 s, 1 x 3 8.8 s, 3 x 3 (21 slices, 8.5 KB of spills) 13.8 s.
+#ifndef RL_MT_HES_NA
+#define RL_MT_HES_NA 1
+#endif
+#ifndef RL_MT_HES_NB
+#define RL_MT_HES_NB 1
+#endif
+constexpr int kMtHesNA = RL_MT_HES_NA, kMtHesNB = RL_MT_HES_NB;
+static_assert(kMtLoc % kMtHesNA == 0 && kMtLoc % kMtHesNB == 0, "direction groups must tile the 18 local unknowns");
+constexpr int mt_hes_slices() {
+  int c = 0;
+  for (int ga = 0; ga < kMtLoc / kMtHesNA; ++ga)
+    for (int gb = 0; gb < kMtLoc / kMtHesNB; ++gb)
+      if (kMtHesNA * ga <= kMtHesNB * gb + kMtHesNB - 1) ++c;
+  return c;
+}
+constexpr int kMtHesSlices = mt_hes_slices();
 constexpr double kMtEpsReg = 1e-8;  // dual regularisation of the KKT system
 constexpr double kMtThetaGrowth = 2.0;
 constexpr double kMtCostDiag = 2e-4 + 4e-1, kMtCostOff = -2e-1;  // Hessian of 1e-4 |U|^2 + 1e-1 |dU|^2 (:119-123)
@@ -64,54 +82,94 @@ template <int ND, typename T> struct MtLift<Dual<ND, T>> {
   }
 };
 
-// eq (7, row-scaled) and g (17, row-scaled) of the pair (j, j+1) from the scaled unknowns of both nodes
-template <typename S>
-__device__ __forceinline__ void mt_pair(const MtProblem& P, int j, const S (&wo)[kMtNv], const S (&wn)[kMtNv],
-                                        S (&eq)[kMtNe], S (&g)[kMtNi]) {
+// eq (7, row-scaled) and g (17, row-scaled) of the pair (j, j+1) from the scaled unknowns of both nodes.  The
+// rows are handed to a SINK as soon as they exist -- sink.eq(c, v) / sink.g(c, v) ADD v to row c; the defect
+// rows arrive in two pieces -- so that a caller that only needs a weighted sum of the rows (the Lagrangian of
+// the Hessian kernel) never holds the 24 of them at once.
+template <typename S, typename Sink>
+__device__ __forceinline__ void mt_pair_emit(const MtProblem& P, int j, const S (&wo)[kMtNv], const S (&wn)[kMtNv], Sink& sink) {
   const double* p = P.p;
   const int jn = j + 1 == P.N ? 0 : j + 1;
-  S x[6], xn[6], u[4], un[4];
+  S x[6], xn[6], u[4];
   x[0] = MtLift<S>::make(P.s[j]); xn[0] = MtLift<S>::make(P.s[jn]);
 #pragma unroll
   for (int c = 0; c < 5; ++c) { x[1 + c] = wo[c] * P.sw[c]; xn[1 + c] = wn[c] * P.sw[c]; }
   u[0] = wo[5] * P.sw[5]; u[1] = MtLift<S>::make(0.0); u[2] = wo[6] * P.sw[6]; u[3] = wo[7] * P.sw[7];
-  un[0] = wn[5] * P.sw[5]; un[1] = MtLift<S>::make(0.0); un[2] = wn[6] * P.sw[6]; un[3] = wn[7] * P.sw[7];
   const S t = wo[8] * P.sw[8];
   const double k = P.kappa[j];
+  const double su0 = P.sw[5], su2 = P.sw[6], sx1 = P.sw[0], sx5 = P.sw[4];
+  {  // the rows that only need the unknowns themselves
+    const S un0 = wn[5] * P.sw[5], un2 = wn[6] * P.sw[6];
+    const S v = x[5], delta = u[2];
+    const S fd = u[0] * (m_tanh(u[0]) * 0.5 + 0.5);
+    sink.g(4, (v * fd - p[DT_PMAX]) / p[DT_PMAX]);
+    sink.g(5, (1.0 - v) / sx5);
+    sink.g(6, (p[DT_FB_MAX] - u[0]) / su0); sink.g(7, (u[0] - p[DT_FD_MAX]) / su0);
+    sink.g(8, (-p[DT_DELTA_MAX] - delta) / su2); sink.g(9, (delta - p[DT_DELTA_MAX]) / su2);
+    const S ru = (un0 - u[0]) / t, rd = (un2 - delta) / t;
+    sink.g(10, (p[DT_FB_MAX] / p[DT_TB] - ru) / su0); sink.g(11, (ru - p[DT_FD_MAX] / p[DT_TD]) / su0);
+    sink.g(12, (-p[DT_DELTA_MAX] / p[DT_TDELTA] - rd) / su2); sink.g(13, (rd - p[DT_DELTA_MAX] / p[DT_TDELTA]) / su2);
+    sink.g(14, ((P.right[j] + P.margin) - x[1]) / sx1); sink.g(15, (x[1] - (P.left[j] - P.margin)) / sx1);
+    sink.g(16, -t);
+  }
   {  // utils/utils.py:10-18
     const S d = xn[2] - x[2];
-    xn[2] = m_atan2(m_sin(d), m_cos(d)) + x[2];
+    S sdd, cdd;
+    m_sincos(d, sdd, cdd);
+    xn[2] = m_atan2(sdd, cdd) + x[2];
     const S ds = x[0] - xn[0], kk = m_abs(ds) + P.track_length / 2.0;
     xn[0] = xn[0] + (kk - m_fmod(kk, P.track_length)) * dt_sign(m_val(ds));
   }
-  S f1[6], f2[6], fm[6], xm[6];
-  DtTyres<S> ty, ty2;
-  dt_dynamics(p, x, u, k, f1, ty);
-  dt_dynamics(p, xn, u, k, f2, ty2);
+  S f1[6], f2[6], xm[6];
+  {
+    DtTyres<S> ty;
+    dt_dynamics(p, x, u, k, f1, ty);
+    const S delta = u[2], gam = u[3];
+    S sd, cd_;
+    m_sincos(delta, sd, cd_);
+    sink.eq(6, (gam - p[DT_HCOG] / (0.5 * (p[DT_TWF] + p[DT_TWR])) *
+                         (ty.fy[2] + ty.fy[3] + (ty.fx[0] + ty.fx[1]) * sd + (ty.fy[0] + ty.fy[1]) * cd_)) * P.se[6]);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) xm[c] = 0.5 * (x[c] + xn[c]) + (t / 8.0) * (f1[c] - f2[c]);
-  dt_dynamics(p, xm, u, k, fm, ty2);
-#pragma unroll
-  for (int c = 0; c < 6; ++c) eq[c] = (x[c] + (t / 6.0) * (f1[c] + 4.0 * fm[c] + f2[c]) - xn[c]) * P.se[c];
-  const S delta = u[2], gam = u[3], v = x[5];
-  eq[6] = (gam - p[DT_HCOG] / (0.5 * (p[DT_TWF] + p[DT_TWR])) *
-                     (ty.fy[2] + ty.fy[3] + (ty.fx[0] + ty.fx[1]) * m_sin(delta) + (ty.fy[0] + ty.fy[1]) * m_cos(delta))) * P.se[6];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const S qx = ty.fx[w] / (p[DT_MU] * ty.fz[w]), qy = ty.fy[w] / (p[DT_MU] * ty.fz[w]);
-    g[w] = qx * qx + qy * qy - 1.0;
+    for (int w = 0; w < 4; ++w) {
+      const S qx = ty.fx[w] / (p[DT_MU] * ty.fz[w]), qy = ty.fy[w] / (p[DT_MU] * ty.fz[w]);
+      sink.g(w, qx * qx + qy * qy - 1.0);
+    }
   }
-  const S fd = u[0] * (m_tanh(u[0]) * 0.5 + 0.5);
-  const double su0 = P.sw[5], su2 = P.sw[6], sx1 = P.sw[0], sx5 = P.sw[4];
-  g[4] = (v * fd - p[DT_PMAX]) / p[DT_PMAX];
-  g[5] = (1.0 - v) / sx5;
-  g[6] = (p[DT_FB_MAX] - u[0]) / su0; g[7] = (u[0] - p[DT_FD_MAX]) / su0;
-  g[8] = (-p[DT_DELTA_MAX] - delta) / su2; g[9] = (delta - p[DT_DELTA_MAX]) / su2;
-  const S ru = (un[0] - u[0]) / t, rd = (un[2] - delta) / t;
-  g[10] = (p[DT_FB_MAX] / p[DT_TB] - ru) / su0; g[11] = (ru - p[DT_FD_MAX] / p[DT_TD]) / su0;
-  g[12] = (-p[DT_DELTA_MAX] / p[DT_TDELTA] - rd) / su2; g[13] = (rd - p[DT_DELTA_MAX] / p[DT_TDELTA]) / su2;
-  g[14] = ((P.right[j] + P.margin) - x[1]) / sx1; g[15] = (x[1] - (P.left[j] - P.margin)) / sx1;
-  g[16] = -t;
+  {
+    DtTyres<S> ty2;
+    dt_dynamics(p, xn, u, k, f2, ty2);
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    xm[c] = 0.5 * (x[c] + xn[c]) + (t / 8.0) * (f1[c] - f2[c]);
+    sink.eq(c, (x[c] + (t / 6.0) * (f1[c] + f2[c]) - xn[c]) * P.se[c]);
+  }
+  {
+    S fm[6];
+    DtTyres<S> ty2;
+    dt_dynamics(p, xm, u, k, fm, ty2);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sink.eq(c, ((t / 6.0) * (4.0 * fm[c])) * P.se[c]);
+  }
+}
+
+template <typename S>
+struct MtRowSink {     // all 24 rows (function values, Jacobian slices)
+  S (&eq_)[kMtNe];
+  S (&g_)[kMtNi];
+  __device__ __forceinline__ void eq(int c, const S& v) { eq_[c] = eq_[c] + v; }
+  __device__ __forceinline__ void g(int c, const S& v) { g_[c] = g_[c] + v; }
+};
+
+template <typename S>
+__device__ __forceinline__ void mt_pair(const MtProblem& P, int j, const S (&wo)[kMtNv], const S (&wn)[kMtNv],
+                                        S (&eq)[kMtNe], S (&g)[kMtNi]) {
+#pragma unroll
+  for (int c = 0; c < kMtNe; ++c) eq[c] = MtLift<S>::make(0.0);
+#pragma unroll
+  for (int c = 0; c < kMtNi; ++c) g[c] = MtLift<S>::make(0.0);
+  MtRowSink<S> sink{eq, g};
+  mt_pair_emit<S>(P, j, wo, wn, sink);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -142,7 +200,7 @@ __device__ __forceinline__ void mt_instance(MtProblem& P, int b) {
 }
 
 // k_mt_derivs<KIND>: one thread per (node, instance, slice).  KIND 0: functions (1 slice), 1: Jacobian (6 slices
-// of three directions), 2: Hessian (21 slices = pairs of direction groups) -- three kernels, so that the cheap
+// of three directions), 2: Hessian (kMtHesSlices pairs of direction groups) -- three kernels, so that the cheap
 // ones do not inherit the register budget of the forward-over-forward one.
 template <int KIND>
 __global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
@@ -184,52 +242,59 @@ __global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
       for (int c = 0; c < kMtNi; ++c) st.jac[(o * kMtNf + kMtNe + c) * kMtLoc + v0 + i] = g[c].d[i];
     }
   } else {
-    // Hessian of L = y . eq + z . g: direction groups (ga <= gb) of three unknowns each
-    int q = slice - 1 - kMtJacSlices, ga = 0;
-    while (q >= kMtHesGroups - ga) { q -= kMtHesGroups - ga; ++ga; }
-    const int gb = ga + q;
-    using D1 = Dual<3>;
-    using D2 = Dual<3, D1>;
-    D2 wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
+    // Hessian of L = y . eq + z . g: slice = (inner group ga of NA unknowns, outer group gb of NB unknowns)
+    constexpr int NA = kMtHesNA, NB = kMtHesNB;
+    int q = (int)blockIdx.z, ga = 0, gb = 0;
+    for (;; ++ga) {   // the q-th kept pair, groups of a outermost (slices of one a share cache lines of H)
+      const int first = (NA * ga) / NB;   // smallest gb with NA ga <= NB gb + NB - 1
+      const int cnt = kMtLoc / NB - first;
+      if (q < cnt) { gb = first + q; break; }
+      q -= cnt;
+    }
+    using D1 = Dual<NA>;
+    using D2 = Dual<NB, D1>;
+    D2 wo[kMtNv], wn[kMtNv];
     auto seed = [&](D2& r, double val, int var) {
       r.v.v = val;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        r.v.d[i] = (var == 3 * ga + i) ? 1.0 : 0.0;          // inner directions: group a
-        r.d[i].v = (var == 3 * gb + i) ? 1.0 : 0.0;          // outer directions: group b
+      for (int ia = 0; ia < NA; ++ia) r.v.d[ia] = (var == NA * ga + ia) ? 1.0 : 0.0;   // inner directions: group a
 #pragma unroll
-        for (int q2 = 0; q2 < 3; ++q2) r.d[i].d[q2] = 0.0;
+      for (int ib = 0; ib < NB; ++ib) {
+        r.d[ib].v = (var == NB * gb + ib) ? 1.0 : 0.0;                                   // outer directions: group b
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) r.d[ib].d[ia] = 0.0;
       }
     };
 #pragma unroll
     for (int a = 0; a < kMtNv; ++a) { seed(wo[a], wo_[a], a); seed(wn[a], wn_[a], kMtNv + a); }
-    mt_pair<D2>(P, j, wo, wn, eq, g);
-    double h[3][3] = {};
-    const double* y = st.y + o * kMtNe;
-    const double* z = st.z + o * kMtNi;
+    // the sink keeps only the mixed second derivatives of the Lagrangian
+    struct LagrSink {
+      const double* y; const double* z;
+      double h[NB][NA];
+      __device__ __forceinline__ void add(double m, const D2& v) {
 #pragma unroll
-    for (int c = 0; c < kMtNe; ++c) {
-      const double m = y[c];
+        for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
-      for (int ib = 0; ib < 3; ++ib)
+          for (int ia = 0; ia < NA; ++ia) h[ib][ia] = fma(m, v.d[ib].d[ia], h[ib][ia]);
+      }
+      __device__ __forceinline__ void eq(int c, const D2& v) { add(y[c], v); }
+      __device__ __forceinline__ void g(int c, const D2& v) { add(z[c], v); }
+    } sink;
+    sink.y = st.y + o * kMtNe; sink.z = st.z + o * kMtNi;
 #pragma unroll
-        for (int ia = 0; ia < 3; ++ia) h[ib][ia] += m * eq[c].d[ib].d[ia];
-    }
+    for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
-    for (int c = 0; c < kMtNi; ++c) {
-      const double m = z[c];
-#pragma unroll
-      for (int ib = 0; ib < 3; ++ib)
-#pragma unroll
-        for (int ia = 0; ia < 3; ++ia) h[ib][ia] += m * g[c].d[ib].d[ia];
-    }
+      for (int ia = 0; ia < NA; ++ia) sink.h[ib][ia] = 0.0;
+    mt_pair_emit<D2>(P, j, wo, wn, sink);
+    const auto& h = sink.h;
+    // every entry (a <= b) lies in exactly one slice: it writes the entry and its mirror image
     double* H = st.hes + o * kMtLoc * kMtLoc;
 #pragma unroll
-    for (int ib = 0; ib < 3; ++ib)
+    for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
-      for (int ia = 0; ia < 3; ++ia) {
-        H[(3 * gb + ib) * kMtLoc + 3 * ga + ia] = h[ib][ia];
-        H[(3 * ga + ia) * kMtLoc + 3 * gb + ib] = h[ib][ia];
+      for (int ia = 0; ia < NA; ++ia) {
+        const int va = NA * ga + ia, vb = NB * gb + ib;
+        if (va <= vb) { H[vb * kMtLoc + va] = h[ib][ia]; H[va * kMtLoc + vb] = h[ib][ia]; }
       }
   }
 }
