@@ -37,26 +37,25 @@ namespace rl {
 constexpr int kMtNv = 9, kMtNe = 7, kMtNi = 17, kMtNf = kMtNe + kMtNi, kMtNb = kMtNv + kMtNe;  // 16
 constexpr int kMtLoc = 2 * kMtNv;  // 18 local unknowns of a pair: own 9 + next node's 9
 constexpr int kMtJacSlices = kMtLoc / 3;
-// Hessian slices: inner direction groups of kMtHesNA unknowns x outer groups of kMtHesNB unknowns; a slice is
-// kept when it holds an entry (a, b) with a <= b.  Nested duals carry (1 + NA)(1 + NB) doubles per value, and the
-// model keeps ~50 values alive: measured on MI355X (MGKT, 256 instances, whole solve) 1 x 1 (171 slices, 0.5 KB
-// of spills per lane) 4.7 s, 1 x 2 8.4 s, 1 x 3 8.8 s, 3 x 3 (21 slices, 8.5 KB of spills) 13.8 s.
-#ifndef RL_MT_HES_NA
-#define RL_MT_HES_NA 1
-#endif
-#ifndef RL_MT_HES_NB
-#define RL_MT_HES_NB 1
-#endif
-constexpr int kMtHesNA = RL_MT_HES_NA, kMtHesNB = RL_MT_HES_NB;
-static_assert(kMtLoc % kMtHesNA == 0 && kMtLoc % kMtHesNB == 0, "direction groups must tile the 18 local unknowns");
+// Hessian slices: one thread differentiates along ONE pair of local unknowns (a <= b) with nested duals of
+// (1 + 1)(1 + 1) = 4 doubles per value; the model keeps ~50 values alive, so wider direction groups spill:
+// measured on MI355X (MGKT, 256 instances, whole solve) 1 x 1 directions (0.5 KB of spills per lane) 4.7 s,
+// 1 x 2 8.4 s, 1 x 3 8.8 s, 3 x 3 (21 slices, 8.5 KB of spills) 13.8 s.
+// Structure of the pair functions (mt_pair_emit): the next node's gamma and t (local 16, 17) do not occur; its
+// F and delta (14, 15) occur only in the rate rows (u' - u) / t, i.e. together with this node's F, delta, t.
+// Those pairs are never evaluated (their entries of `hes` stay at the zero they are initialised with).
+__host__ __device__ constexpr bool mt_hes_pair_kept(int a, int b) {   // a <= b
+  if (b >= 16) return false;
+  if (b >= 14) return a >= 5 && a <= 8;
+  return true;
+}
 constexpr int mt_hes_slices() {
   int c = 0;
-  for (int ga = 0; ga < kMtLoc / kMtHesNA; ++ga)
-    for (int gb = 0; gb < kMtLoc / kMtHesNB; ++gb)
-      if (kMtHesNA * ga <= kMtHesNB * gb + kMtHesNB - 1) ++c;
+  for (int b = 0; b < kMtLoc; ++b)
+    for (int a = 0; a <= b; ++a) c += mt_hes_pair_kept(a, b) ? 1 : 0;
   return c;
 }
-constexpr int kMtHesSlices = mt_hes_slices();
+constexpr int kMtHesSlices = mt_hes_slices();   // 113 of the 171 pairs
 constexpr double kMtEpsReg = 1e-8;  // dual regularisation of the KKT system
 constexpr double kMtThetaGrowth = 2.0;
 constexpr double kMtCostDiag = 2e-4 + 4e-1, kMtCostOff = -2e-1;  // Hessian of 1e-4 |U|^2 + 1e-1 |dU|^2 (:119-123)
@@ -242,13 +241,20 @@ __global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
       for (int c = 0; c < kMtNi; ++c) st.jac[(o * kMtNf + kMtNe + c) * kMtLoc + v0 + i] = g[c].d[i];
     }
   } else {
-    // Hessian of L = y . eq + z . g: slice = (inner group ga of NA unknowns, outer group gb of NB unknowns)
-    constexpr int NA = kMtHesNA, NB = kMtHesNB;
+    // Hessian of L = y . eq + z . g: slice = the q-th kept pair (ga, gb), ga <= gb, of local unknowns
+    constexpr int NA = 1, NB = 1;
     int q = (int)blockIdx.z, ga = 0, gb = 0;
-    for (;; ++ga) {   // the q-th kept pair, groups of a outermost (slices of one a share cache lines of H)
-      const int first = (NA * ga) / NB;   // smallest gb with NA ga <= NB gb + NB - 1
-      const int cnt = kMtLoc / NB - first;
-      if (q < cnt) { gb = first + q; break; }
+    for (gb = 0; gb < kMtLoc; ++gb) {
+      int cnt = 0;
+      for (int a = 0; a <= gb; ++a) cnt += mt_hes_pair_kept(a, gb) ? 1 : 0;
+      if (q < cnt) {
+        for (ga = 0;; ++ga) {
+          if (!mt_hes_pair_kept(ga, gb)) continue;
+          if (q == 0) break;
+          --q;
+        }
+        break;
+      }
       q -= cnt;
     }
     using D1 = Dual<NA>;
