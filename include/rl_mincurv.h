@@ -16,6 +16,10 @@
  *   - a spline is (t[nt], cx[n], cy[n], k) with n = nt-k-1, exactly scipy's BSpline.t/.c/.k;
  *   - "host" entry points take host pointers and synchronise; the *_dev entry points take DEVICE
  *     pointers, enqueue on the context's stream (rl_ctx_set_stream) and do not synchronise;
+ *   - device memory is owned by the context: host entry points stage through a pool of blocks that is
+ *     reused from call to call (a repeated call of the same shape allocates nothing), the *_dev entry
+ *     points of the simulator and the min-time solve carve their work arrays out of one grow-only arena;
+ *     both are released by rl_ctx_destroy.  One context = one stream = one caller at a time;
  *   - there is NO CPU fallback: without a usable HIP device rl_ctx_create fails.
  */
 #ifndef RL_MINCURV_H

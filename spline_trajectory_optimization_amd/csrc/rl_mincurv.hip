@@ -76,9 +76,56 @@ struct rl_ctx {
   // min-time solve carve their work arrays out of it, so that steady-state calls allocate nothing.
   void* arena = nullptr;
   size_t arena_cap = 0;
+  // Device staging blocks of the HOST-pointer entry points (PoolBuf): handed out best-fit, returned at the end of
+  // the call, freed with the context -- a second call of the same shape allocates nothing.
+  struct PoolBlock { void* p; size_t cap; bool used; };
+  std::vector<PoolBlock> pool;
 };
 
 namespace {
+// per-call device staging of the host-pointer entry points, from the context's pool (every such entry point ends
+// with a stream synchronisation, so a block is idle when it is returned)
+template <typename T>
+struct PoolBuf {
+  rl_ctx* ctx;
+  T* p = nullptr;
+  size_t n = 0;
+  int slot = -1;
+  explicit PoolBuf(rl_ctx* c) : ctx(c) {}
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i)
+      if (!ctx->pool[i].used && ctx->pool[i].cap >= bytes && (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = i;
+    if (best < 0) {
+      if (ctx->pool.size() >= 96) {   // shapes keep changing: drop what is idle before growing further
+        for (auto& blk : ctx->pool)
+          if (!blk.used && blk.p) { (void)hipFree(blk.p); blk.p = nullptr; blk.cap = 0; }
+      }
+      void* q = nullptr;
+      const hipError_t e = hipMalloc(&q, bytes);
+      if (e != hipSuccess) return e;
+      for (int i = 0; i < (int)ctx->pool.size() && best < 0; ++i)
+        if (!ctx->pool[i].p) { ctx->pool[i] = {q, bytes, false}; best = i; }
+      if (best < 0) { ctx->pool.push_back({q, bytes, false}); best = (int)ctx->pool.size() - 1; }
+    }
+    ctx->pool[best].used = true;
+    slot = best;
+    p = static_cast<T*>(ctx->pool[best].p);
+    return hipSuccess;
+  }
+  void release() {
+    if (slot >= 0) ctx->pool[slot].used = false;
+    slot = -1; p = nullptr; n = 0;
+  }
+  ~PoolBuf() { release(); }
+  PoolBuf(const PoolBuf&) = delete;
+  PoolBuf& operator=(const PoolBuf&) = delete;
+};
+
 // sequential carve-out of the context's scratch arena; reserve() first with the total
 struct Arena {
   rl_ctx* ctx; size_t off = 0;
@@ -276,6 +323,8 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
 void rl_ctx_destroy(rl_ctx* ctx) {
   if (!ctx) return;
   if (ctx->arena) (void)hipFree(ctx->arena);
+  for (auto& blk : ctx->pool)
+    if (blk.p) (void)hipFree(blk.p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
@@ -301,7 +350,7 @@ int rl_spline_eval(rl_ctx* ctx, const double* t, int nt, const double* cx, const
   if (N <= 0 || der_max < 0 || der_max > 2) return fail(RL_ERR_ARG, "bad N / der_max");
   RL_HIP(hipSetDevice(ctx->device));
   const int n = nt - k - 1;
-  DevBuf<double> dt, dcx, dcy, du, dout;
+  PoolBuf<double> dt(ctx), dcx(ctx), dcy(ctx), du(ctx), dout(ctx);
   RL_HIP(dt.alloc(nt)); RL_HIP(dcx.alloc(n)); RL_HIP(dcy.alloc(n)); RL_HIP(du.alloc(N));
   RL_HIP(dout.alloc((size_t)2 * (der_max + 1) * N));
   RL_HIP(hipMemcpyAsync(dt.p, t, nt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -327,7 +376,7 @@ int rl_sample_along(rl_ctx* ctx, const double* t, int nt, const double* cx, cons
   if (N <= 0) return fail(RL_ERR_ARG, "bad N");
   RL_HIP(hipSetDevice(ctx->device));
   const int n = nt - k - 1;
-  DevBuf<double> dt, dcx, dcy, du, dpts, dseg;
+  PoolBuf<double> dt(ctx), dcx(ctx), dcy(ctx), du(ctx), dpts(ctx), dseg(ctx);
   RL_HIP(dt.alloc(nt)); RL_HIP(dcx.alloc(n)); RL_HIP(dcy.alloc(n)); RL_HIP(du.alloc(N));
   RL_HIP(dpts.alloc((size_t)N * RL_NCOL)); RL_HIP(dseg.alloc(N));
   RL_HIP(hipMemcpyAsync(dt.p, t, nt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -353,7 +402,7 @@ int rl_fill_bounds(rl_ctx* ctx, double* points, int N, const double* ringL, int 
   if (!ctx || !points || !ringL || !ringR) return fail(RL_ERR_ARG, "null argument");
   if (N <= 0 || nL < 2 || nR < 2) return fail(RL_ERR_ARG, "bad sizes");
   RL_HIP(hipSetDevice(ctx->device));
-  DevBuf<double> dpts, dL, dR;
+  PoolBuf<double> dpts(ctx), dL(ctx), dR(ctx);
   RL_HIP(dpts.alloc((size_t)N * RL_NCOL)); RL_HIP(dL.alloc((size_t)2 * nL)); RL_HIP(dR.alloc((size_t)2 * nR));
   RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   RL_HIP(hipMemcpyAsync(dL.p, ringL, dL.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -468,8 +517,8 @@ int rl_mincurv_cost(rl_ctx* ctx, const rl_track* trk, const int* idx, int n_idx,
   for (int q = 0; q < n_idx; ++q)
     if (idx[q] < 0 || idx[q] >= trk->n) return fail(RL_ERR_ARG, "control point index out of range");
   RL_HIP(hipSetDevice(ctx->device));
-  DevBuf<int> didx, dM;
-  DevBuf<double> dz, dH, dg;
+  PoolBuf<int> didx(ctx), dM(ctx);
+  PoolBuf<double> dz(ctx), dH(ctx), dg(ctx);
   RL_HIP(didx.alloc(n_idx)); RL_HIP(dM.alloc(n_idx));
   RL_HIP(dH.alloc((size_t)4 * n_idx)); RL_HIP(dg.alloc((size_t)2 * n_idx));
   RL_HIP(hipMemcpyAsync(didx.p, idx, n_idx * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -508,7 +557,7 @@ int rl_track_constraint(rl_ctx* ctx, const rl_track* trk, const double* points, 
   const int m = s1 - s0;
   *M = m;
   if (m == 0) return RL_OK;
-  DevBuf<double> dpts, db, dl, du;
+  PoolBuf<double> dpts(ctx), db(ctx), dl(ctx), du(ctx);
   RL_HIP(dpts.alloc((size_t)N * RL_NCOL)); RL_HIP(db.alloc(m)); RL_HIP(dl.alloc((size_t)2 * m)); RL_HIP(du.alloc((size_t)2 * m));
   RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const rl::TrackDev td = trk->dev();
@@ -641,8 +690,8 @@ int rl_mincurv_solve_batch_host(rl_ctx* ctx, const rl_track* trk, int bounds_for
   RL_HIP(hipSetDevice(ctx->device));
   const int n = trk->n, N = trk->N;
   const int cols = bounds_form == RL_BOUNDS_WIDTHS ? 2 : (bounds_form == RL_BOUNDS_POINTS ? 4 : 0);
-  DevBuf<double> din, dctrl, dxy;
-  DevBuf<int> dns, dst;
+  PoolBuf<double> din(ctx), dctrl(ctx), dxy(ctx);
+  PoolBuf<int> dns(ctx), dst(ctx);
   if (cols) {
     if (!in) return fail(RL_ERR_ARG, "bounds input is null");
     RL_HIP(din.alloc((size_t)B * N * cols));
@@ -828,7 +877,7 @@ int rl_mincurv_global_batch_host(rl_ctx* ctx, const rl_track* trk, const double*
   if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
   RL_HIP(hipSetDevice(ctx->device));
   const int n = trk->n, N = trk->N, np = n - trk->k;
-  DevBuf<double> dw, dctrl, dxy, da, dst;
+  PoolBuf<double> dw(ctx), dctrl(ctx), dxy(ctx), da(ctx), dst(ctx);
   RL_HIP(dw.alloc((size_t)B * N * 2)); RL_HIP(dctrl.alloc((size_t)B * n * 2));
   if (out_xy) RL_HIP(dxy.alloc((size_t)B * N * 2));
   if (out_a) RL_HIP(da.alloc((size_t)B * np));
@@ -905,8 +954,8 @@ int rl_qss_sim(rl_ctx* ctx, double* points, int B, int N, const double* acc_x, c
   if (!ctx || !points || !iters) return fail(RL_ERR_ARG, "null argument");
   if (B <= 0 || N < 2) return fail(RL_ERR_ARG, "bad sizes");
   RL_HIP(hipSetDevice(ctx->device));
-  DevBuf<double> dpts;
-  DevBuf<int> dit;
+  PoolBuf<double> dpts(ctx);
+  PoolBuf<int> dit(ctx);
   RL_HIP(dpts.alloc((size_t)B * N * RL_NCOL)); RL_HIP(dit.alloc(B));
   RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   if (int rc = rl_qss_sim_dev(ctx, dpts.p, B, N, acc_x, acc_c, acc_m, dcc_x, dcc_c, dcc_m, params, dit.p)) return rc;
@@ -926,11 +975,11 @@ int rl_dt_eval_nodes(rl_ctx* ctx, const double* model, int B, int N, const doubl
   if (B <= 0 || N < 2 || !(track_length > 0.0)) return fail(RL_ERR_ARG, "bad sizes");
   RL_HIP(hipSetDevice(ctx->device));
   const size_t bn = (size_t)B * N;
-  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, deq, dg, dc;
+  PoolBuf<double> ds(ctx), dk(ctx), dl(ctx), dr(ctx), dX(ctx), dU(ctx), dT(ctx), deq(ctx), dg(ctx), dc(ctx);
   RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(N)); RL_HIP(dr.alloc(N));
   RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn));
   RL_HIP(deq.alloc(bn * rl::kDtNeq)); RL_HIP(dg.alloc(bn * rl::kDtNineq)); RL_HIP(dc.alloc(bn));
-  auto up = [&](DevBuf<double>& d, const double* h) {
+  auto up = [&](PoolBuf<double>& d, const double* h) {
     return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   };
   RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
@@ -964,12 +1013,12 @@ int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double*
   if (B <= 0 || N < 2 || !(track_length > 0.0)) return fail(RL_ERR_ARG, "bad sizes");
   RL_HIP(hipSetDevice(ctx->device));
   const size_t bn = (size_t)B * N;
-  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, dje, dji, dgc;
+  PoolBuf<double> ds(ctx), dk(ctx), dl(ctx), dr(ctx), dX(ctx), dU(ctx), dT(ctx), dje(ctx), dji(ctx), dgc(ctx);
   RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(N)); RL_HIP(dr.alloc(N));
   RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn));
   RL_HIP(dje.alloc(bn * rl::kDtNeq * rl::kDtNvar)); RL_HIP(dji.alloc(bn * rl::kDtNineq * rl::kDtNvar));
   RL_HIP(dgc.alloc(bn * rl::kDtNvar));
-  auto up = [&](DevBuf<double>& d, const double* h) {
+  auto up = [&](PoolBuf<double>& d, const double* h) {
     return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   };
   RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
@@ -1072,10 +1121,10 @@ int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const
   const size_t bn = (size_t)B * N, nb_ = bounds_per_instance ? bn : (size_t)N;
   for (size_t i = 0; i < nb_; ++i)
     if (!(right[i] + margin < left[i] - margin)) return fail(RL_ERR_ARG, "track narrower than the vehicle plus margins (min_time_optimizer.py:135)");
-  DevBuf<double> ds, dk, dl, dr, dX, dU, dT, dst;
+  PoolBuf<double> ds(ctx), dk(ctx), dl(ctx), dr(ctx), dX(ctx), dU(ctx), dT(ctx), dst(ctx);
   RL_HIP(ds.alloc(N)); RL_HIP(dk.alloc(N)); RL_HIP(dl.alloc(nb_)); RL_HIP(dr.alloc(nb_));
   RL_HIP(dX.alloc(bn * 6)); RL_HIP(dU.alloc(bn * 4)); RL_HIP(dT.alloc(bn)); RL_HIP(dst.alloc((size_t)B * 12));
-  auto up = [&](DevBuf<double>& d, const double* h) { return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream); };
+  auto up = [&](PoolBuf<double>& d, const double* h) { return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream); };
   RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
   RL_HIP(up(dX, X)); RL_HIP(up(dU, U)); RL_HIP(up(dT, T));
   g_mt_poll = true;
@@ -1099,8 +1148,8 @@ static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_
   RL_HIP(hipSetDevice(ctx->device));
   const int n = trk->n, N = trk->N;
   if (int rc = rl_track_set_control_points(trk, cx, cy)) return rc;
-  DevBuf<double> dctrl, dpts;
-  DevBuf<int> dns, dst;
+  PoolBuf<double> dctrl(ctx), dpts(ctx);
+  PoolBuf<int> dns(ctx), dst(ctx);
   RL_HIP(dctrl.alloc((size_t)n * 2)); RL_HIP(dpts.alloc((size_t)N * RL_NCOL));
   RL_HIP(dns.alloc((size_t)2 * (max_iter > 0 ? max_iter : 1))); RL_HIP(dst.alloc(1));
   RL_HIP(hipMemsetAsync(dpts.p, 0, dpts.n * sizeof(double), ctx->stream));
@@ -1109,7 +1158,7 @@ static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_
                               RL_SEARCH_WINDOWED, dctrl.p, nullptr, dpts.p, dns.p, dst.p, stats, nullptr, joint);
   if (rc) return rc;
   RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-  DevBuf<double> dseg, dcx;
+  PoolBuf<double> dseg(ctx), dcx(ctx);
   if (points && trk->length > 0.0) {
     // DIST_TO_SF_BWD / _FWD of the final table (models/trajectory.py:283-289): GK21 segment lengths of the
     // optimised spline, accumulated in the reference's order; DIST_FWD uses the length the spline object
