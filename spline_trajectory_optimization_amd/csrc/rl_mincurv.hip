@@ -1195,3 +1195,12 @@ static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_
   return RL_OK;
 }
 
+
+#ifdef MT_STAMPS
+extern "C" int rl_debug_mt_stamps(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rl::g_mt_stamps), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(rl::g_mt_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

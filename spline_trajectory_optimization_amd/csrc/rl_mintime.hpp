@@ -355,7 +355,9 @@ __device__ __forceinline__ void mt_to_k(double vi, int q, double (&vk)[4]) {
 // pivot k one v_readlane pair (the pivot), five ds_bpermute pairs (column k for the lane's row, row k for the
 // lane's four columns) and four lane-local updates.  Returns the number of negative pivots (they are the LDL'
 // pivots of the block: their signs, summed over the whole elimination, are the inertia of the KKT matrix), or
-// -1 when a pivot is negligible / not finite.
+// -1 when a pivot is negligible / not finite.  (Measured and dropped: issuing the moves of pivot k + 1 before the
+// update of pivot k and advancing the moved values by the update formula, which shortens the dependent chain to
+// 1/p_k -> p_{k+1} -- 11 % slower: the step is bound by its instruction count, not by the chain.)
 __device__ __forceinline__ int mt_invert(MtBlk& S, int lane) {
   const int i = lane & 15, q = lane >> 4;
   int neg = 0;
@@ -376,11 +378,11 @@ __device__ __forceinline__ int mt_invert(MtBlk& S, int lane) {
     const bool ik = i == k;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool jk = r == kr && q == kq;
-      double v = S.v[r] - colk * rowk[r] * ip;
-      v = jk ? -colk * ip : v;
-      v = ik ? rowk[r] * ip : v;
-      v = (ik && jk) ? ip : v;
+      const double t = rowk[r] * ip;                 // row k of the result; S_ij -= S_ik t_j elsewhere
+      double v = fma(-colk, t, S.v[r]);
+      if (r == kr) v = q == kq ? -colk * ip : v;     // column k
+      v = ik ? t : v;
+      if (r == kr) v = (ik && q == kq) ? ip : v;
       S.v[r] = v;
     }
   }
@@ -530,6 +532,14 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
   }
 }
 
+#ifdef MT_STAMPS
+__device__ unsigned long long g_mt_stamps[8];
+#define MT_T(v) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define MT_ACC(slot, t1, t0) mt_acc[slot] += (t1) - (t0)
+#else
+#define MT_T(v) do { } while (0)
+#define MT_ACC(slot, t1, t0) do { } while (0)
+#endif
 // k_mt_kkt: one wave per instance: block elimination of the cyclic block-tridiagonal KKT system from the
 // assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.  All blocks stay in
 // registers (MtBlk); the blocks of the next node are fetched while the current node is eliminated.  Kept for
@@ -563,6 +573,10 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
     for (int r = 0; r < 4; ++r) X.v[r] += (i == 4 * r + q && i < kMtNv) ? delta : 0.0; };
   const MtBlk zero = {{0.0, 0.0, 0.0, 0.0}};
 
+#ifdef MT_STAMPS
+  unsigned long long mt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mt_a = 0, mt_b = 0, mt_c = 0;
+  MT_T(mt_c);
+#endif
   int attempt = 0;
   bool ok = false;
   MtBlk Sl = zero;
@@ -581,6 +595,7 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
     MtBlk eN = ld(Eg), dN = N > 2 ? ld_t(Dg + 256) : zero;   // blocks of the next step, in flight
     double rN = N > 2 ? Rg[16 + i] : 0.0;
     for (int j = 0; j < N - 1 && !bad; ++j) {
+      MT_T(mt_a);
       const MtBlk E = eN, dC = dN;
       const double rC = rN;
       if (j + 1 < N - 1) {               // prefetch for step j + 1: E_{j+1}, D_{j+2}, r_{j+2}
@@ -592,14 +607,17 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) F.v[r] += E.v[r];
       }
+      MT_T(mt_b); MT_ACC(0, mt_b, mt_a);
       const int neg = mt_invert(S, lane);                   // S_j^-1
       if (neg < 0) { bad = true; break; }
       n_neg += neg;
+      MT_T(mt_a); MT_ACC(1, mt_a, mt_b);
       const double aj = mt_gemv(S, rk);                     // a_j = S_j^-1 r_j
       if (q == 0) vec[(size_t)j * 16 + i] = aj;
       const MtBlk Pm = j < N - 2 ? mt_mul_t(S, E) : zero;   // P_j = E_j S_j^-1
       const MtBlk Qm = mt_mul_t(S, F);                      // Q_j = F_j S_j^-1
       double* Bj = blk + (size_t)j * 3 * 256;
+      MT_T(mt_b); MT_ACC(2, mt_b, mt_a);
       st_rm(Bj, Pm); st_rm(Bj + 256, Qm);
       rl -= mt_gemv(Qm, rk);                                // r_last -= Q_j r_j
       {
@@ -607,6 +625,7 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Sl.v[r] -= U.v[r];
       }
+      MT_T(mt_a); MT_ACC(3, mt_a, mt_b);
       if (j < N - 2) {
         // next node: S_{j+1} = D_{j+1} + delta - P_j E_j' ; F_{j+1} = -Q_j E_j' ; r_{j+1} -= P_j r_j
         const MtBlk M = mt_mul_t(E, Pm), Fn = mt_mul_t(E, Qm);
@@ -616,6 +635,7 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
         const double rn = rC - mt_gemv(Pm, rk);
         mt_to_k(rn, q, rk);
       }
+      MT_T(mt_b); MT_ACC(4, mt_b, mt_a);
     }
     if (!bad) {
       const int neg = mt_invert(Sl, lane);
@@ -634,6 +654,7 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
     if (lane == 0) scal[5] = 2.0;
     return;
   }
+  MT_T(mt_a); MT_ACC(5, mt_a, mt_c);
   // ---- back substitution: x_last = S_last^-1 r_last; x_j = a_j - Q_j' x_last - P_j' x_{j+1}
   double* dw = st.dw + (size_t)b * N * kMtNv;
   double* dy = st.dy + (size_t)b * N * kMtNe;
@@ -666,40 +687,43 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
     }
   }
   mt_wave_sync();
-  // the chain: lanes 0..15 own one component each; P_{j-1} and a'_{j-1} are fetched while x_j is formed
+  MT_T(mt_b); MT_ACC(6, mt_b, mt_a);
+  // the chain: lanes 0..15 own one component each; P and a' of the node THREE steps ahead are fetched while x_j is
+  // formed (four rotating register sets: a step is shorter than the latency of a load)
   if (lane < 16) {
-    double pj[16], aj;
-    {
-      const double* Bj = blk + (size_t)(N - 2) * 3 * 256;
+    double pb[4][17];
+    auto fetch = [&](double (&dst)[17], int node) {
+      if (node >= 0) {
+        const double* Bn = blk + (size_t)node * 3 * 256;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) pj[k] = Bj[k * 16 + lane];
-      aj = Bj[512 + lane];
-    }
-    int cur = 1;
-    for (int j = N - 2; j >= 0; --j) {
-      double pn[16], an = 0.0;
-      if (j > 0) {
-        const double* Bn = blk + (size_t)(j - 1) * 3 * 256;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) pn[k] = Bn[k * 16 + lane];
-        an = Bn[512 + lane];
+        for (int k = 0; k < 16; ++k) dst[k] = Bn[k * 16 + lane];
+        dst[16] = Bn[512 + lane];
       }
-      double x0 = aj, x1 = 0.0;
+    };
+    fetch(pb[0], N - 2); fetch(pb[1], N - 3); fetch(pb[2], N - 4);
+    int cur = 1;
+    for (int j0 = N - 2; j0 >= 0; j0 -= 4) {
 #pragma unroll
-      for (int k = 0; k < 16; k += 2) { x0 = fma(-pj[k], xs[cur][k], x0); x1 = fma(-pj[k + 1], xs[cur][k + 1], x1); }
-      const double x = x0 + x1;
-      if (lane < kMtNv) dw[(size_t)j * kMtNv + lane] = x;
-      else dy[(size_t)j * kMtNe + lane - kMtNv] = x;
-      xs[cur ^ 1][lane] = x;
-      mt_wave_sync();
-      cur ^= 1;
-      if (j > 0) {
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 - u;
+        if (j < 0) break;
+        fetch(pb[(u + 3) & 3], j - 3);
+        double x0 = pb[u][16], x1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) pj[k] = pn[k];
-        aj = an;
+        for (int k = 0; k < 16; k += 2) { x0 = fma(-pb[u][k], xs[cur][k], x0); x1 = fma(-pb[u][k + 1], xs[cur][k + 1], x1); }
+        const double x = x0 + x1;
+        if (lane < kMtNv) dw[(size_t)j * kMtNv + lane] = x;
+        else dy[(size_t)j * kMtNe + lane - kMtNv] = x;
+        xs[cur ^ 1][lane] = x;
+        mt_wave_sync();
+        cur ^= 1;
       }
     }
   }
+#ifdef MT_STAMPS
+  MT_T(mt_a); MT_ACC(7, mt_a, mt_b);
+  if (lane == 0 && b == 0) for (int qq = 0; qq < 8; ++qq) atomicAdd(&g_mt_stamps[qq], mt_acc[qq]);
+#endif
 }
 
 // residuals only (final report of the instances that ran into the iteration limit)
