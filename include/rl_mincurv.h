@@ -243,7 +243,11 @@ int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const
 /* Same with DEVICE pointers for s, kappa, left, right, X, U, T, stats (model stays a host array): enqueued on
  * the context's stream, no synchronisation, exactly max_iter iterations are enqueued (finished instances return
  * from every kernel at once); all work arrays come from the context's grow-only scratch, so steady-state calls
- * allocate nothing.  The caller guarantees right + margin < left - margin. */
+ * allocate nothing.  The caller guarantees right + margin < left - margin.
+ * Batches of 12 or more instances are split into three sub-batches on three in-order queues (the context's stream
+ * plus two helper streams owned by the context) so that one sub-batch's elimination overlaps another's derivative
+ * kernels; the helpers fork from and are joined back into the context's stream with events inside the call, so the
+ * stream semantics seen by the caller do not change (RL_MT_GROUPS=1 keeps everything on the one stream). */
 int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
                                const double* left, const double* right, int bounds_per_instance, double margin,
                                double track_length, double average_track_width, double speed_cap, double* X, double* U,
