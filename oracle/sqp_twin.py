@@ -38,7 +38,9 @@ import scipy.sparse.linalg as spla
 from . import dt_checker as dc
 
 NV, NE, NI = 9, 7, 17
-THETA_GROWTH = 2.0   # a step may not more than double the l1 infeasibility, whatever it does to the objective
+THETA_GROWTH = 2.0
+FILTER = 8
+THETA_FLOOR = 1e-5     # ... above 1e-5 per row (next to a feasible point twice nothing is nothing)   # a step may not more than double the l1 infeasibility, whatever it does to the objective
 # reduced variable a -> (array, column): X cols 1..5, U cols 0,2,3, T
 _XCOL = [1, 2, 3, 4, 5]
 _UCOL = [0, 2, 3]
@@ -294,6 +296,7 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
     _, H = P.cost_grad_hess(w)
     I9 = sp.identity(N * NV, format="csr")
     status = 0
+    filt = []
     kkt = viol = compl = np.inf
     for it in range(max_iter):
         eq, g = P.functions(w)
@@ -315,7 +318,10 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
             break
         # barrier parameter: monotone (Fiacco-McCormick): lowered once the barrier problem is solved to ~10 mu
         if max(kkt, viol, np.abs(sz * zz - mu).max()) <= 10.0 * mu:
-            mu = max(min(0.2 * mu, mu ** 1.5), tol / 10.0)     # no lower than needed for compl <= tol
+            mu_new = max(min(0.2 * mu, mu ** 1.5), tol / 10.0)     # no lower than needed for compl <= tol
+            if mu_new != mu:
+                filt = []      # a new barrier problem: another objective, the filter starts empty
+            mu = mu_new
         Hk = H + lagrangian_hessian(P, w, y, z)
         W = sp.diags(zz / sz)
         Kww0 = (Hk + G.T @ W @ G).tocsr()
@@ -348,8 +354,15 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
             eqt, gt = P.functions(wt)
             tht = np.abs(eqt).sum() + np.abs(gt.ravel() + stt).sum()
             pht = P.cost(wt) - mu * np.log(stt).sum()
-            if np.isfinite(pht) and np.isfinite(tht) and tht <= THETA_GROWTH * th0 + 1e-9 and \
-                    (tht <= (1 - 1e-5) * th0 or pht <= ph0 - 1e-5 * th0):
+            floor = THETA_FLOOR * N * (NE + NI)
+            acc = np.isfinite(pht) and np.isfinite(tht) and tht <= max(THETA_GROWTH * th0, floor) + 1e-9 and \
+                (tht <= (1 - 1e-5) * th0 or pht <= ph0 - 1e-5 * th0)
+            # ... and, where it is the floor that lets the infeasibility grow, acceptable to the (up to FILTER) earlier
+            # iterates of this barrier problem: no cycling between two nearly feasible points
+            if THETA_GROWTH * th0 < floor:
+                for (thf, phf) in filt[-FILTER:]:
+                    acc = acc and (tht <= (1 - 1e-5) * thf or pht <= phf - 1e-5 * thf)
+            if acc:
                 ok = True
                 break
             a *= 0.5
@@ -360,6 +373,7 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
                 break
             continue
         hist[-1][6] = a
+        filt.append((th0, ph0))     # the point just left joins the filter
         w = wt; s = stt.reshape(N, NI)
         y = y + a * dy
         z = (zz + min(ad, 1.0) * dz).reshape(N, NI)

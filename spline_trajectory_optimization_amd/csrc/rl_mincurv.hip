@@ -1075,7 +1075,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   const size_t bn = (size_t)B * N;
   const size_t counts[] = {bn * rl::kMtNv, bn * rl::kMtNi, bn * rl::kMtNe, bn * rl::kMtNi, bn * rl::kMtNf,
                            bn * rl::kMtNf * rl::kMtLoc, bn * rl::kMtLoc * rl::kMtLoc, bn * rl::kMtNv, bn * rl::kMtNe,
-                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16};
+                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16, (size_t)B * 2 * rl::kMtFilter};
   size_t total = 0;
   for (size_t c : counts) total += Arena::pad(c * sizeof(double));
   Arena ar(ctx);
@@ -1087,6 +1087,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.hes = ar.take<double>(counts[6]); st.dw = ar.take<double>(counts[7]); st.dy = ar.take<double>(counts[8]);
   st.blk = ar.take<double>(counts[9]); st.vec = ar.take<double>(counts[10]); st.scal = ar.take<double>(counts[11]);
   st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
+  st.filt = ar.take<double>(counts[15]);
   st.tol = tol;
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
   RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
@@ -1117,7 +1118,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     G.st.w = st.w + o * rl::kMtNv; G.st.s = st.s + o * rl::kMtNi; G.st.y = st.y + o * rl::kMtNe; G.st.z = st.z + o * rl::kMtNi;
     G.st.fun = st.fun + o * rl::kMtNf; G.st.jac = st.jac + o * rl::kMtNf * rl::kMtLoc; G.st.hes = st.hes + o * rl::kMtLoc * rl::kMtLoc;
     G.st.dw = st.dw + o * rl::kMtNv; G.st.dy = st.dy + o * rl::kMtNe; G.st.blk = st.blk + o * 3 * 256; G.st.vec = st.vec + o * 16;
-    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16;
+    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.filt = st.filt + (size_t)G.b0 * 2 * rl::kMtFilter; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16;
     G.X = X + o * 6; G.U = U + o * 4; G.T = T + o; G.stats = stats + (size_t)G.b0 * 12;
   }
   if (ngrp > 1) {   // fork: the other streams start after everything already enqueued on the first

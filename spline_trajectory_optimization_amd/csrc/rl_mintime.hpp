@@ -57,7 +57,8 @@ constexpr int mt_hes_slices() {
 }
 constexpr int kMtHesSlices = mt_hes_slices();   // 113 of the 171 pairs
 constexpr double kMtEpsReg = 1e-8;  // dual regularisation of the KKT system
-constexpr double kMtThetaGrowth = 2.0;
+constexpr double kMtThetaGrowth = 2.0, kMtThetaFloor = 1e-5;
+constexpr int kMtFilter = 8;   // entries of the filter (a ring: the oldest is overwritten)
 constexpr double kMtCostDiag = 2e-4 + 4e-1, kMtCostOff = -2e-1;  // Hessian of 1e-4 |U|^2 + 1e-1 |dU|^2 (:119-123)
 
 struct MtProblem {
@@ -188,6 +189,7 @@ struct MtState {       // per-batch device arrays, instance-major
   double* dblk;   // [B,N,256] assembled diagonal blocks D_j (without delta)
   double* eblk;   // [B,N,256] assembled coupling blocks E_j = M[j+1][j]
   double* rhs;    // [B,N,16]  assembled right-hand sides
+  double* filt;   // [B,16] filter: (infeasibility, barrier objective) of up to 8 earlier iterates of the current barrier problem
   double* scal;   // [B,16] per-instance scalars: 0 mu, 1 delta, 2 kkt, 3 viol, 4 compl, 5 status (0 run, 1 converged,
                   //        2 failed), 6 iterations, 7 last alpha, 8 theta0, 9 phi0, 10 refactorisations, 11 lap time
   double tol;
@@ -448,7 +450,11 @@ __global__ void __launch_bounds__(64) k_mt_prepare(MtProblem P, MtState st) {
     return;
   }
   // monotone barrier update once the barrier problem is solved to 10 mu; no lower than compl <= tol needs
-  if (fmax(fmax(kkt, viol), errmu) <= 10.0 * mu) mu = fmax(fmin(0.2 * mu, mu * sqrt(mu)), st.tol / 10.0);
+  if (fmax(fmax(kkt, viol), errmu) <= 10.0 * mu) {
+    const double mu_new = fmax(fmin(0.2 * mu, mu * sqrt(mu)), st.tol / 10.0);
+    if (mu_new != mu && lane == 0) scal[14] = 0.0;   // a new barrier problem: its objective is another function, the filter starts empty
+    mu = mu_new;
+  }
   if (lane == 0) scal[0] = mu;
 }
 
@@ -805,6 +811,9 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
   // backtracking against the filter {(theta0, phi0)}
   double a = ap;
   bool ok = false;
+  int halvings = 0;
+  double* filt = st.filt + (size_t)b * 2 * kMtFilter;
+  const int nfilt_total = (int)scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
   for (int trial = 0; trial < 12; ++trial) {
     double theta = 0.0, phi = 0.0;
     bool fin = true;
@@ -832,8 +841,18 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
     }
     theta = mt_block_reduce<256>(theta, red, 0); phi = mt_block_reduce<256>(phi, red, 0);
     fin = isfinite(theta) && isfinite(phi);
-    // a step may not more than double the l1 infeasibility, whatever it does to the objective
-    if (fin && theta <= kMtThetaGrowth * theta0 + 1e-9 && (theta <= (1.0 - 1e-5) * theta0 || phi <= phi0 - 1e-5 * theta0)) { ok = true; break; }
+    // a step may not more than double the l1 infeasibility, whatever it does to the objective -- above a floor of
+    // 1e-5 per row: next to a feasible point (theta0 ~ 0) the second-order infeasibility of any useful step is larger
+    // than twice nothing, and without the floor such instances crept along with two halvings per iteration
+    const double floor_ = kMtThetaFloor * (double)(N * kMtNf);
+    bool acc = fin && theta <= fmax(kMtThetaGrowth * theta0, floor_) + 1e-9 &&
+               (theta <= (1.0 - 1e-5) * theta0 || phi <= phi0 - 1e-5 * theta0);
+    // ... and where it is the floor that lets the infeasibility grow, the step must be acceptable to the earlier
+    // iterates of this barrier problem as well: otherwise two nearly feasible points, one of less infeasibility and
+    // one of less objective, can be visited in turn for ever (seen on 4 of 256 instances)
+    for (int e = 0; e < nfilt && acc && kMtThetaGrowth * theta0 < floor_; ++e)
+      acc = theta <= (1.0 - 1e-5) * filt[2 * e] || phi <= filt[2 * e + 1] - 1e-5 * filt[2 * e];
+    if (acc) { ok = true; halvings = trial; break; }
     a *= 0.5;
   }
   double delta = scal[1];
@@ -853,7 +872,12 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
     sv[idx] = s_; zv[idx] = z_;
   }
   delta = fmin(fmax(delta * (a > 0.9 ? 0.4 : (a > 0.3 ? 1.0 : 5.0)), 1e-6), 1e3);
-  if (tid == 0) { scal[1] = delta; scal[7] = a; scal[6] += 1.0; scal[8] = theta0; scal[9] = phi0; }
+  if (tid == 0) {
+    scal[1] = delta; scal[7] = a; scal[6] += 1.0; scal[8] = theta0; scal[9] = phi0; scal[12] = ap; scal[13] = (double)halvings;
+    const int slot = nfilt_total % kMtFilter;   // the point just left joins the filter
+    filt[2 * slot] = theta0; filt[2 * slot + 1] = phi0;
+    scal[14] = (double)(nfilt_total + 1);
+  }
 }
 
 // physical X [B,N,6], U [B,N,4], T [B,N]  <->  scaled unknowns w [B,N,9]
@@ -884,7 +908,7 @@ __global__ void k_mt_stats(MtState st, double* stats) {
   const double* q = st.scal + (size_t)b * 16;
   double* o = stats + (size_t)b * 12;
   o[0] = q[6]; o[1] = q[2]; o[2] = q[3]; o[3] = q[4]; o[4] = q[11]; o[5] = q[5]; o[6] = q[0]; o[7] = q[1];
-  o[8] = q[7]; o[9] = q[10]; o[10] = 0.0; o[11] = 0.0;
+  o[8] = q[7]; o[9] = q[10]; o[10] = q[12]; o[11] = q[13];
 }
 
 // initial slacks / multipliers from the functions at w0:  s = max(-g, 1e-2), z = mu0 / s, y = 0
