@@ -21,9 +21,11 @@ QP) through its block-tridiagonal cyclic KKT system:
 H = Hessian of the Lagrangian (objective + exact constraint curvature: a Gauss-Newton variant without it
 does not converge on this problem, measured), delta is a Levenberg / inertia-correction parameter: raised
 until the block elimination shows 9 positive and 7 negative pivots per node, adapted by the step length
-afterwards.  Step length: fraction to the boundary (0.995) for s and z, then backtracking against a
-one-entry filter on (infeasibility, barrier objective).  mu is lowered monotonically once the barrier problem
-is solved to 10 mu.
+afterwards.  Step length: fraction to the boundary (0.995) for s and z, then backtracking on (infeasibility,
+barrier objective): improve one of them against the current point, do not raise the infeasibility above
+max(2 x current, 1e-5 per row), and -- where that floor is what lets it grow -- be acceptable to the last 8
+iterates of the barrier problem as well (filter).  mu is lowered monotonically once the barrier problem is
+solved to 10 mu.
 
 The HIP kernels (k_mt_*) implement exactly this iteration; this file differs in how it does the work:
 derivatives by complex-step differentiation of the numpy model, second derivatives by central differences

@@ -22,8 +22,8 @@
 //                                   factorised node by node (block LDL' without pivoting; the lap closure is
 //                                   a border block row carried along); the count of negative pivots
 //                                   (7 N of 16 N) is the inertia test that drives delta
-//                     k_mt_step     fraction-to-the-boundary rule, backtracking against a filter on
-//                                   (infeasibility, barrier objective), update of w, s, y, z, delta
+//                     k_mt_step     fraction-to-the-boundary rule, backtracking on (infeasibility, barrier
+//                                   objective) with a small filter, update of w, s, y, z, delta
 //   One wave per instance in k_mt_kkt (every 16 x 16 block lives in registers, 4 entries per lane, in the
 //   operand layout of v_mfma_f64_16x16x4_f64: the block products run on the matrix cores, the block
 //   inverse on cross-lane moves), one thread per (instance, node, slice) in
