@@ -71,17 +71,62 @@ RL_DT Dual<ND, T> operator/(Dual<ND, T> a, double b) { const double ib = 1.0 / b
 RL_DT Dual<ND, T> operator/(double b, const Dual<ND, T>& a) { Dual<ND, T> r; r.v = b / a.v; const T f = -(r.v / a.v); RL_DUAL_FOR r.d[i_] = f * a.d[i_]; return r; }
 // f(a) with f(a.v) = v and f'(a.v) = dv given in the component type
 RL_DT Dual<ND, T> chain(Dual<ND, T> a, const T& v, const T& dv) { a.v = v; RL_DUAL_FOR a.d[i_] = a.d[i_] * dv; return a; }
-__device__ __forceinline__ double m_sin(double x) { return sin(x); }
-__device__ __forceinline__ double m_cos(double x) { return cos(x); }
+// ---- the model's elementary functions on plain doubles.  The derivative kernels of the min-time solve evaluate
+// them once per direction pair and node (113 times per node and iteration): the library versions (185 / 85
+// instructions for sincos / atan, with a large-argument path that the model's angles never take) were half of those
+// kernels' instructions.  These are the fdlibm kernels (Sun Microsystems' k_sin.c / k_cos.c / s_atan.c coefficients)
+// written branch-free for the wavefront: Cody-Waite reduction with a two-part pi/2 (the model's arguments are angles
+// of a few radians; the absolute error grows like 1e-16 |x|, there is no large-argument path), polynomial on
+// [-pi/4, pi/4], quadrant by select; atan with its four break points as selects and one division.  Accuracy ~1 ulp
+// (the reference's numpy / CasADi values differ from any libm by as much).
+__device__ __forceinline__ void m_sincos(double x, double& s, double& c) {
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, x);
+  r = fma(-k, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double cr = 1.0 - fma(-z * z, pc, 0.5 * z);   // 1 - (z/2 - z^2 pc)
+  const int n = (int)fmin(fmax(k, -1e9), 1e9) & 3;
+  const double ss = (n & 1) ? cr : sr, cc = (n & 1) ? sr : cr;
+  s = (n & 2) ? -ss : ss;
+  c = ((n + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ double m_sin(double x) { double s, c; m_sincos(x, s, c); return s; }
+__device__ __forceinline__ double m_cos(double x) { double s, c; m_sincos(x, s, c); return c; }
 __device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
-__device__ __forceinline__ double m_atan(double x) { return atan(x); }
+__device__ __forceinline__ double m_atan(double x) {
+  const double ax = fabs(x);
+  const bool r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
+  // t = num / den:  x | (2x-1)/(2+x) | (x-1)/(x+1) | (x-1.5)/(1+1.5x) | -1/x
+  const double num = r0 ? ax : (r1 ? 2.0 * ax - 1.0 : (r2 ? ax - 1.0 : (r3 ? ax - 1.5 : -1.0)));
+  const double den = r0 ? 1.0 : (r1 ? 2.0 + ax : (r2 ? ax + 1.0 : (r3 ? fma(1.5, ax, 1.0) : ax)));
+  const double hi = r0 ? 0.0 : (r1 ? 4.63647609000806093515e-01 : (r2 ? 7.85398163397448278999e-01
+                                   : (r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00)));
+  const double lo = r0 ? 0.0 : (r1 ? 2.26987774529616870924e-17 : (r2 ? 3.06161699786838301793e-17
+                                   : (r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17)));
+  const double t = num / den;
+  const double z = t * t, w = z * z;
+  const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02),
+                                                 6.66107313738753120669e-02), 9.09088713343650656196e-02),
+                                   1.42857142725034663711e-01), 3.33333333333329318027e-01);
+  const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02),
+                                          -7.69187620504482999495e-02), -1.11111104054623557880e-01),
+                            -1.99999999998764832476e-01);
+  const double res = hi - ((t * (s1 + s2) - lo) - t);
+  return x < 0.0 ? -res : res;   // a NaN argument falls through every comparison and comes back as NaN
+}
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
 __device__ __forceinline__ double m_fmod(double x, double m) { return fmod(x, m); }
 __device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
 // sine and cosine of a dual number share ONE sincos of the value at every nesting level (the derivative of
 // either needs the other): a nested dual costs one range reduction instead of four
-__device__ __forceinline__ void m_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
 RL_DT void m_sincos(const Dual<ND, T>& x, Dual<ND, T>& s, Dual<ND, T>& c) {
   T sv, cv; m_sincos(x.v, sv, cv); s = chain(x, sv, cv); c = chain(x, cv, -sv);
 }
