@@ -80,6 +80,7 @@ struct rl_ctx {
   static constexpr int kMaxGroups = 4;
   hipStream_t aux_stream[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+  bool mt_hes_sweep = false;     // RL_MT_HES_SWEEP=1: the Hessian by k_mt_derivs<2> instead of the chain-rule kernels
   int mt_groups = 3;             // RL_MT_GROUPS=1..4 (measured at 256 / 1024 instances: 3.66 / 11.55 s, 3.31 / 11.05, 3.14 / 10.53, 3.11 / 10.59)
   // Device staging blocks of the HOST-pointer entry points (PoolBuf): handed out best-fit, returned at the end of
   // the call, freed with the context -- a second call of the same shape allocates nothing.
@@ -317,6 +318,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
   }
   c->num_cu = prop.multiProcessorCount;
   if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
+  if (const char* v = getenv("RL_MT_HES_SWEEP")) c->mt_hes_sweep = v[0] == '1';
   if (const char* v = getenv("RL_MT_GROUPS")) { const int g = atoi(v); if (g >= 1 && g <= rl_ctx::kMaxGroups) c->mt_groups = g; }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
@@ -1075,7 +1077,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   const size_t bn = (size_t)B * N;
   const size_t counts[] = {bn * rl::kMtNv, bn * rl::kMtNi, bn * rl::kMtNe, bn * rl::kMtNi, bn * rl::kMtNf,
                            bn * rl::kMtNf * rl::kMtLoc, bn * rl::kMtLoc * rl::kMtLoc, bn * rl::kMtNv, bn * rl::kMtNe,
-                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16, (size_t)B * 2 * rl::kMtFilter};
+                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16, (size_t)B * 2 * rl::kMtFilter, bn * rl::kMtHw};
   size_t total = 0;
   for (size_t c : counts) total += Arena::pad(c * sizeof(double));
   Arena ar(ctx);
@@ -1087,7 +1089,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.hes = ar.take<double>(counts[6]); st.dw = ar.take<double>(counts[7]); st.dy = ar.take<double>(counts[8]);
   st.blk = ar.take<double>(counts[9]); st.vec = ar.take<double>(counts[10]); st.scal = ar.take<double>(counts[11]);
   st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
-  st.filt = ar.take<double>(counts[15]);
+  st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]);
   st.tol = tol;
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
   RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
@@ -1118,7 +1120,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     G.st.w = st.w + o * rl::kMtNv; G.st.s = st.s + o * rl::kMtNi; G.st.y = st.y + o * rl::kMtNe; G.st.z = st.z + o * rl::kMtNi;
     G.st.fun = st.fun + o * rl::kMtNf; G.st.jac = st.jac + o * rl::kMtNf * rl::kMtLoc; G.st.hes = st.hes + o * rl::kMtLoc * rl::kMtLoc;
     G.st.dw = st.dw + o * rl::kMtNv; G.st.dy = st.dy + o * rl::kMtNe; G.st.blk = st.blk + o * 3 * 256; G.st.vec = st.vec + o * 16;
-    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.filt = st.filt + (size_t)G.b0 * 2 * rl::kMtFilter; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16;
+    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.filt = st.filt + (size_t)G.b0 * 2 * rl::kMtFilter; G.st.hw = st.hw + o * rl::kMtHw; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16;
     G.X = X + o * 6; G.U = U + o * 4; G.T = T + o; G.stats = stats + (size_t)G.b0 * 12;
   }
   if (ngrp > 1) {   // fork: the other streams start after everything already enqueued on the first
@@ -1149,7 +1151,15 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       const dim3 gn((N + 63) / 64, G.nb);
       hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, G.nb, rl::kMtJacSlices), bn64, 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, G.nb, rl::kMtHesSlices), bn64, 0, G.q, G.P, G.st);
+      if (ctx->mt_hes_sweep) {   // cross-check: forward over forward through the whole pair function
+        hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, G.nb, rl::kMtHesSlices), bn64, 0, G.q, G.P, G.st);
+      } else {
+        hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3((N + 63) / 64, G.nb, rl::kMtPairs8), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_jac, dim3((N + 63) / 64, G.nb, 16), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_point<1>, dim3((N + 63) / 64, G.nb, 2 * rl::kMtPairs8), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
+      }
       hipLaunchKernelGGL(rl::k_mt_prepare, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);

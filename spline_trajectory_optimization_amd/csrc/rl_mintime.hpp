@@ -189,6 +189,7 @@ struct MtState {       // per-batch device arrays, instance-major
   double* dblk;   // [B,N,256] assembled diagonal blocks D_j (without delta)
   double* eblk;   // [B,N,256] assembled coupling blocks E_j = M[j+1][j]
   double* rhs;    // [B,N,16]  assembled right-hand sides
+  double* hw;     // [B,N,kMtHw] work array of the chain-rule Hessian (k_mt_hes_*)
   double* filt;   // [B,16] filter: (infeasibility, barrier objective) of up to 8 earlier iterates of the current barrier problem
   double* scal;   // [B,16] per-instance scalars: 0 mu, 1 delta, 2 kkt, 3 viol, 4 compl, 5 status (0 run, 1 converged,
                   //        2 failed), 6 iterations, 7 last alpha, 8 theta0, 9 phi0, 10 refactorisations, 11 lap time
@@ -304,6 +305,258 @@ __global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
         const int va = NA * ga + ia, vb = NB * gb + ib;
         if (va <= vb) { H[vb * kMtLoc + va] = h[ib][ia]; H[va * kMtLoc + vb] = h[ib][ia]; }
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hessian of the pair Lagrangian by the CHAIN RULE through the Hermite-Simpson midpoint (the default; the
+// forward-over-forward sweep over the whole pair function, k_mt_derivs<2>, stays as the cross-check).
+//
+// With Y = (n, xi, omega, beta, v), U = (F, delta, gamma), f = the dynamics (6 rows), F = its rows 1..5,
+// yh = y * se (the defect multipliers), the only rows with curvature are
+//     L = (t/6) yh.f(Y,U) + (t/6) yh.f(Y',U) + (2t/3) yh.f(Ym,U) + own(Y,U) + rate(F,F',delta,delta',t),
+//     Ym = (Y + Y')/2 + (t/8) (F(Y,U) - F(Y',U)),
+// own = load-transfer row, four tyre ellipses, power row.  Every dynamics evaluation is differentiated on its own
+// 8 variables (36 pairs of directions instead of 105 of the 14 that the pair function depends on, one dynamics
+// evaluation per pair instead of three):
+//   values   f(Y,U), f(Y',U) -> Ym, F1 - F2                                               k_mt_hes_values
+//   middle   gradient gm and Hessian Hm of phi = yh.f at (Ym,U)                            k_mt_hes_point<0>
+//   ends     Jacobians J1, J2 of f at (Y,U), (Y',U)                                         k_mt_hes_jac
+//            Hessians H1, H2 of  (t/6) yh.f +- (t^2/12) gm_Y.F (+ own at the first point)   k_mt_hes_point<1>
+//   assembly H = H1 (+) H2 + (2t/3) M' Hm M + the products with t + the rate rows, scaled   k_mt_hes_assemble
+// with M = d(Ym,U)/d(Y,U,t,Y').  3.1 times fewer instructions than the sweep, and fewer live values per thread.
+constexpr int kMtPv = 8, kMtPairs8 = 36;
+constexpr int kMtHwXm = 0, kMtHwDf = 5, kMtHwGm = 10, kMtHwHm = 18, kMtHwJ1 = 54, kMtHwJ2 = 102, kMtHwH1 = 150, kMtHwH2 = 186,
+              kMtHw = 222;
+
+__device__ __forceinline__ void mt_pair8(int q, int& a, int& b) {   // q-th pair a <= b of 8
+  a = 0;
+  while (q >= kMtPv - a) { q -= kMtPv - a; ++a; }
+  b = a + q;
+}
+__device__ __forceinline__ int mt_tri8(int a, int b) {               // inverse, any order
+  const int lo = a < b ? a : b, hi = a < b ? b : a;
+  return lo * kMtPv - lo * (lo - 1) / 2 + (hi - lo);
+}
+
+// physical unknowns of the pair; the next state is brought next to this one (utils/utils.py:10-18: locally the identity)
+__device__ __forceinline__ void mt_phys(const MtProblem& P, const double* wo, const double* wn, double (&Y)[5], double (&Yn)[5],
+                                        double (&U)[3], double& t) {
+#pragma unroll
+  for (int c = 0; c < 5; ++c) { Y[c] = wo[c] * P.sw[c]; Yn[c] = wn[c] * P.sw[c]; }
+  U[0] = wo[5] * P.sw[5]; U[1] = wo[6] * P.sw[6]; U[2] = wo[7] * P.sw[7];
+  t = wo[8] * P.sw[8];
+  const double d = Yn[1] - Y[1];
+  double sd, cd;
+  m_sincos(d, sd, cd);
+  Yn[1] = m_atan2(sd, cd) + Y[1];
+}
+
+template <typename S>
+__device__ __forceinline__ void mt_dyn(const MtProblem& P, int j, const S (&Y)[5], const S (&U)[3], S (&f)[6], DtTyres<S>& ty) {
+  S x[6], u[4];
+  x[0] = MtLift<S>::make(P.s[j]);
+#pragma unroll
+  for (int c = 0; c < 5; ++c) x[1 + c] = Y[c];
+  u[0] = U[0]; u[1] = MtLift<S>::make(0.0); u[2] = U[1]; u[3] = U[2];
+  dt_dynamics(P.p, x, u, P.kappa[j], f, ty);
+}
+
+// the rows of this node that are curved and depend on (Y, U) only, weighted with their multipliers
+template <typename S>
+__device__ __forceinline__ S mt_own_rows(const MtProblem& P, const S (&Y)[5], const S (&U)[3], const DtTyres<S>& ty,
+                                         const double* y, const double* z) {
+  const double* p = P.p;
+  S sd, cd_;
+  m_sincos(U[1], sd, cd_);
+  S L = (U[2] - p[DT_HCOG] / (0.5 * (p[DT_TWF] + p[DT_TWR])) *
+                    (ty.fy[2] + ty.fy[3] + (ty.fx[0] + ty.fx[1]) * sd + (ty.fy[0] + ty.fy[1]) * cd_)) * (P.se[6] * y[6]);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const S qx = ty.fx[w] / (p[DT_MU] * ty.fz[w]), qy = ty.fy[w] / (p[DT_MU] * ty.fz[w]);
+    L = L + (qx * qx + qy * qy - 1.0) * z[w];
+  }
+  const S fd = U[0] * (m_tanh(U[0]) * 0.5 + 0.5);
+  L = L + ((Y[4] * fd - p[DT_PMAX]) / p[DT_PMAX]) * z[4];
+  return L;
+}
+
+// grid (node blocks, B): values of the two end evaluations -> midpoint and F1 - F2
+__global__ void __launch_bounds__(64) k_mt_hes_values(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
+  if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  const int jn = j + 1 == N ? 0 : j + 1;
+  double Y[5], Yn[5], U[3], t;
+  mt_phys(P, st.w + ((size_t)b * N + j) * kMtNv, st.w + ((size_t)b * N + jn) * kMtNv, Y, Yn, U, t);
+  double f1[6], f2[6];
+  {
+    DtTyres<double> ty;
+    mt_dyn<double>(P, j, Y, U, f1, ty);
+    mt_dyn<double>(P, j, Yn, U, f2, ty);
+  }
+  double* hw = st.hw + ((size_t)b * N + j) * kMtHw;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const double df = f1[1 + c] - f2[1 + c];
+    hw[kMtHwXm + c] = 0.5 * (Y[c] + Yn[c]) + (t / 8.0) * df;
+    hw[kMtHwDf + c] = df;
+  }
+}
+
+// grid (node blocks, B, 16): Jacobians of f at the two ends, one direction per thread
+__global__ void __launch_bounds__(64) k_mt_hes_jac(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
+  const int pt = blockIdx.z >> 3, d = blockIdx.z & 7;
+  if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  const int jn = j + 1 == N ? 0 : j + 1;
+  double Y[5], Yn[5], U[3], t;
+  mt_phys(P, st.w + ((size_t)b * N + j) * kMtNv, st.w + ((size_t)b * N + jn) * kMtNv, Y, Yn, U, t);
+  using D = Dual<1>;
+  D Yd[5], Ud[3], f[6];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) { Yd[c].v = pt ? Yn[c] : Y[c]; Yd[c].d[0] = d == c ? 1.0 : 0.0; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { Ud[c].v = U[c]; Ud[c].d[0] = d == 5 + c ? 1.0 : 0.0; }
+  DtTyres<D> ty;
+  mt_dyn<D>(P, j, Yd, Ud, f, ty);
+  double* J = st.hw + ((size_t)b * N + j) * kMtHw + (pt ? kMtHwJ2 : kMtHwJ1);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) J[c * kMtPv + d] = f[c].d[0];
+}
+
+// grid (node blocks, B, 36 [MID] or 72 [ENDS]): one pair of directions of one dynamics evaluation per thread
+template <int ENDS>
+__global__ void __launch_bounds__(64) k_mt_hes_point(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
+  const int pt = ENDS ? (int)blockIdx.z / kMtPairs8 : 0, q = ENDS ? (int)blockIdx.z % kMtPairs8 : (int)blockIdx.z;
+  if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  const int jn = j + 1 == N ? 0 : j + 1;
+  const size_t o = (size_t)b * N + j;
+  double Y[5], Yn[5], U[3], t;
+  mt_phys(P, st.w + o * kMtNv, st.w + ((size_t)b * N + jn) * kMtNv, Y, Yn, U, t);
+  double* hw = st.hw + o * kMtHw;
+  int a, bb;
+  mt_pair8(q, a, bb);
+  using D2 = Dual<1, Dual<1>>;
+  D2 Yd[5], Ud[3], f[6];
+  auto seed = [&](D2& r, double val, int var) {
+    r.v.v = val; r.v.d[0] = var == a ? 1.0 : 0.0; r.d[0].v = var == bb ? 1.0 : 0.0; r.d[0].d[0] = 0.0;
+  };
+#pragma unroll
+  for (int c = 0; c < 5; ++c) seed(Yd[c], ENDS ? (pt ? Yn[c] : Y[c]) : hw[kMtHwXm + c], c);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) seed(Ud[c], U[c], 5 + c);
+  const double* y = st.y + o * kMtNe;
+  DtTyres<D2> ty;
+  mt_dyn<D2>(P, j, Yd, Ud, f, ty);
+  D2 L = f[0] * (y[0] * P.se[0] * (ENDS ? t / 6.0 : 1.0));
+#pragma unroll
+  for (int c = 1; c < 6; ++c) {
+    double m = y[c] * P.se[c];
+    if (ENDS) m = m * (t / 6.0) + (pt ? -1.0 : 1.0) * (t * t / 12.0) * hw[kMtHwGm + c - 1];
+    L = L + f[c] * m;
+  }
+  if (ENDS) {
+    if (pt == 0) L = L + mt_own_rows<D2>(P, Yd, Ud, ty, y, st.z + o * kMtNi);
+    hw[(pt ? kMtHwH2 : kMtHwH1) + q] = L.d[0].d[0];
+  } else {
+    hw[kMtHwHm + q] = L.d[0].d[0];
+    if (a == bb) hw[kMtHwGm + a] = L.v.d[0];
+  }
+}
+
+// grid (N, B), one wave per node: the 18 x 18 Hessian of the scaled unknowns from the pieces
+__global__ void __launch_bounds__(64) k_mt_hes_assemble(MtProblem P, MtState st) {
+  __shared__ double M[kMtPv][14], T[kMtPv][14], Hm[kMtPv][kMtPv], g[kMtPv], gpsi[14], gphi[2][kMtPv], gF[2][kMtPv];
+  const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, N = P.N;
+  if (st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  const int jn = j + 1 == N ? 0 : j + 1;
+  const size_t o = (size_t)b * N + j;
+  const double* wo = st.w + o * kMtNv;
+  const double* wn = st.w + ((size_t)b * N + jn) * kMtNv;
+  const double* hw = st.hw + o * kMtHw;
+  const double* y = st.y + o * kMtNe;
+  const double* z = st.z + o * kMtNi;
+  const double t = wo[8] * P.sw[8];
+  const double* J1 = hw + kMtHwJ1;
+  const double* J2 = hw + kMtHwJ2;
+  // z = (Y 0..4, U 5..7, t 8, Y' 9..13); variables of the second end evaluation: Y' then U
+  auto map2 = [](int zi) { return zi >= 9 ? zi - 9 : (zi >= 5 && zi < 8 ? zi : -1); };
+  if (lane < kMtPv) g[lane] = hw[kMtHwGm + lane];
+  {
+    const int a = lane >> 3, c = lane & 7;
+    Hm[a][c] = hw[kMtHwHm + mt_tri8(a, c)];
+  }
+  if (lane < 2 * kMtPv) {   // gradients of yh.f and of gm_Y.F at the two ends
+    const int pt = lane >> 3, a = lane & 7;
+    const double* J = pt ? J2 : J1;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s1 += y[c] * P.se[c] * J[c * kMtPv + a];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) s2 += hw[kMtHwGm + r] * J[(1 + r) * kMtPv + a];
+    gphi[pt][a] = s1; gF[pt][a] = s2;
+  }
+  for (int e = lane; e < kMtPv * 14; e += 64) {   // M = d(Ym, U) / d(Y, U, t, Y')
+    const int r = e / 14, zi = e - 14 * r;
+    double v = 0.0;
+    if (r < 5) {
+      if (zi < 5) v = (zi == r ? 0.5 : 0.0) + (t / 8.0) * J1[(1 + r) * kMtPv + zi];
+      else if (zi < 8) v = (t / 8.0) * (J1[(1 + r) * kMtPv + zi] - J2[(1 + r) * kMtPv + zi]);
+      else if (zi == 8) v = hw[kMtHwDf + r] / 8.0;
+      else v = (zi - 9 == r ? 0.5 : 0.0) - (t / 8.0) * J2[(1 + r) * kMtPv + (zi - 9)];
+    } else {
+      v = zi == r ? 1.0 : 0.0;   // U rows: z indices 5..7
+    }
+    M[r][zi] = v;
+  }
+  __syncthreads();
+  for (int e = lane; e < kMtPv * 14; e += 64) {   // T = Hm M
+    const int r = e / 14, zi = e - 14 * r;
+    double v = 0.0;
+#pragma unroll
+    for (int p = 0; p < kMtPv; ++p) v += Hm[r][p] * M[p][zi];
+    T[r][zi] = v;
+  }
+  if (lane < 14) {
+    double v = 0.0;
+#pragma unroll
+    for (int p = 0; p < kMtPv; ++p) v += M[p][lane] * g[p];
+    gpsi[lane] = v;
+  }
+  __syncthreads();
+  const double su0 = P.sw[5], su2 = P.sw[6];
+  const double k1 = (z[11] - z[10]) / su0, k2 = (z[13] - z[12]) / su2;   // rate rows: k (u' - u) / t
+  const double dF = (wn[5] - wo[5]) * P.sw[5], dD = (wn[6] - wo[6]) * P.sw[6];
+  double* H = st.hes + o * kMtLoc * kMtLoc;
+  for (int e = lane; e < kMtLoc * kMtLoc; e += 64) {
+    const int la = e / kMtLoc, lb = e - kMtLoc * la;
+    double v = 0.0;
+    if (la < 14 && lb < 14) {
+      double s = 0.0;
+#pragma unroll
+      for (int p = 0; p < kMtPv; ++p) s += M[p][la] * T[p][lb];
+      v = (2.0 * t / 3.0) * s;
+      if (la < 8 && lb < 8) v += hw[kMtHwH1 + mt_tri8(la, lb)];
+      const int a2 = map2(la), b2 = map2(lb);
+      if (a2 >= 0 && b2 >= 0) v += hw[kMtHwH2 + mt_tri8(a2, b2)];
+      if ((la == 8) != (lb == 8)) {   // products with t
+        const int oth = la == 8 ? lb : la, o2 = map2(oth);
+        v += (2.0 / 3.0) * gpsi[oth];
+        if (oth < 8) v += gphi[0][oth] / 6.0 + (t / 12.0) * gF[0][oth];
+        if (o2 >= 0) v += gphi[1][o2] / 6.0 - (t / 12.0) * gF[1][o2];
+      } else if (la == 8 && lb == 8) {
+        v += (4.0 / 3.0) * gpsi[8];
+      }
+    }
+    // rate rows k1 (F' - F) / t + k2 (delta' - delta) / t: F 5, delta 6, t 8, F' 14, delta' 15
+    const int lo = la < lb ? la : lb, hi = la < lb ? lb : la;
+    if (lo == 8 && hi == 8) v += 2.0 * (k1 * dF + k2 * dD) / (t * t * t);
+    else if (lo == 5 && hi == 8) v += k1 / (t * t);
+    else if (lo == 6 && hi == 8) v += k2 / (t * t);
+    else if (lo == 8 && hi == 14) v -= k1 / (t * t);
+    else if (lo == 8 && hi == 15) v -= k2 / (t * t);
+    H[e] = v * P.sw[la % kMtNv] * P.sw[lb % kMtNv];
   }
 }
 

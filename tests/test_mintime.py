@@ -102,6 +102,31 @@ def test_mintime_solve_vs_twin(coarse):
 
 
 @pytest.mark.gpu
+def test_hessian_chain_rule_vs_forward_over_forward_sweep(tmp_path):
+    """The two Hessian implementations of the library -- the chain rule through the Hermite-Simpson midpoint
+    (k_mt_hes_*, default) and forward-over-forward duals through the whole pair function (k_mt_derivs<2>,
+    RL_MT_HES_SWEEP=1) -- drive the same iteration: after 12 iterations from the QSS warm start the iterates agree
+    to rounding.  (Each library instance reads the switch when its context is created: two processes.)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = {}
+    for mode in ("0", "1"):
+        f = str(tmp_path / f"it_{mode}.npz")
+        env = dict(os.environ, RL_MT_HES_SWEEP=mode)
+        subprocess.run([sys.executable, os.path.join(here, "mintime_run.py"), f, "12"], check=True, env=env, timeout=300)
+        out[mode] = np.load(f)
+    a, b = out["0"], out["1"]
+    assert a["st"][0, 0] == b["st"][0, 0] == 12.0
+    su = np.maximum(np.abs(b["U"]).max(axis=(0, 1)), 1.0)      # controls in their own scale (u[1] is identically zero)
+    dev = max(np.abs(a["X"] - b["X"]).max(), np.abs(a["T"] - b["T"]).max(), np.abs((a["U"] - b["U"]) / su).max())
+    print(f"chain rule vs sweep after 12 iterations: max deviation {dev:.2e}, kkt {a['st'][0, 1]:.6e} / {b['st'][0, 1]:.6e}")
+    assert dev <= 1e-8, dev
+    assert a["st"][0, 1] == pytest.approx(b["st"][0, 1], rel=1e-6)
+
+
+@pytest.mark.gpu
 def test_mintime_batch_with_per_instance_widths(coarse):
     """A batch of tracks that differ in their widths (BASELINE config 2's perturbation applied to config 5):
     instances are independent (a duplicate agrees bit for bit, instance 0 equals the single solve), wider tracks
