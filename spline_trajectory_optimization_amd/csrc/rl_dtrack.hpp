@@ -2,7 +2,7 @@
 // the model's FUNCTION EVALUATION for B candidate solutions x N nodes -- vehicle dynamics in the
 // curvilinear (Frenet) frame, Hermite-Simpson defects, tyre friction ellipses, load-transfer
 // residual, actuator constraints and the objective -- i.e. what an NLP/SQP solver calls at every
-// iterate.  The solve itself (batched SQP with a block-banded KKT) is not built yet.
+// iterate.  The solve built on it: rl_mintime.hpp.
 //
 // Restates models/double_track.py:10-140 (dynamics: the double-track model of
 // doi:10.1080/00423114.2019.1704804 with the reference's simplified Pacejka curve, tanh-blended

@@ -14,8 +14,9 @@
 //   17 inequalities tyre ellipses (4), power, v >= 1, force / steer limits, force / steer RATE limits
 //       (two rows each), lateral limits, t >= 0                                   g_j(w_j, w_j+1) + s_j = 0, s_j > 0
 //
-//   every iteration:  k_mt_derivs   functions, Jacobians (forward duals) and the EXACT Hessian of the pair
-//                                   Lagrangians (forward over forward duals) through the templated model code
+//   every iteration:  k_mt_derivs   functions and Jacobians (forward duals) through the templated model code
+//                     k_mt_hes_*    the EXACT Hessian of the pair Lagrangians: forward over forward duals on each
+//                                   dynamics evaluation, chain rule through the Hermite-Simpson midpoint
 //                     k_mt_kkt      the barrier QP  [K  A'; A  -eps I] [dw; dy] = rhs  with
 //                                   K = H_cost + Hess + G' S^-1 Z G + delta I: block tridiagonal and CYCLIC
 //                                   (closed lap), 16 x 16 blocks (9 unknowns + 7 multipliers per node),
