@@ -194,6 +194,20 @@ def global_qp_leg(trk, d_widths, g, args, torch, with_cpu):
     return leg
 
 
+def mintime_leg(B):
+    """Third leg (BASELINE configs[4]): the reference's min-time example (MGKT kart circuit, 828 nodes) as a
+    batch of width-perturbed tracks through rl_mintime_solve_batch -- QSS warm start, then the interior-point SQP-type
+    iteration to KKT 1e-6.  Timed on the host around ONE call (copies included), outside the headline's region.  The
+    reference solves this NLP with IPOPT (absent here): there is no CPU number to put beside it."""
+    try:
+        from spline_trajectory_optimization_amd.min_time_optm.example import timed_batch_solve
+        leg = timed_batch_solve(B)
+        leg["solver_pinned_by"] = "CPU twin oracle/sqp_twin.py (tests/test_mintime.py); NLP functions by fixture G8"
+        return leg
+    except Exception as e:   # the headline must not depend on this leg
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def valu_block(prof, kernel_ms):
     """FP64 VALU view of a kernel from the committed counters + this run's kernel time.
       valu_active_frac = SQ_ACTIVE_INST_VALU [quad-cycles] x 4 / (1024 SIMDs x kernel cycles), kernel cycles =
@@ -409,6 +423,8 @@ def run_rank(args):
         if world == 1 and args.workload == "monza" and not args.no_global:
             res["global_qp"] = global_qp_leg(groups[0]["trk"], groups[0]["d_widths"], groups[0], args, torch,
                                              with_cpu=not args.no_cpu_baseline)
+        if world == 1 and args.workload == "monza" and not args.no_mintime:
+            res["mintime_nlp"] = mintime_leg(args.mintime_batch)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
         print(json.dumps(res), flush=True)
@@ -427,6 +443,8 @@ def main():
     ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-global", action="store_true", help="skip the global-QP leg")
+    ap.add_argument("--no-mintime", action="store_true", help="skip the min-time NLP leg")
+    ap.add_argument("--mintime-batch", type=int, default=1024)
     ap.add_argument("--cpu-instances", type=int, default=8)
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST HOOK: all ranks use cuda:0 and the gloo backend (exercises the N>1 code path "

@@ -1,0 +1,56 @@
+"""The reference's example problem of the min-time optimiser (min_time_optm/example/: the MGKT kart circuit with
+the yaml's model and estimates, entrypoints/traj_opt_double_track.py:24-86) as a BATCH of width-perturbed tracks --
+BASELINE config 2's perturbation applied to config 5.  Used by bench.py's `mintime_nlp` leg and tools/bench_mintime.py."""
+import os
+import time
+
+import numpy as np
+
+from . import defaults
+from .min_time_optimizer import DoubleTrackProblem
+from ..models.race_track import RaceTrack
+from ..models.vehicle import Vehicle, VehicleParams
+from ..simulator.simulator import Simulator
+
+MGKT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "race_track", "mgkt")
+
+
+def load_mgkt(name):
+    return np.loadtxt(os.path.join(MGKT_DIR, name), delimiter=",", skiprows=1, usecols=(0, 1))
+
+
+def mgkt_problem(interval=1.0):
+    """RaceTrack + QSS warm start (on the GPU) + the NLP of the example at the yaml's node spacing."""
+    est = defaults.ESTIMATES
+    rt = RaceTrack("MGKT", load_mgkt("MGKT_OUT_BOUND_enu.csv"), load_mgkt("MGKT_IN_BOUND_enu.csv"),
+                   load_mgkt("MGKT_CENTER_enu.csv"), s=1.0, interval=interval)
+    veh = Vehicle(VehicleParams(np.array(est["acc_speed_loopup"]), np.array(est["dcc_speed_lookup"]), est["max_lon_acc_mpss"],
+                                est["max_lon_dcc_mpss"], est["max_left_acc_mpss"], est["max_right_acc_mpss"],
+                                est["max_speed_mps"], est["max_jerk_mpsc"]))
+    traj = rt.center_d.copy()
+    rt.fill_trajectory_boundaries(traj)
+    traj = Simulator(veh).run_simulation(traj, False).trajectory
+    return DoubleTrackProblem({"N": len(traj), "model": defaults.MODEL, "race_track": rt, "traj_d": traj,
+                               "average_track_width": 7.0, "speed_cap": 30.0})
+
+
+def perturbed_widths(prob, B, seed=1234):
+    """[B, N] left / right distances: every track scaled by its own factor in [0.9, 1.15)."""
+    e = np.random.default_rng(seed).uniform(-0.1, 0.15, size=(B, 1))
+    return prob.left[None] * (1 + e), prob.right[None] * (1 + e)
+
+
+def timed_batch_solve(B, max_iter=300, tol=1e-6):
+    """One call of the batched solve, timed on the host (copies of the initial guess and of the solution included)."""
+    prob = mgkt_problem()
+    left, right = perturbed_widths(prob, B)
+    prob.solve_batch(left[:2], right[:2], max_iter=8)          # warm-up (module load)
+    t0 = time.perf_counter()
+    X, U, T, st = prob.solve_batch(left, right, max_iter=max_iter, tol=tol)
+    dt = time.perf_counter() - t0
+    return {"metric": "min-time double-track NLP solves/sec (MGKT, N=%d nodes, 9 unknowns + 7 equalities + 17 inequalities "
+                      "per node)" % prob.N, "value": B / dt, "unit": "NLP solves/s", "batch": B, "wall_s": dt,
+            "converged": int((st[:, 5] == 1).sum()), "iterations_mean": float(st[:, 0].mean()),
+            "iterations_max": float(st[:, 0].max()), "kkt_max": float(st[:, 1].max()), "viol_max": float(st[:, 2].max()),
+            "lap_s_min_max": [float(st[:, 4].min()), float(st[:, 4].max())], "tol": tol,
+            "includes": "host->device copies of the initial guess and device->host of the solution"}

@@ -1,41 +1,12 @@
 #!/usr/bin/env python3
 """Throughput of the batched min-time solve (BASELINE config 5): B width-perturbed copies of the reference's
-example track (MGKT, interval 1 m, N = 828 nodes), one call.  Prints one JSON line."""
+example track (MGKT, interval 1 m, N = 828 nodes), one call.  Prints one JSON line.   python tools/bench_mintime.py [B]"""
 import json
 import os
 import sys
-import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from spline_trajectory_optimization_amd.min_time_optm import defaults  # noqa: E402
-from spline_trajectory_optimization_amd.min_time_optm.min_time_optimizer import DoubleTrackProblem  # noqa: E402
-from spline_trajectory_optimization_amd.models.race_track import RaceTrack  # noqa: E402
-from spline_trajectory_optimization_amd.models.vehicle import Vehicle, VehicleParams  # noqa: E402
-from spline_trajectory_optimization_amd.simulator.simulator import Simulator  # noqa: E402
-from mintime_problem import _load  # noqa: E402
+sys.path.insert(0, ROOT)
+from spline_trajectory_optimization_amd.min_time_optm.example import timed_batch_solve  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-est = defaults.ESTIMATES
-rt = RaceTrack("MGKT", _load("MGKT_OUT_BOUND_enu.csv"), _load("MGKT_IN_BOUND_enu.csv"), _load("MGKT_CENTER_enu.csv"), s=1.0, interval=1.0)
-veh = Vehicle(VehicleParams(np.array(est["acc_speed_loopup"]), np.array(est["dcc_speed_lookup"]), est["max_lon_acc_mpss"],
-                            est["max_lon_dcc_mpss"], est["max_left_acc_mpss"], est["max_right_acc_mpss"], est["max_speed_mps"],
-                            est["max_jerk_mpsc"]))
-traj = rt.center_d.copy(); rt.fill_trajectory_boundaries(traj)
-traj = Simulator(veh).run_simulation(traj, False).trajectory
-prob = DoubleTrackProblem({"N": len(traj), "model": defaults.MODEL, "race_track": rt, "traj_d": traj,
-                           "average_track_width": 7.0, "speed_cap": 30.0})
-e = np.random.default_rng(1234).uniform(-0.1, 0.15, size=(B, 1))
-left, right = prob.left[None] * (1 + e), prob.right[None] * (1 + e)
-prob.solve_batch(left[:2], right[:2], max_iter=8)          # warm-up (module load)
-t0 = time.perf_counter()
-X, U, T, st = prob.solve_batch(left, right, max_iter=300, tol=1e-6)
-dt = time.perf_counter() - t0
-print(json.dumps({"metric": "min-time double-track NLP solves/sec (MGKT, N=828 nodes, 9 unknowns + 7 equalities + 17 "
-                            "inequalities per node)", "value": B / dt, "unit": "NLP solves/s", "batch": B, "wall_s": dt,
-                  "converged": int((st[:, 5] == 1).sum()), "iterations_mean": float(st[:, 0].mean()),
-                  "iterations_max": float(st[:, 0].max()), "kkt_max": float(st[:, 1].max()), "viol_max": float(st[:, 2].max()),
-                  "lap_s_min_max": [float(st[:, 4].min()), float(st[:, 4].max())],
-                  "includes": "host->device copies of the initial guess and device->host of the solution"}))
+print(json.dumps(timed_batch_solve(int(sys.argv[1]) if len(sys.argv) > 1 else 256)))
