@@ -1150,13 +1150,14 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       const Grp& G = grp[g];
       const dim3 gn((N + 63) / 64, G.nb);
       hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, G.nb, rl::kMtJacSlices), bn64, 0, G.q, G.P, G.st);
-      if (ctx->mt_hes_sweep) {   // cross-check: forward over forward through the whole pair function
+      if (ctx->mt_hes_sweep) {   // cross-check: forward (over forward) duals through the whole pair function
+        hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, G.nb, rl::kMtJacSlices), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, G.nb, rl::kMtHesSlices), bn64, 0, G.q, G.P, G.st);
       } else {
         hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + 63) / 64, G.nb, 24), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3((N + 63) / 64, G.nb, rl::kMtPairs8), bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_hes_jac, dim3((N + 63) / 64, G.nb, 16), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_hes_point<1>, dim3((N + 63) / 64, G.nb, 2 * rl::kMtPairs8), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_hes_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
       }
@@ -1180,7 +1181,13 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     const Grp& G = grp[g];
     const dim3 gn((N + 63) / 64, G.nb);
     hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, G.q, G.P, G.st);
-    hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, G.nb, rl::kMtJacSlices), bn64, 0, G.q, G.P, G.st);
+    if (ctx->mt_hes_sweep) {
+      hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, G.nb, rl::kMtJacSlices), bn64, 0, G.q, G.P, G.st);
+    } else {
+      hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + 63) / 64, G.nb, 24), bn64, 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
+    }
     hipLaunchKernelGGL(rl::k_mt_residuals, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
     hipLaunchKernelGGL(rl::k_mt_unpack, gn, bn64, 0, G.q, G.P, G.st, G.X, G.U, G.T);
     hipLaunchKernelGGL(rl::k_mt_stats, dim3((G.nb + 63) / 64), bn64, 0, G.q, G.st, G.stats);

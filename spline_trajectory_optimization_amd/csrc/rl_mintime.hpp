@@ -322,13 +322,14 @@ __global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
 // evaluation per pair instead of three):
 //   values   f(Y,U), f(Y',U) -> Ym, F1 - F2                                               k_mt_hes_values
 //   middle   gradient gm and Hessian Hm of phi = yh.f at (Ym,U)                            k_mt_hes_point<0>
-//   ends     Jacobians J1, J2 of f at (Y,U), (Y',U)                                         k_mt_hes_jac
+//   ends     Jacobians J1, J2 of f at (Y,U), (Y',U) (and Jm at the midpoint: the Jacobian    k_mt_jac_dirs
+//            of the pair rows is assembled from the three by the same chain rule)            k_mt_jac_assemble
 //            Hessians H1, H2 of  (t/6) yh.f +- (t^2/12) gm_Y.F (+ own at the first point)   k_mt_hes_point<1>
 //   assembly H = H1 (+) H2 + (2t/3) M' Hm M + the products with t + the rate rows, scaled   k_mt_hes_assemble
 // with M = d(Ym,U)/d(Y,U,t,Y').  3.1 times fewer instructions than the sweep, and fewer live values per thread.
 constexpr int kMtPv = 8, kMtPairs8 = 36;
 constexpr int kMtHwXm = 0, kMtHwDf = 5, kMtHwGm = 10, kMtHwHm = 18, kMtHwJ1 = 54, kMtHwJ2 = 102, kMtHwH1 = 150, kMtHwH2 = 186,
-              kMtHw = 222;
+              kMtHwJm = 222, kMtHwOw = 270, kMtHwF = 318, kMtHw = 336;   // Jm [6][8], own-row gradients [6][8], f1 f2 fm [3][6]
 
 __device__ __forceinline__ void mt_pair8(int q, int& a, int& b) {   // q-th pair a <= b of 8
   a = 0;
@@ -402,27 +403,139 @@ __global__ void __launch_bounds__(64) k_mt_hes_values(MtProblem P, MtState st) {
     hw[kMtHwXm + c] = 0.5 * (Y[c] + Yn[c]) + (t / 8.0) * df;
     hw[kMtHwDf + c] = df;
   }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { hw[kMtHwF + c] = f1[c]; hw[kMtHwF + 6 + c] = f2[c]; }
 }
 
-// grid (node blocks, B, 16): Jacobians of f at the two ends, one direction per thread
-__global__ void __launch_bounds__(64) k_mt_hes_jac(MtProblem P, MtState st) {
+// the curved rows of this node that depend on (Y, U) only, one by one (row order: eq 6, g 0..3, g 4)
+template <typename S>
+__device__ __forceinline__ void mt_own_rows_each(const MtProblem& P, const S (&Y)[5], const S (&U)[3], const DtTyres<S>& ty,
+                                                 S (&r)[6]) {
+  const double* p = P.p;
+  S sd, cd_;
+  m_sincos(U[1], sd, cd_);
+  r[0] = (U[2] - p[DT_HCOG] / (0.5 * (p[DT_TWF] + p[DT_TWR])) *
+                     (ty.fy[2] + ty.fy[3] + (ty.fx[0] + ty.fx[1]) * sd + (ty.fy[0] + ty.fy[1]) * cd_)) * P.se[6];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const S qx = ty.fx[w] / (p[DT_MU] * ty.fz[w]), qy = ty.fy[w] / (p[DT_MU] * ty.fz[w]);
+    r[1 + w] = qx * qx + qy * qy - 1.0;
+  }
+  const S fd = U[0] * (m_tanh(U[0]) * 0.5 + 0.5);
+  r[5] = (Y[4] * fd - p[DT_PMAX]) / p[DT_PMAX];
+}
+
+// grid (node blocks, B, 24): Jacobians of f at the two ends and at the midpoint, one direction per thread; the
+// first end also differentiates its own curved rows, the midpoint leaves the value of f there
+__global__ void __launch_bounds__(64) k_mt_jac_dirs(MtProblem P, MtState st) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
   const int pt = blockIdx.z >> 3, d = blockIdx.z & 7;
   if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
   const int jn = j + 1 == N ? 0 : j + 1;
   double Y[5], Yn[5], U[3], t;
   mt_phys(P, st.w + ((size_t)b * N + j) * kMtNv, st.w + ((size_t)b * N + jn) * kMtNv, Y, Yn, U, t);
+  double* hw = st.hw + ((size_t)b * N + j) * kMtHw;
   using D = Dual<1>;
   D Yd[5], Ud[3], f[6];
 #pragma unroll
-  for (int c = 0; c < 5; ++c) { Yd[c].v = pt ? Yn[c] : Y[c]; Yd[c].d[0] = d == c ? 1.0 : 0.0; }
+  for (int c = 0; c < 5; ++c) { Yd[c].v = pt == 0 ? Y[c] : (pt == 1 ? Yn[c] : hw[kMtHwXm + c]); Yd[c].d[0] = d == c ? 1.0 : 0.0; }
 #pragma unroll
   for (int c = 0; c < 3; ++c) { Ud[c].v = U[c]; Ud[c].d[0] = d == 5 + c ? 1.0 : 0.0; }
   DtTyres<D> ty;
   mt_dyn<D>(P, j, Yd, Ud, f, ty);
-  double* J = st.hw + ((size_t)b * N + j) * kMtHw + (pt ? kMtHwJ2 : kMtHwJ1);
+  double* J = hw + (pt == 0 ? kMtHwJ1 : (pt == 1 ? kMtHwJ2 : kMtHwJm));
 #pragma unroll
   for (int c = 0; c < 6; ++c) J[c * kMtPv + d] = f[c].d[0];
+  if (pt == 0) {
+    D r[6];
+    mt_own_rows_each<D>(P, Yd, Ud, ty, r);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) hw[kMtHwOw + c * kMtPv + d] = r[c].d[0];
+  }
+  if (pt == 2 && d == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) hw[kMtHwF + 12 + c] = f[c].v;
+  }
+}
+
+// grid (N, B), one wave per node: the 24 x 18 Jacobian of the pair rows in the scaled unknowns, from J1, J2, Jm by
+// the chain rule (defect rows), the own-row gradients, and the closed forms of the linear and the rate rows
+__global__ void __launch_bounds__(64) k_mt_jac_assemble(MtProblem P, MtState st) {
+  __shared__ double M[kMtPv][14], JM[6][14];
+  const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, N = P.N;
+  if (st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  const int jn = j + 1 == N ? 0 : j + 1;
+  const size_t o = (size_t)b * N + j;
+  const double* wo = st.w + o * kMtNv;
+  const double* wn = st.w + ((size_t)b * N + jn) * kMtNv;
+  const double* hw = st.hw + o * kMtHw;
+  const double t = wo[8] * P.sw[8];
+  const double* J1 = hw + kMtHwJ1;
+  const double* J2 = hw + kMtHwJ2;
+  const double* Jm = hw + kMtHwJm;
+  for (int e = lane; e < kMtPv * 14; e += 64) {   // M = d(Ym, U) / d(Y, U, t, Y')  (as in k_mt_hes_assemble)
+    const int r = e / 14, zi = e - 14 * r;
+    double v = 0.0;
+    if (r < 5) {
+      if (zi < 5) v = (zi == r ? 0.5 : 0.0) + (t / 8.0) * J1[(1 + r) * kMtPv + zi];
+      else if (zi < 8) v = (t / 8.0) * (J1[(1 + r) * kMtPv + zi] - J2[(1 + r) * kMtPv + zi]);
+      else if (zi == 8) v = hw[kMtHwDf + r] / 8.0;
+      else v = (zi - 9 == r ? 0.5 : 0.0) - (t / 8.0) * J2[(1 + r) * kMtPv + (zi - 9)];
+    } else {
+      v = zi == r ? 1.0 : 0.0;
+    }
+    M[r][zi] = v;
+  }
+  __syncthreads();
+  for (int e = lane; e < 6 * 14; e += 64) {
+    const int c = e / 14, zi = e - 14 * c;
+    double v = 0.0;
+#pragma unroll
+    for (int p = 0; p < kMtPv; ++p) v += Jm[c * kMtPv + p] * M[p][zi];
+    JM[c][zi] = v;
+  }
+  __syncthreads();
+  const double ru = (wn[5] - wo[5]) * P.sw[5] / t, rd = (wn[6] - wo[6]) * P.sw[6] / t;
+  double* Jout = st.jac + o * kMtNf * kMtLoc;
+  for (int e = lane; e < kMtNf * kMtLoc; e += 64) {
+    const int row = e / kMtLoc, col = e - kMtLoc * row;
+    double v = 0.0;   // derivative with respect to the PHYSICAL unknown of column col
+    if (row < 6) {
+      const int c = row;
+      if (col < 14) {
+        const int zi = col;
+        double dv = 4.0 * JM[c][zi];
+        if (zi < 5) dv += J1[c * kMtPv + zi];
+        else if (zi < 8) dv += J1[c * kMtPv + zi] + J2[c * kMtPv + zi];
+        else if (zi >= 9) dv += J2[c * kMtPv + (zi - 9)];
+        v = (t / 6.0) * dv;
+        if (zi == 8) v += (hw[kMtHwF + c] + 4.0 * hw[kMtHwF + 12 + c] + hw[kMtHwF + 6 + c]) / 6.0;
+        if (zi < 5 && c == 1 + zi) v += 1.0;
+        if (zi >= 9 && c == 1 + (zi - 9)) v -= 1.0;
+        v *= P.se[c];
+      }
+    } else if (row <= 11) {                 // eq 6, g 0..3, g 4: own rows of (Y, U)
+      if (col < kMtPv) v = hw[kMtHwOw + (row - 6) * kMtPv + col];
+    } else {
+      const int gq = row - kMtNe;           // 5 .. 16
+      const double su0 = P.sw[5], su2 = P.sw[6];
+      if (gq == 5) v = col == 4 ? -1.0 / P.sw[4] : 0.0;
+      else if (gq == 6) v = col == 5 ? -1.0 / su0 : 0.0;
+      else if (gq == 7) v = col == 5 ? 1.0 / su0 : 0.0;
+      else if (gq == 8) v = col == 6 ? -1.0 / su2 : 0.0;
+      else if (gq == 9) v = col == 6 ? 1.0 / su2 : 0.0;
+      else if (gq == 10 || gq == 11) {      // (c - ru) / su0, (ru - c') / su0
+        double dr = col == 5 ? -1.0 / t : (col == 14 ? 1.0 / t : (col == 8 ? -ru / t : 0.0));
+        v = (gq == 10 ? -dr : dr) / su0;
+      } else if (gq == 12 || gq == 13) {
+        double dr = col == 6 ? -1.0 / t : (col == 15 ? 1.0 / t : (col == 8 ? -rd / t : 0.0));
+        v = (gq == 12 ? -dr : dr) / su2;
+      } else if (gq == 14) v = col == 0 ? -1.0 / P.sw[0] : 0.0;
+      else if (gq == 15) v = col == 0 ? 1.0 / P.sw[0] : 0.0;
+      else v = col == 8 ? -1.0 : 0.0;       // g 16 = -t
+    }
+    Jout[e] = v * P.sw[col % kMtNv];
+  }
 }
 
 // grid (node blocks, B, 36 [MID] or 72 [ENDS]): one pair of directions of one dynamics evaluation per thread
