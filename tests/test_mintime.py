@@ -192,6 +192,34 @@ def test_reference_pipeline_on_the_example_track():
 
 
 @pytest.mark.gpu
+def test_monza_from_the_qss_guess():
+    """The same pipeline on the reference's OTHER example track (Monza, 5.8 km; nodes every 5 m -> N = 1158) with the
+    yaml's kart model: converges from the QSS guess well inside the yaml's tolerances (traj_opt_double_track.yaml:8-10),
+    stays between the boundaries, and is faster than the QSS profile it started from."""
+    from spline_trajectory_optimization_amd import batch
+    from spline_trajectory_optimization_amd.min_time_optm.min_time_optimizer import optimise_track
+    from spline_trajectory_optimization_amd.models.race_track import RaceTrack
+    from spline_trajectory_optimization_amd.models.vehicle import Vehicle, VehicleParams
+    from spline_trajectory_optimization_amd.simulator.simulator import Simulator
+    centre, left, right = batch.load_monza()
+    est = defaults.ESTIMATES
+    rt = RaceTrack("Monza", left, right, centre, s=10.0, interval=5.0)
+    veh = Vehicle(VehicleParams(np.array(est["acc_speed_loopup"]), np.array(est["dcc_speed_lookup"]), est["max_lon_acc_mpss"],
+                                est["max_lon_dcc_mpss"], est["max_left_acc_mpss"], est["max_right_acc_mpss"],
+                                est["max_speed_mps"], est["max_jerk_mpsc"]))
+    qss = rt.center_d.copy(); rt.fill_trajectory_boundaries(qss)
+    qss_lap = float(Simulator(veh).run_simulation(qss, False).trajectory[:, 16].sum())
+    out, X, U, T, st = optimise_track(rt, veh, defaults.MODEL, 10.0, defaults.SOLVER["speed_cap"], max_iter=300, tol=1e-6)
+    print(f"Monza N={len(out)}: iterations {st[0]:.0f} status {st[5]:.0f} kkt {st[1]:.1e} viol {st[2]:.1e} lap {st[4]:.3f} s "
+          f"(QSS {qss_lap:.3f} s)")
+    assert st[5] == 1.0 and max(st[1], st[2], st[3]) <= 1e-6 <= defaults.SOLVER["tol"]
+    assert st[4] < qss_lap and abs(T.sum() - st[4]) <= 1e-9
+    margin = defaults.MODEL["vehicle_width"] / 2 + defaults.MODEL["safety_margin"]
+    assert (X[:, 1] <= rt.left_intp(rt.abscissa) - margin + 1e-6).all() and (X[:, 1] >= rt.right_intp(rt.abscissa) + margin - 1e-6).all()
+    assert np.isfinite(out.points).all() and X[:, 5].min() >= 1.0 - 1e-6
+
+
+@pytest.mark.gpu
 def test_width_perturbed_batch_at_full_resolution_all_converge():
     """BASELINE config 2's perturbation applied to config 5 at the example's own resolution (MGKT, 828 nodes): every
     instance of the batch reaches the 1e-6 tolerance (the globalisation once left 1 - 2 % of such batches creeping or
