@@ -1058,7 +1058,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
                                double track_length, double average_track_width, double speed_cap, double* X, double* U,
                                double* T, int max_iter, double tol, double* stats) {
   if (!ctx || !model || !s || !kappa || !left || !right || !X || !U || !T || !stats) return fail(RL_ERR_ARG, "null argument");
-  if (B <= 0 || N < 4 || !(track_length > 0.0) || max_iter < 1 || !(tol > 0.0)) return fail(RL_ERR_ARG, "bad sizes");
+  if (B <= 0 || N < 8 || !(track_length > 0.0) || max_iter < 1 || !(tol > 0.0)) return fail(RL_ERR_ARG, "bad sizes (N >= 8 nodes)");
   if (!(average_track_width > 0.0) || !(speed_cap > 0.0)) return fail(RL_ERR_ARG, "bad scales");
   RL_HIP(hipSetDevice(ctx->device));
   rl::MtProblem P;
@@ -1163,7 +1163,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       }
       hipLaunchKernelGGL(rl::k_mt_prepare, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_step, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
     }
     if (g_mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
@@ -1281,12 +1281,3 @@ static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_
   return RL_OK;
 }
 
-
-#ifdef MT_STAMPS
-extern "C" int rl_debug_mt_stamps(unsigned long long* out) {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rl::g_mt_stamps), sizeof(z)) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(rl::g_mt_stamps), z, sizeof(z)) != hipSuccess) return -1;
-  return 0;
-}
-#endif

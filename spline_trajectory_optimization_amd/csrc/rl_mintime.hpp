@@ -905,21 +905,27 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
   }
 }
 
-#ifdef MT_STAMPS
-__device__ unsigned long long g_mt_stamps[8];
-#define MT_T(v) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
-#define MT_ACC(slot, t1, t0) mt_acc[slot] += (t1) - (t0)
-#else
-#define MT_T(v) do { } while (0)
-#define MT_ACC(slot, t1, t0) do { } while (0)
-#endif
-// k_mt_kkt: one wave per instance: block elimination of the cyclic block-tridiagonal KKT system from the
-// assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.  All blocks stay in
-// registers (MtBlk); the blocks of the next node are fetched while the current node is eliminated.  Kept for
-// the back substitution, per node: P_j = E_j S_j^-1, Q_j = F_j S_j^-1 (row major) and a_j = S_j^-1 r_j.
-__global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
-  __shared__ double xs[2][16];
-  const int b = blockIdx.x, lane = threadIdx.x, N = P.N;
+// k_mt_kkt: two waves per instance: block elimination of the cyclic block-tridiagonal KKT system from the
+// assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.
+//
+// The last node N-1 is the BORDER (its couplings to node 0 and to node N-2 close the lap); the chain 0 .. N-2 is
+// eliminated from BOTH ENDS at once: front A (wave 0) takes 0, 1, ..., m-1, front B (wave 1) takes N-2, N-3, ...,
+// m+1, each carrying its fill F towards the border, and they meet at node m = (N-1)/2, which receives the Schur
+// complements of both.  The dependent chain is (N-1)/2 block steps instead of N-1; the back substitution runs from
+// m outwards on both sides.  Both fronts are the same code: front B sees the chain reversed, so its "E" (coupling of
+// the node to the next one of the front) is E_{j-1}' and its first border block is M[N-1][N-2] = E_{N-2}.
+// All blocks stay in registers (MtBlk); the blocks of the next node are fetched while the current node is
+// eliminated.  Kept for the back substitution, per node: P_j = E S_j^-1, Q_j = F_j S_j^-1 (row major), a_j = S_j^-1 r_j.
+struct MtKktShare {                   // what front B hands to the meeting node, flags, and the start of the way back
+  double T[256], Fn[256], Sl[256];    // blocks in the lanes' own order (lane * 4 + r)
+  double rn[16], rl[16], xl[16], xm[16];
+  double xs[2][2][16];
+  int bad[2], nneg[2], ok;
+};
+
+__global__ void __launch_bounds__(128) k_mt_kkt(MtProblem P, MtState st) {
+  __shared__ MtKktShare X;
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, N = P.N;
   const int i = lane & 15, q = lane >> 4;
   double* scal = st.scal + (size_t)b * 16;
   if (scal[5] != 0.0) return;
@@ -929,128 +935,162 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
   double* blk = st.blk + (size_t)b * N * 3 * 256;   // per node: P [256], Q [256], a' [16]
   double* vec = st.vec + (size_t)b * N * 16;
   double delta = scal[1];
-  auto ld = [&](const double* G) { MtBlk X;      // row-major block -> A-layout
+  auto ld = [&](const double* G) { MtBlk Z;      // row-major block -> A-layout
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X.v[r] = G[i * 16 + 4 * r + q];
-    return X; };
-  auto ld_t = [&](const double* G) { MtBlk X;    // its transpose (a symmetric block: the coalesced way to read it)
+    for (int r = 0; r < 4; ++r) Z.v[r] = G[i * 16 + 4 * r + q];
+    return Z; };
+  auto ld_t = [&](const double* G) { MtBlk Z;    // its transpose (a symmetric block: the coalesced way to read it)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X.v[r] = G[(4 * r + q) * 16 + i];
-    return X; };
-  auto st_rm = [&](double* G, const MtBlk& X) {
+    for (int r = 0; r < 4; ++r) Z.v[r] = G[(4 * r + q) * 16 + i];
+    return Z; };
+  auto st_rm = [&](double* G, const MtBlk& Z) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) G[i * 16 + 4 * r + q] = X.v[r]; };
+    for (int r = 0; r < 4; ++r) G[i * 16 + 4 * r + q] = Z.v[r]; };
   // delta I on the unknowns' part of a diagonal block
-  auto shift = [&](MtBlk& X) {
+  auto shift = [&](MtBlk& Z) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X.v[r] += (i == 4 * r + q && i < kMtNv) ? delta : 0.0; };
+    for (int r = 0; r < 4; ++r) Z.v[r] += (i == 4 * r + q && i < kMtNv) ? delta : 0.0; };
   const MtBlk zero = {{0.0, 0.0, 0.0, 0.0}};
+  const int m = (N - 1) / 2;                         // meeting node (N >= 8: neither next to the border nor an end)
+  const int cnt = wave == 0 ? m : N - 2 - m;         // nodes of this front
+  auto node = [&](int s_) { return wave == 0 ? s_ : N - 2 - s_; };
+  // coupling of node j to the NEXT node of its front, in the role of E_j of the ascending recursion
+  auto ld_e = [&](int j) { return wave == 0 ? ld(Eg + (size_t)j * 256) : ld_t(Eg + (size_t)(j - 1) * 256); };
 
-#ifdef MT_STAMPS
-  unsigned long long mt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mt_a = 0, mt_b = 0, mt_c = 0;
-  MT_T(mt_c);
-#endif
   int attempt = 0;
   bool ok = false;
-  MtBlk Sl = zero;
-  double rl = 0.0;
   for (; attempt < 12 && !ok; ++attempt) {
     bool bad = false;
     int n_neg = 0;
-    // S_last and its right-hand side; F = border block M[N-1][j] (fill-in), F_0 = M[N-1][0] = E_{N-1}'
-    Sl = ld_t(Dg + (size_t)(N - 1) * 256); shift(Sl);
-    MtBlk S = ld_t(Dg); shift(S);
-    MtBlk F = ld_t(Eg + (size_t)(N - 1) * 256);
-    rl = Rg[(size_t)(N - 1) * 16 + i];
+    MtBlk S = ld_t(Dg + (size_t)node(0) * 256); shift(S);
+    // border block of the front's first node: M[N-1][0] = E_{N-1}'  /  M[N-1][N-2] = E_{N-2}
+    MtBlk F = wave == 0 ? ld_t(Eg + (size_t)(N - 1) * 256) : ld(Eg + (size_t)(N - 2) * 256);
+    MtBlk SlC = zero, Tx = zero, Fx = zero;   // contributions to S_last; what the meeting node receives
+    double rlC = 0.0, rx = 0.0;
     double rk[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rk[r] = Rg[4 * r + q];
-    MtBlk eN = ld(Eg), dN = N > 2 ? ld_t(Dg + 256) : zero;   // blocks of the next step, in flight
-    double rN = N > 2 ? Rg[16 + i] : 0.0;
-    for (int j = 0; j < N - 1 && !bad; ++j) {
-      MT_T(mt_a);
+    for (int r = 0; r < 4; ++r) rk[r] = Rg[(size_t)node(0) * 16 + 4 * r + q];
+    MtBlk eN = ld_e(node(0)), dN = cnt > 1 ? ld_t(Dg + (size_t)node(1) * 256) : zero;   // blocks of the next step, in flight
+    double rN = cnt > 1 ? Rg[(size_t)node(1) * 16 + i] : 0.0;
+    for (int s_ = 0; s_ < cnt && !bad; ++s_) {
+      const int j = node(s_);
       const MtBlk E = eN, dC = dN;
       const double rC = rN;
-      if (j + 1 < N - 1) {               // prefetch for step j + 1: E_{j+1}, D_{j+2}, r_{j+2}
-        eN = ld(Eg + (size_t)(j + 1) * 256);
-        dN = j + 2 < N - 1 ? ld_t(Dg + (size_t)(j + 2) * 256) : zero;
-        rN = j + 2 < N - 1 ? Rg[(size_t)(j + 2) * 16 + i] : 0.0;
+      if (s_ + 1 < cnt) {                // prefetch for the next step
+        eN = ld_e(node(s_ + 1));
+        dN = s_ + 2 < cnt ? ld_t(Dg + (size_t)node(s_ + 2) * 256) : zero;
+        rN = s_ + 2 < cnt ? Rg[(size_t)node(s_ + 2) * 16 + i] : 0.0;
       }
-      if (j == N - 2) {                  // the regular coupling of the last node joins the border
-#pragma unroll
-        for (int r = 0; r < 4; ++r) F.v[r] += E.v[r];
-      }
-      MT_T(mt_b); MT_ACC(0, mt_b, mt_a);
       const int neg = mt_invert(S, lane);                   // S_j^-1
       if (neg < 0) { bad = true; break; }
       n_neg += neg;
-      MT_T(mt_a); MT_ACC(1, mt_a, mt_b);
       const double aj = mt_gemv(S, rk);                     // a_j = S_j^-1 r_j
       if (q == 0) vec[(size_t)j * 16 + i] = aj;
-      const MtBlk Pm = j < N - 2 ? mt_mul_t(S, E) : zero;   // P_j = E_j S_j^-1
+      const MtBlk Pm = mt_mul_t(S, E);                      // P_j = E S_j^-1
       const MtBlk Qm = mt_mul_t(S, F);                      // Q_j = F_j S_j^-1
       double* Bj = blk + (size_t)j * 3 * 256;
-      MT_T(mt_b); MT_ACC(2, mt_b, mt_a);
       st_rm(Bj, Pm); st_rm(Bj + 256, Qm);
-      rl -= mt_gemv(Qm, rk);                                // r_last -= Q_j r_j
+      rlC -= mt_gemv(Qm, rk);                               // r_last -= Q_j r_j
       {
         const MtBlk U = mt_mul_t(F, Qm);                    // S_last -= Q_j F_j'
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Sl.v[r] -= U.v[r];
+        for (int r = 0; r < 4; ++r) SlC.v[r] -= U.v[r];
       }
-      MT_T(mt_a); MT_ACC(3, mt_a, mt_b);
-      if (j < N - 2) {
-        // next node: S_{j+1} = D_{j+1} + delta - P_j E_j' ; F_{j+1} = -Q_j E_j' ; r_{j+1} -= P_j r_j
-        const MtBlk M = mt_mul_t(E, Pm), Fn = mt_mul_t(E, Qm);
+      // next node of the front: S += -P E' ; F = -Q E' ; r += -P r_j   (the last step hands them to the meeting node)
+      const MtBlk M = mt_mul_t(E, Pm), Fn = mt_mul_t(E, Qm);
+      const double rn = -mt_gemv(Pm, rk);
+      if (s_ + 1 < cnt) {
         S = dC; shift(S);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { S.v[r] -= M.v[r]; F.v[r] = -Fn.v[r]; }
-        const double rn = rC - mt_gemv(Pm, rk);
-        mt_to_k(rn, q, rk);
+        mt_to_k(rC + rn, q, rk);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Tx.v[r] = -M.v[r]; Fx.v[r] = -Fn.v[r]; }
+        rx = rn;
       }
-      MT_T(mt_b); MT_ACC(4, mt_b, mt_a);
     }
-    if (!bad) {
-      const int neg = mt_invert(Sl, lane);
+    if (wave == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { X.T[lane * 4 + r] = Tx.v[r]; X.Fn[lane * 4 + r] = Fx.v[r]; X.Sl[lane * 4 + r] = SlC.v[r]; }
+      if (q == 0) { X.rn[i] = rx; X.rl[i] = rlC; }
+    }
+    if (lane == 0) { X.bad[wave] = bad ? 1 : 0; X.nneg[wave] = n_neg; }
+    __syncthreads();
+    const bool fronts_ok = X.bad[0] == 0 && X.bad[1] == 0;
+    if (fronts_ok && wave == 0) {
+      // ---- meeting node m, then the border
+      bool okm = true;
+      MtBlk Sm = ld_t(Dg + (size_t)m * 256); shift(Sm);
+      MtBlk Fm, Sl = ld_t(Dg + (size_t)(N - 1) * 256);
+      shift(Sl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Sm.v[r] += Tx.v[r] + X.T[lane * 4 + r];
+        Fm.v[r] = Fx.v[r] + X.Fn[lane * 4 + r];
+        Sl.v[r] += SlC.v[r] + X.Sl[lane * 4 + r];
+      }
+      double rmk[4];
+      mt_to_k(Rg[(size_t)m * 16 + i] + rx + X.rn[i], q, rmk);
+      double rl = Rg[(size_t)(N - 1) * 16 + i] + rlC + X.rl[i];
+      int total = X.nneg[0] + X.nneg[1];
+      const int negm = mt_invert(Sm, lane);
+      if (negm < 0) okm = false;
+      total += negm;
+      const double am = mt_gemv(Sm, rmk);
+      if (q == 0) vec[(size_t)m * 16 + i] = am;
+      const MtBlk Qm = mt_mul_t(Sm, Fm);
+      double* Bm = blk + (size_t)m * 3 * 256;
+      st_rm(Bm, zero); st_rm(Bm + 256, Qm);
+      rl -= mt_gemv(Qm, rmk);
+      {
+        const MtBlk U = mt_mul_t(Fm, Qm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sl.v[r] -= U.v[r];
+      }
+      const int negl = mt_invert(Sl, lane);
       // inertia (9N, 7N, 0): the reduced Hessian is positive definite (Sylvester's law on the LDL' pivots)
-      if (neg < 0 || n_neg + neg != N * kMtNe) bad = true;
+      if (negl < 0 || total + negl != N * kMtNe) okm = false;
+      if (okm) {
+        double rlk[4];
+        mt_to_k(rl, q, rlk);
+        const double xl = mt_gemv(Sl, rlk);     // x_last = S_last^-1 r_last
+        if (q == 0) X.xl[i] = xl;
+      }
+      if (lane == 0) X.ok = okm ? 1 : 0;
     }
-    if (bad) {
+    __syncthreads();
+    if (!fronts_ok || X.ok == 0) {
       delta = fmax(10.0 * delta, 1e-4);
+      __syncthreads();                   // everybody has read the flags before the next attempt rewrites them
       if (delta > 1e8) break;
       continue;
     }
     ok = true;
   }
-  if (lane == 0) { scal[1] = delta; scal[10] += (double)(attempt - 1); }
+  if (threadIdx.x == 0) { scal[1] = delta; scal[10] += (double)(attempt - 1); }
   if (!ok) {
-    if (lane == 0) scal[5] = 2.0;
+    if (threadIdx.x == 0) scal[5] = 2.0;
     return;
   }
-  MT_T(mt_a); MT_ACC(5, mt_a, mt_c);
-  // ---- back substitution: x_last = S_last^-1 r_last; x_j = a_j - Q_j' x_last - P_j' x_{j+1}
+  // ---- back substitution: x_j = a_j - Q_j' x_last - P_j' x_(neighbour towards m), from m outwards on both sides
   double* dw = st.dw + (size_t)b * N * kMtNv;
   double* dy = st.dy + (size_t)b * N * kMtNe;
-  {
-    double rlk[4];
-    mt_to_k(rl, q, rlk);
-    const double xl = mt_gemv(Sl, rlk);
-    if (q == 0) {
-      xs[0][i] = xl; xs[1][i] = xl;      // x_{j+1} for j = N-2 is x_last too (its P is zero: the coupling sits in Q)
-      if (i < kMtNv) dw[(size_t)(N - 1) * kMtNv + i] = xl;
-      else dy[(size_t)(N - 1) * kMtNe + i - kMtNv] = xl;
-    }
+  if (wave == 0 && lane < 16) {
+    const double xl = X.xl[lane];
+    if (lane < kMtNv) dw[(size_t)(N - 1) * kMtNv + lane] = xl;
+    else dy[(size_t)(N - 1) * kMtNe + lane - kMtNv] = xl;
   }
-  mt_wave_sync();
-  // a'_j = a_j - Q_j' x_last for every node, four nodes at a time (lane = node q of the four, component i);
-  // written to the node's third slot, which nothing has read before (no stale line in the vector L1)
+  // a'_j = a_j - Q_j' x_last for the nodes of this wave's side (wave 0: 0 .. m, wave 1: m+1 .. N-2), four nodes at
+  // a time (lane = node q of the four, component i); written to the node's third slot, which nothing has read before
   {
     double xl[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) xl[k] = xs[0][k];
-    for (int j0 = 0; j0 < N - 1; j0 += 4) {
+    for (int k = 0; k < 16; ++k) xl[k] = X.xl[k];
+    const int j_lo = wave == 0 ? 0 : m + 1, j_hi = wave == 0 ? m + 1 : N - 1;
+    for (int j0 = j_lo; j0 < j_hi; j0 += 4) {
       const int j = j0 + q;
-      if (j < N - 1) {
+      if (j < j_hi) {
         const double* Qg = blk + (size_t)j * 3 * 256 + 256;
         double acc = vec[(size_t)j * 16 + i];
 #pragma unroll
@@ -1060,43 +1100,52 @@ __global__ void __launch_bounds__(64) k_mt_kkt(MtProblem P, MtState st) {
     }
   }
   mt_wave_sync();
-  MT_T(mt_b); MT_ACC(6, mt_b, mt_a);
-  // the chain: lanes 0..15 own one component each; P and a' of the node THREE steps ahead are fetched while x_j is
-  // formed (four rotating register sets: a step is shorter than the latency of a load)
-  if (lane < 16) {
-    double pb[4][17];
-    auto fetch = [&](double (&dst)[17], int node) {
-      if (node >= 0) {
-        const double* Bn = blk + (size_t)node * 3 * 256;
+  // x_m = a'_m (P_m = 0) starts both chains: wave 0 walks m-1, ..., 0, wave 1 walks m+1, ..., N-2.  Lanes 0..15 of
+  // each wave own one component each; P and a' of the node THREE steps ahead are fetched while x_j is formed (four
+  // rotating register sets: a step is shorter than the latency of a load).
+  if (wave == 0 && lane < 16) {
+    const double x = blk[(size_t)m * 3 * 256 + 512 + lane];
+    if (lane < kMtNv) dw[(size_t)m * kMtNv + lane] = x;
+    else dy[(size_t)m * kMtNe + lane - kMtNv] = x;
+    X.xm[lane] = x;
+  }
+  double (*xs)[16] = X.xs[wave];
+  const int steps = wave == 0 ? m : N - 2 - m;
+  auto chain_node = [&](int s_) { return wave == 0 ? m - 1 - s_ : m + 1 + s_; };
+  double pb[4][17];
+  auto fetch = [&](double (&dst)[17], int s_) {
+    if (s_ < steps && lane < 16) {
+      const double* Bn = blk + (size_t)chain_node(s_) * 3 * 256;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dst[k] = Bn[k * 16 + lane];
-        dst[16] = Bn[512 + lane];
-      }
-    };
-    fetch(pb[0], N - 2); fetch(pb[1], N - 3); fetch(pb[2], N - 4);
-    int cur = 1;
-    for (int j0 = N - 2; j0 >= 0; j0 -= 4) {
+      for (int k = 0; k < 16; ++k) dst[k] = Bn[k * 16 + lane];
+      dst[16] = Bn[512 + lane];
+    }
+  };
+  fetch(pb[0], 0); fetch(pb[1], 1); fetch(pb[2], 2);
+  __syncthreads();
+  if (lane < 16) xs[0][lane] = X.xm[lane];
+  mt_wave_sync();
+  int cur = 0;
+  for (int s0 = 0; s0 < steps; s0 += 4) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = j0 - u;
-        if (j < 0) break;
-        fetch(pb[(u + 3) & 3], j - 3);
+    for (int u = 0; u < 4; ++u) {
+      const int s_ = s0 + u;
+      if (s_ >= steps) break;
+      fetch(pb[(u + 3) & 3], s_ + 3);
+      if (lane < 16) {
         double x0 = pb[u][16], x1 = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; k += 2) { x0 = fma(-pb[u][k], xs[cur][k], x0); x1 = fma(-pb[u][k + 1], xs[cur][k + 1], x1); }
         const double x = x0 + x1;
+        const int j = chain_node(s_);
         if (lane < kMtNv) dw[(size_t)j * kMtNv + lane] = x;
         else dy[(size_t)j * kMtNe + lane - kMtNv] = x;
         xs[cur ^ 1][lane] = x;
-        mt_wave_sync();
-        cur ^= 1;
       }
+      mt_wave_sync();
+      cur ^= 1;
     }
   }
-#ifdef MT_STAMPS
-  MT_T(mt_a); MT_ACC(7, mt_a, mt_b);
-  if (lane == 0 && b == 0) for (int qq = 0; qq < 8; ++qq) atomicAdd(&g_mt_stamps[qq], mt_acc[qq]);
-#endif
 }
 
 // residuals only (final report of the instances that ran into the iteration limit)
