@@ -223,8 +223,9 @@ int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double*
  * builds (min_time_optm/min_time_optimizer.py:93-163; IPOPT through casadi.Opti, :158-161 -- a third-party
  * solver that is not part of the reference tree).  Method (rl_mintime.hpp): primal-dual interior-point
  * SQP-type iteration, one barrier QP subproblem per iteration with the exact Hessian of the Lagrangian
- * (forward-over-forward differentiation of the model code), its cyclic block-tridiagonal KKT system
- * (16 x 16 blocks per node) factorised per instance on the GPU, filter line search.
+ * (forward-over-forward differentiation of each dynamics evaluation, chain rule through the collocation
+ * midpoint), its cyclic block-tridiagonal KKT system (16 x 16 blocks per node) eliminated per instance on the
+ * GPU from both ends of the lap at once, filter line search.  N >= 8 nodes.
  *   model, s, kappa, left, right, margin, track_length: as rl_dt_eval_nodes; left/right are [B,N] when
  *   bounds_per_instance != 0 (a batch of tracks that differ in their widths), [N] otherwise
  *   average_track_width, speed_cap: the reference's variable scaling (:109; yaml keys of the same name)
@@ -234,7 +235,7 @@ int rl_dt_eval_jac(rl_ctx* ctx, const double* model, int B, int N, const double*
  *       complementarity are all <= tol (IPOPT's `tol` measures the same three in its own scaling)
  *   stats [B,12]: iterations, dual infeasibility, constraint violation, complementarity, lap time [s],
  *       status (1 converged, 0 iteration limit, 2 failed), barrier mu, Levenberg delta, last step length,
- *       refactorisations, 2 reserved
+ *       refactorisations, step length allowed by the fraction-to-the-boundary rule, halvings of the last line search
  * Host pointers.  CPU twin for tests: oracle/sqp_twin.py. */
 int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const double* s, const double* kappa,
                            const double* left, const double* right, int bounds_per_instance, double margin,
