@@ -25,7 +25,7 @@ afterwards.  Step length: fraction to the boundary (0.995) for s and z, then bac
 barrier objective): improve one of them against the current point, do not raise the infeasibility above
 max(2 x current, 1e-5 per row), and -- where that floor is what lets it grow -- be acceptable to the last 8
 iterates of the barrier problem as well (filter).  mu is lowered monotonically once the barrier problem is
-solved to 10 mu.
+solved to 30 mu.
 
 The HIP kernels (k_mt_*) implement exactly this iteration; this file differs in how it does the work:
 derivatives by complex-step differentiation of the numpy model, second derivatives by central differences
@@ -42,6 +42,8 @@ from . import dt_checker as dc
 NV, NE, NI = 9, 7, 17
 THETA_GROWTH = 2.0
 FILTER = 8
+MU_KAPPA = 30.0                                   # the barrier problem counts as solved at MU_KAPPA * mu
+D_DOWN, D_UP, A_HI, A_LO = 0.4, 3.0, 0.9, 0.2     # Levenberg parameter x D_DOWN after a step > A_HI, x D_UP after one <= A_LO
 THETA_FLOOR = 1e-5     # ... above 1e-5 per row (next to a feasible point twice nothing is nothing)   # a step may not more than double the l1 infeasibility, whatever it does to the objective
 # reduced variable a -> (array, column): X cols 1..5, U cols 0,2,3, T
 _XCOL = [1, 2, 3, 4, 5]
@@ -318,8 +320,8 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
         if max(kkt, viol, compl) <= tol:
             status = 1
             break
-        # barrier parameter: monotone (Fiacco-McCormick): lowered once the barrier problem is solved to ~10 mu
-        if max(kkt, viol, np.abs(sz * zz - mu).max()) <= 10.0 * mu:
+        # barrier parameter: monotone (Fiacco-McCormick): lowered once the barrier problem is solved to ~MU_KAPPA mu
+        if max(kkt, viol, np.abs(sz * zz - mu).max()) <= MU_KAPPA * mu:
             mu_new = max(min(0.2 * mu, mu ** 1.5), tol / 10.0)     # no lower than needed for compl <= tol
             if mu_new != mu:
                 filt = []      # a new barrier problem: another objective, the filter starts empty
@@ -381,7 +383,7 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
         z = (zz + min(ad, 1.0) * dz).reshape(N, NI)
         z = np.clip(z, mu / (1e10 * s), 1e10 * mu / s)
         # Levenberg parameter: a short step means the linearisation was not trusted that far
-        delta = min(max(delta * (0.4 if a > 0.9 else (1.0 if a > 0.3 else 5.0)), 1e-6), 1e3)
+        delta = min(max(delta * (D_DOWN if a > A_HI else (1.0 if a > A_LO else D_UP)), 1e-6), 1e3)
     X, U, T = P.unpack(w)
     info = {"iterations": len(hist), "kkt": kkt, "viol": viol, "compl": compl, "lap_time": float(T.sum()), "history": hist,
             "status": status, "y": y, "z": z, "s": s, "mu": mu, "delta": delta}

@@ -1091,6 +1091,14 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
   st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]);
   st.tol = tol;
+  {
+    // measured on 1024 width-perturbed MGKT tracks (tools/mintime_knobs.sh): (d_up, a_lo, mu_kappa) = (5, 0.3, 10) 96.5
+    // iterations on average, (3, 0.2, 30) 77.8, every single change of d_down, mu_fac, mu_pow or mu0 worse or failing
+    auto knob = [](const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; };
+    st.d_down = knob("RL_MT_D_DOWN", 0.4); st.d_up = knob("RL_MT_D_UP", 3.0);
+    st.a_hi = knob("RL_MT_A_HI", 0.9); st.a_lo = knob("RL_MT_A_LO", 0.2);
+    st.mu_fac = knob("RL_MT_MU_FAC", 0.2); st.mu_pow = knob("RL_MT_MU_POW", 1.5); st.mu_kappa = knob("RL_MT_MU_KAPPA", 30.0);
+  }
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
   RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
   // A few sub-batches on as many streams: the KKT elimination is one wave per instance and latency bound (its time
@@ -1137,12 +1145,13 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     return hipSuccess;
   };
   const dim3 bn64(64);
+  const double mt_mu0 = getenv("RL_MT_MU0") ? atof(getenv("RL_MT_MU0")) : 1e-1, mt_delta0 = getenv("RL_MT_DELTA0") ? atof(getenv("RL_MT_DELTA0")) : 1e-4;
   for (int g = 0; g < ngrp; ++g) {
     const Grp& G = grp[g];
     const dim3 gn((N + 63) / 64, G.nb);
     hipLaunchKernelGGL(rl::k_mt_pack, gn, bn64, 0, G.q, G.P, G.st, (const double*)G.X, (const double*)G.U, (const double*)G.T);
     hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, G.q, G.P, G.st);
-    hipLaunchKernelGGL(rl::k_mt_init, dim3((N * rl::kMtNi + 255) / 256, G.nb), dim3(256), 0, G.q, G.P, G.st, 1e-1, 1e-4);
+    hipLaunchKernelGGL(rl::k_mt_init, dim3((N * rl::kMtNi + 255) / 256, G.nb), dim3(256), 0, G.q, G.P, G.st, mt_mu0, mt_delta0);
   }
   RL_HIP(hipGetLastError());
   for (int it = 0; it < max_iter; ++it) {   // finished instances return at once from every kernel

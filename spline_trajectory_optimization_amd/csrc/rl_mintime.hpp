@@ -195,6 +195,8 @@ struct MtState {       // per-batch device arrays, instance-major
   double* scal;   // [B,16] per-instance scalars: 0 mu, 1 delta, 2 kkt, 3 viol, 4 compl, 5 status (0 run, 1 converged,
                   //        2 failed), 6 iterations, 7 last alpha, 8 theta0, 9 phi0, 10 refactorisations, 11 lap time
   double tol;
+  // strategy constants (defaults in rl_mincurv.hip; the RL_MT_* environment switches exist for experiments)
+  double d_down, d_up, a_hi, a_lo, mu_fac, mu_pow, mu_kappa;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -816,9 +818,9 @@ __global__ void __launch_bounds__(64) k_mt_prepare(MtProblem P, MtState st) {
     if (lane == 0) scal[5] = 1.0;
     return;
   }
-  // monotone barrier update once the barrier problem is solved to 10 mu; no lower than compl <= tol needs
-  if (fmax(fmax(kkt, viol), errmu) <= 10.0 * mu) {
-    const double mu_new = fmax(fmin(0.2 * mu, mu * sqrt(mu)), st.tol / 10.0);
+  // monotone barrier update once the barrier problem is solved to mu_kappa mu; no lower than compl <= tol needs
+  if (fmax(fmax(kkt, viol), errmu) <= st.mu_kappa * mu) {
+    const double mu_new = fmax(fmin(st.mu_fac * mu, pow(mu, st.mu_pow)), st.tol / 10.0);
     if (mu_new != mu && lane == 0) scal[14] = 0.0;   // a new barrier problem: its objective is another function, the filter starts empty
     mu = mu_new;
   }
@@ -1287,7 +1289,7 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
     z_ = fmin(fmax(z_, mu / (1e10 * s_)), 1e10 * mu / s_);
     sv[idx] = s_; zv[idx] = z_;
   }
-  delta = fmin(fmax(delta * (a > 0.9 ? 0.4 : (a > 0.3 ? 1.0 : 5.0)), 1e-6), 1e3);
+  delta = fmin(fmax(delta * (a > st.a_hi ? st.d_down : (a > st.a_lo ? 1.0 : st.d_up)), 1e-6), 1e3);
   if (tid == 0) {
     scal[1] = delta; scal[7] = a; scal[6] += 1.0; scal[8] = theta0; scal[9] = phi0; scal[12] = ap; scal[13] = (double)halvings;
     const int slot = nfilt_total % kMtFilter;   // the point just left joins the filter
