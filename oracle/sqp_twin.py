@@ -42,6 +42,7 @@ from . import dt_checker as dc
 NV, NE, NI = 9, 7, 17
 THETA_GROWTH = 2.0
 FILTER = 8
+TH_FILTER = 1e-4
 MU_KAPPA = 30.0                                   # the barrier problem counts as solved at MU_KAPPA * mu
 D_DOWN, D_UP, A_HI, A_LO = 0.4, 3.0, 0.9, 0.2     # Levenberg parameter x D_DOWN after a step > A_HI, x D_UP after one <= A_LO
 THETA_FLOOR = 1e-5     # ... above 1e-5 per row (next to a feasible point twice nothing is nothing)   # a step may not more than double the l1 infeasibility, whatever it does to the objective
@@ -361,9 +362,9 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
             floor = THETA_FLOOR * N * (NE + NI)
             acc = np.isfinite(pht) and np.isfinite(tht) and tht <= max(THETA_GROWTH * th0, floor) + 1e-9 and \
                 (tht <= (1 - 1e-5) * th0 or pht <= ph0 - 1e-5 * th0)
-            # ... and, where it is the floor that lets the infeasibility grow, acceptable to the (up to FILTER) earlier
-            # iterates of this barrier problem: no cycling between two nearly feasible points
-            if THETA_GROWTH * th0 < floor:
+            # ... and, once nearly feasible (l1 infeasibility below TH_FILTER per row), acceptable to the (up to FILTER)
+            # earlier iterates of this barrier problem: no cycling between two nearly feasible points
+            if th0 < TH_FILTER * N * (NE + NI):
                 for (thf, phf) in filt[-FILTER:]:
                     acc = acc and (tht <= (1 - 1e-5) * thf or pht <= phf - 1e-5 * thf)
             if acc:

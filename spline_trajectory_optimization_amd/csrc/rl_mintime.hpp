@@ -196,7 +196,7 @@ struct MtState {       // per-batch device arrays, instance-major
                   //        2 failed), 6 iterations, 7 last alpha, 8 theta0, 9 phi0, 10 refactorisations, 11 lap time
   double tol;
   // strategy constants (defaults in rl_mincurv.hip; the RL_MT_* environment switches exist for experiments)
-  double d_down, d_up, a_hi, a_lo, mu_fac, mu_pow, mu_kappa;
+  double d_down, d_up, a_hi, a_lo, mu_fac, mu_pow, mu_kappa, th_filter;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1265,10 +1265,11 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
     const double floor_ = kMtThetaFloor * (double)(N * kMtNf);
     bool acc = fin && theta <= fmax(kMtThetaGrowth * theta0, floor_) + 1e-9 &&
                (theta <= (1.0 - 1e-5) * theta0 || phi <= phi0 - 1e-5 * theta0);
-    // ... and where it is the floor that lets the infeasibility grow, the step must be acceptable to the earlier
-    // iterates of this barrier problem as well: otherwise two nearly feasible points, one of less infeasibility and
-    // one of less objective, can be visited in turn for ever (seen on 4 of 256 instances)
-    for (int e = 0; e < nfilt && acc && kMtThetaGrowth * theta0 < floor_; ++e)
+    // ... and once the iterate is nearly feasible (l1 infeasibility below th_filter per row) the step must be acceptable
+    // to the earlier iterates of this barrier problem as well: otherwise two points, one of less infeasibility and
+    // one of less objective, can be visited in turn for ever (seen on a few of 1024 instances).  Far from feasibility
+    // the iteration legitimately trades one for the other, and a filter there would need a restoration phase.
+    for (int e = 0; e < nfilt && acc && theta0 < st.th_filter * (double)(N * kMtNf); ++e)
       acc = theta <= (1.0 - 1e-5) * filt[2 * e] || phi <= filt[2 * e + 1] - 1e-5 * filt[2 * e];
     if (acc) { ok = true; halvings = trial; break; }
     a *= 0.5;

@@ -30,6 +30,6 @@ print(json.dumps({"B": B, "not_converged": bad.tolist(), "scale": (1 + e[bad, 0]
 names = ["iters", "kkt", "viol", "compl", "lap", "status", "mu", "delta", "alpha", "refact", "alpha_ftb", "halvings"]
 for b in bad[:3]:
     print(int(b), {n: float(v) for n, v in zip(names, st[b])})
-    for k in (40, 60, 80, 100, 120, 150, 200, 300):
+    for k in (20, 30, 40, 50, 60, 80, 100, 150, 300):
         _, _, _, s1 = prob.solve_batch(left[b:b + 1], right[b:b + 1], max_iter=k, tol=1e-6)
         print("   after", k, {n: float(f"{v:.4g}") for n, v in zip(names, s1[0])})
