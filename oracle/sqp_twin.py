@@ -43,6 +43,7 @@ NV, NE, NI = 9, 7, 17
 THETA_GROWTH = 2.0
 FILTER = 8
 TH_FILTER = 1e-4
+DUAL_CAP = 1.0
 MU_KAPPA = 30.0                                   # the barrier problem counts as solved at MU_KAPPA * mu
 D_DOWN, D_UP, A_HI, A_LO = 0.4, 3.0, 0.9, 0.2     # Levenberg parameter x D_DOWN after a step > A_HI, x D_UP after one <= A_LO
 THETA_FLOOR = 1e-5     # ... above 1e-5 per row (next to a feasible point twice nothing is nothing)   # a step may not more than double the l1 infeasibility, whatever it does to the objective
@@ -360,13 +361,14 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
             tht = np.abs(eqt).sum() + np.abs(gt.ravel() + stt).sum()
             pht = P.cost(wt) - mu * np.log(stt).sum()
             floor = THETA_FLOOR * N * (NE + NI)
+            eth, eph = 1e-13 * N * (NE + NI), 1e-13 * abs(ph0)     # what rounding alone moves the two sums by
             acc = np.isfinite(pht) and np.isfinite(tht) and tht <= max(THETA_GROWTH * th0, floor) + 1e-9 and \
-                (tht <= (1 - 1e-5) * th0 or pht <= ph0 - 1e-5 * th0)
+                (tht <= (1 - 1e-5) * th0 + eth or pht <= ph0 - 1e-5 * th0 + eph)
             # ... and, once nearly feasible (l1 infeasibility below TH_FILTER per row), acceptable to the (up to FILTER)
             # earlier iterates of this barrier problem: no cycling between two nearly feasible points
             if th0 < TH_FILTER * N * (NE + NI):
                 for (thf, phf) in filt[-FILTER:]:
-                    acc = acc and (tht <= (1 - 1e-5) * thf or pht <= phf - 1e-5 * thf)
+                    acc = acc and (tht <= (1 - 1e-5) * thf + eth or pht <= phf - 1e-5 * thf + eph)
             if acc:
                 ok = True
                 break
@@ -381,7 +383,7 @@ def solve(P, w0, max_iter=60, tol=1e-6, eps_reg=1e-8, delta0=1e-4, mu0=1e-1, ver
         filt.append((th0, ph0))     # the point just left joins the filter
         w = wt; s = stt.reshape(N, NI)
         y = y + a * dy
-        z = (zz + min(ad, 1.0) * dz).reshape(N, NI)
+        z = (zz + min(ad, 1.0, max(DUAL_CAP * a, 1e-3)) * dz).reshape(N, NI)   # the dual step does not outrun the primal one
         z = np.clip(z, mu / (1e10 * s), 1e10 * mu / s)
         # Levenberg parameter: a short step means the linearisation was not trusted that far
         delta = min(max(delta * (D_DOWN if a > A_HI else (1.0 if a > A_LO else D_UP)), 1e-6), 1e3)

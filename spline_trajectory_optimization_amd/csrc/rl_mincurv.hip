@@ -1098,6 +1098,10 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     st.d_down = knob("RL_MT_D_DOWN", 0.4); st.d_up = knob("RL_MT_D_UP", 3.0);
     st.a_hi = knob("RL_MT_A_HI", 0.9); st.a_lo = knob("RL_MT_A_LO", 0.2);
     st.mu_fac = knob("RL_MT_MU_FAC", 0.2); st.mu_pow = knob("RL_MT_MU_POW", 1.5); st.mu_kappa = knob("RL_MT_MU_KAPPA", 30.0);
+    // dual step length <= dual_cap x primal step length (0 = uncoupled): with 1 all 768 instances of tools/mintime_robustness.py
+    // converge (750 uncoupled: the multipliers ran away while the primal step was cut to a few per cent), at 82 instead of 78
+    // iterations on the benchmark batch
+    st.dual_cap = knob("RL_MT_DUAL_CAP", 1.0);
     st.th_filter = knob("RL_MT_TH_FILTER", 1e-4);   // 2e-5 .. 1e-3 all converge for mu0 = 0.05, 0.1, 0.2; 1e-2 blocks the early phase
   }
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));

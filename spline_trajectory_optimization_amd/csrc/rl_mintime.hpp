@@ -196,7 +196,7 @@ struct MtState {       // per-batch device arrays, instance-major
                   //        2 failed), 6 iterations, 7 last alpha, 8 theta0, 9 phi0, 10 refactorisations, 11 lap time
   double tol;
   // strategy constants (defaults in rl_mincurv.hip; the RL_MT_* environment switches exist for experiments)
-  double d_down, d_up, a_hi, a_lo, mu_fac, mu_pow, mu_kappa, th_filter;
+  double d_down, d_up, a_hi, a_lo, mu_fac, mu_pow, mu_kappa, th_filter, dual_cap;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1263,14 +1263,16 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
     // 1e-5 per row: next to a feasible point (theta0 ~ 0) the second-order infeasibility of any useful step is larger
     // than twice nothing, and without the floor such instances crept along with two halvings per iteration
     const double floor_ = kMtThetaFloor * (double)(N * kMtNf);
+    // eth, eph: what rounding alone moves the two sums by (next to the solution the improvement asked for is smaller)
+    const double eth = 1e-13 * (double)(N * kMtNf), eph = 1e-13 * fabs(phi0);
     bool acc = fin && theta <= fmax(kMtThetaGrowth * theta0, floor_) + 1e-9 &&
-               (theta <= (1.0 - 1e-5) * theta0 || phi <= phi0 - 1e-5 * theta0);
+               (theta <= (1.0 - 1e-5) * theta0 + eth || phi <= phi0 - 1e-5 * theta0 + eph);
     // ... and once the iterate is nearly feasible (l1 infeasibility below th_filter per row) the step must be acceptable
     // to the earlier iterates of this barrier problem as well: otherwise two points, one of less infeasibility and
     // one of less objective, can be visited in turn for ever (seen on a few of 1024 instances).  Far from feasibility
     // the iteration legitimately trades one for the other, and a filter there would need a restoration phase.
     for (int e = 0; e < nfilt && acc && theta0 < st.th_filter * (double)(N * kMtNf); ++e)
-      acc = theta <= (1.0 - 1e-5) * filt[2 * e] || phi <= filt[2 * e + 1] - 1e-5 * filt[2 * e];
+      acc = theta <= (1.0 - 1e-5) * filt[2 * e] + eth || phi <= filt[2 * e + 1] - 1e-5 * filt[2 * e] + eph;
     if (acc) { ok = true; halvings = trial; break; }
     a *= 0.5;
   }
@@ -1281,7 +1283,7 @@ __global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
     if (tid == 0) { scal[1] = delta; scal[7] = 0.0; scal[6] += 1.0; if (delta > 1e6) scal[5] = 2.0; }
     return;
   }
-  const double az = fmin(ad, 1.0);
+  const double az = st.dual_cap > 0.0 ? fmin(fmin(ad, 1.0), fmax(st.dual_cap * a, 1e-3)) : fmin(ad, 1.0);
   for (int idx = tid; idx < N * kMtNv; idx += 256) w[idx] += a * dw[idx];
   for (int idx = tid; idx < N * kMtNe; idx += 256) yv[idx] += a * dy[idx];
   for (int idx = tid; idx < N * kMtNi; idx += 256) {

@@ -34,6 +34,32 @@ def mgkt_problem(interval=1.0):
                                "average_track_width": 7.0, "speed_cap": 30.0})
 
 
+def variant_problem(track, interval, model_changes=None):
+    """One cell of the robustness matrix (tools/mintime_robustness.py): `track` in ("mgkt", "monza"), node spacing
+    [m], factors applied to entries of the yaml's model (e.g. {"mu": 0.7}); the QSS warm start stays the kart's."""
+    from .. import batch
+    est = defaults.ESTIMATES
+    model = dict(defaults.MODEL)
+    for key, fac in (model_changes or {}).items():
+        model[key] = defaults.MODEL[key] * fac
+    if track == "mgkt":
+        rt = RaceTrack("MGKT", load_mgkt("MGKT_OUT_BOUND_enu.csv"), load_mgkt("MGKT_IN_BOUND_enu.csv"),
+                       load_mgkt("MGKT_CENTER_enu.csv"), s=1.0, interval=interval)
+        width = 7.0
+    else:
+        centre, left, right = batch.load_monza()
+        rt = RaceTrack("Monza", left, right, centre, s=10.0, interval=interval)
+        width = 10.0
+    veh = Vehicle(VehicleParams(np.array(est["acc_speed_loopup"]), np.array(est["dcc_speed_lookup"]), est["max_lon_acc_mpss"],
+                                est["max_lon_dcc_mpss"], est["max_left_acc_mpss"], est["max_right_acc_mpss"],
+                                est["max_speed_mps"], est["max_jerk_mpsc"]))
+    traj = rt.center_d.copy()
+    rt.fill_trajectory_boundaries(traj)
+    traj = Simulator(veh).run_simulation(traj, False).trajectory
+    return DoubleTrackProblem({"N": len(traj), "model": model, "race_track": rt, "traj_d": traj, "average_track_width": width,
+                               "speed_cap": 30.0})
+
+
 def perturbed_widths(prob, B, seed=1234):
     """[B, N] left / right distances: every track scaled by its own factor in [0.9, 1.15)."""
     e = np.random.default_rng(seed).uniform(-0.1, 0.15, size=(B, 1))

@@ -220,6 +220,24 @@ def test_monza_from_the_qss_guess():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("track,interval,changes", [("mgkt", 4.0, {"mu": 0.7}), ("mgkt", 8.0, {"mu": 0.7}),
+                                                    ("monza", 10.0, {"Pmax": 2.0}), ("monza", 5.0, {})])
+def test_hard_cells_of_the_robustness_matrix(track, interval, changes):
+    """Coarse grids, tracks 25 % narrower to 30 % wider, a model that no longer matches the QSS guess (less friction,
+    twice the power): the cells of tools/mintime_robustness.py in which the multipliers used to run away while the
+    primal step was cut to a few per cent (the dual step length is now tied to the primal one).  All converge."""
+    from spline_trajectory_optimization_amd.min_time_optm.example import variant_problem
+    prob = variant_problem(track, interval, changes)
+    B = 32
+    e = np.random.default_rng(7).uniform(-0.25, 0.3, size=(B, 1))
+    X, U, T, st = prob.solve_batch(prob.left[None] * (1 + e), prob.right[None] * (1 + e), max_iter=300, tol=1e-6)
+    print(f"[{track} {interval} m {changes}] N={prob.N}: iterations {st[:, 0].min():.0f}..{st[:, 0].max():.0f}, "
+          f"converged {int((st[:, 5] == 1).sum())}/{B}, lap {st[:, 4].min():.2f}..{st[:, 4].max():.2f} s")
+    assert (st[:, 5] == 1.0).all(), np.where(st[:, 5] != 1.0)[0]
+    assert max(st[:, 1].max(), st[:, 2].max(), st[:, 3].max()) <= 1e-6
+
+
+@pytest.mark.gpu
 def test_width_perturbed_batch_at_full_resolution_all_converge():
     """BASELINE config 2's perturbation applied to config 5 at the example's own resolution (MGKT, 828 nodes): every
     instance of the batch reaches the 1e-6 tolerance (the globalisation once left 1 - 2 % of such batches creeping or
