@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(64) k_mt_prepare(MtProblem P, MtState st) {
 //   E_j = M[j+1][j] = [[C(j) + H_cost off-diagonal, An(j)'], [0, 0]]
 //   r_j = -[ gc_j + Ao(j)' y_j + An(j-1)' y_{j-1} + Go(j)' zeta_j + Gn(j-1)' zeta_{j-1} ;  eq_j ],
 //         zeta = mu / s + W (g + s)
-struct MtAsmLds { double Do[81], Dn[81], Ct[81], w[2][kMtNi], zeta[2][kMtNi]; };
+struct MtAsmLds { double Do[81], Dn[81], Ct[81], w[2][kMtNi], zeta[2][kMtNi], Go[kMtNi][kMtLoc], Gp[kMtNi][kMtNv]; };
 
 __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
   __shared__ MtAsmLds L;
@@ -860,14 +860,18 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
     L.w[which][i] = wgt;
     L.zeta[which][i] = mu / s_ + wgt * (fun[jj * kMtNf + kMtNe + i] + s_);
   }
+  // the inequality rows of this pair (all 18 columns) and of the previous pair (its "next node" columns) once into
+  // LDS, coalesced: the triple products below read every entry 9 to 18 times
+  for (int e = lane; e < kMtNi * kMtLoc; e += 64) L.Go[e / kMtLoc][e % kMtLoc] = Jo[kMtNe * kMtLoc + e];
+  for (int e = lane; e < kMtNi * kMtNv; e += 64) L.Gp[e / kMtNv][e % kMtNv] = Jp[(kMtNe + e / kMtNv) * kMtLoc + 9 + e % kMtNv];
   __syncthreads();
   for (int e = lane; e < 81; e += 64) {
     const int a = e / 9, c = e - 9 * a;
     double doo = Ho[a * kMtLoc + c], cno = Ho[(9 + a) * kMtLoc + c], dnn = Hp[(9 + a) * kMtLoc + 9 + c];
+#pragma unroll
     for (int i = 0; i < kMtNi; ++i) {
-      const double goa = Jo[(kMtNe + i) * kMtLoc + a], goc = Jo[(kMtNe + i) * kMtLoc + c];
-      const double gna = Jo[(kMtNe + i) * kMtLoc + 9 + a];
-      const double pna = Jp[(kMtNe + i) * kMtLoc + 9 + a], pnc = Jp[(kMtNe + i) * kMtLoc + 9 + c];
+      const double goa = L.Go[i][a], goc = L.Go[i][c], gna = L.Go[i][9 + a];
+      const double pna = L.Gp[i][a], pnc = L.Gp[i][c];
       doo += goa * L.w[0][i] * goc; cno += gna * L.w[0][i] * goc; dnn += pna * L.w[1][i] * pnc;
     }
     L.Do[e] = doo; L.Ct[e] = cno; L.Dn[e] = dnn;
@@ -898,8 +902,7 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
       const int a = lane;
       r = mt_cost_grad(w, N, j, a);
       for (int c = 0; c < kMtNe; ++c) r += Jo[c * kMtLoc + a] * yv[j * kMtNe + c] + Jp[c * kMtLoc + 9 + a] * yv[jp * kMtNe + c];
-      for (int c = 0; c < kMtNi; ++c)
-        r += Jo[(kMtNe + c) * kMtLoc + a] * L.zeta[0][c] + Jp[(kMtNe + c) * kMtLoc + 9 + a] * L.zeta[1][c];
+      for (int c = 0; c < kMtNi; ++c) r += L.Go[c][a] * L.zeta[0][c] + L.Gp[c][a] * L.zeta[1][c];
     } else {
       r = fun[j * kMtNf + (lane - 9)];
     }
