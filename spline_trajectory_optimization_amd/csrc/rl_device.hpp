@@ -224,7 +224,7 @@ constexpr int kWinChunks = 3;
 constexpr int kNear = 1;                        // chunks ce-kNear..ce+kNear are checked one by one
 constexpr int kWinEdges = kWinChunks * kChunk;  // 24; rings must be longer than twice this
 constexpr int kRingPad = kWinEdges + 1;         // vertices repeated behind the ring
-constexpr int kWinBatch = 6;
+constexpr int kWinBatch = 8;
 
 template <typename RingPtr>
 __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, double px, double py,
