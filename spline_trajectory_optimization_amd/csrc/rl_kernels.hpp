@@ -495,7 +495,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
   }
 
   // refresh(i0,i1,j0,j1): new p, normal and closest ring crossings for the samples of two ranges
-  auto refresh = [&](int i0, int i1, int j0, int j1, int mode) {
+  // l_first: the knot interval of sample i0 + tid if the caller has it already (the cost pass of the same step), else -1
+  auto refresh = [&](int i0, int i1, int j0, int j1, int mode, int l_first = -1) {
     const int m0 = i1 - i0, m1 = j1 - j0, m = m0 + m1;
     if (mode == 2) {
       // windowed, wave-cooperative search: a wave takes 64 consecutive samples and intersects
@@ -505,7 +506,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         const int r = wt * kWave + lane;
         const bool active = r < m;
         const int i = active ? (r < m0 ? i0 + r : j0 + (r - m0)) : (m0 > 0 ? i0 : j0);
-        const int l = tr.ell[i];
+        // the refresh of a step starts where its cost pass started: same thread, same sample, same knot interval --
+        // one dependent look-up less on the longest chain of the step (9.52 -> 9.25 ms per 1024 solves)
+        const int l = (l_first >= 0 && wt == wave && r < m0) ? l_first : tr.ell[i];
         CurvePoint<K, 1> c;
         eval_sample<K, 1>(tr, cx, cy, i, l, c);
         double dx, dy, inv_s2;
@@ -885,8 +888,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         double hxx = 0.0, hyy = 0.0, gx = 0.0, gy = 0.0;
         double lox = -INFINITY, hix = INFINITY, loy = -INFINITY, hiy = INFINITY;
         bool bad = false;
+        int l_keep = -1;   // knot interval of this thread's first sample: the refresh of the same step needs it again
         for (int i = s0 + tid; i < s1 && !RL_ABLATE(a, 4); i += BLOCK) {
           const int l = tr.ell[i];
+          if (i == s0 + tid) l_keep = l;
           CurvePoint<K, 2> c;
           eval_sample<K, 2>(tr, cx, cy, i, l, c);
           const int aa = idx - l + K;
@@ -1002,7 +1007,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
             // outside the supports of idx and its alias; the reference re-samples everything after
             // every update (optimizer.py:286-288) and so does this instantiation.
             refresh(0, N, 0, 0, mode);
-          } else if (!RL_ABLATE(a, 1)) refresh(s0, s1, j0, j1, mode);
+          } else if (!RL_ABLATE(a, 1)) refresh(s0, s1, j0, j1, mode, l_keep);
           RL_STAMP(st_t1); RL_STAMP_ADD(4, st_t1, st_t0);
           __syncthreads();
           RL_STAMP(st_t0); RL_STAMP_ADD(5, st_t0, st_t1);
