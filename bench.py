@@ -194,18 +194,69 @@ def global_qp_leg(trk, d_widths, g, args, torch, with_cpu):
     return leg
 
 
-def mintime_leg(B):
+MFMA_F64_PEAK_GFLOPS = 78600.0  # v_mfma_f64_16x16x4_f64 runs at the FP64 vector rate on gfx950 (64 cycles per 2048 flops per SIMD)
+
+
+def mintime_leg(B, with_cpu):
     """Third leg (BASELINE configs[4]): the reference's min-time example (MGKT kart circuit, 828 nodes) as a
     batch of width-perturbed tracks through rl_mintime_solve_batch -- QSS warm start, then the interior-point SQP-type
-    iteration to KKT 1e-6.  Timed on the host around ONE call (copies included), outside the headline's region.  The
-    reference solves this NLP with IPOPT (absent here): there is no CPU number to put beside it."""
+    iteration to KKT 1e-6.  Timed on the host around ONE call (copies included), outside the headline's region.
+    roofline: EXECUTED FP64 flops per instance (rocprofv3 instruction-mix counters of the same batch, committed under
+    profiles/: not measured in this run) x B / wall against the FP64 vector peak, which is also what v_mfma_f64 reaches.
+    cpu_baseline: the CPU twin (oracle/sqp_twin.py, kind "port": the reference's IPOPT path needs casadi) timed for a few
+    iterations of the same N = 828 problem and scaled by the GPU run's mean iteration count."""
     try:
         from spline_trajectory_optimization_amd.min_time_optm.example import timed_batch_solve
         leg = timed_batch_solve(B)
         leg["solver_pinned_by"] = "CPU twin oracle/sqp_twin.py (tests/test_mintime.py); NLP functions by fixture G8"
-        return leg
     except Exception as e:   # the headline must not depend on this leg
         return {"error": f"{type(e).__name__}: {e}"}
+    try:
+        path = os.path.join(ROOT, "profiles", "mintime_counters_latest.json")
+        if os.path.exists(path):
+            c = json.load(open(path))
+            # flops scale with the iterations an instance runs: rescale the profiled batch's figure to this run's mean
+            flops_inst = c["fp64_flops_per_instance"] * leg["iterations_mean"] / c["iterations_mean"]
+            achieved = flops_inst * B / leg["wall_s"] / 1e9
+            nodes = leg.get("nodes", 828)
+            chain_us = c.get("kkt_avg_us")
+            leg["roofline"] = {
+                "bound": "fp64_vector", "achieved": achieved / 1e3, "peak": FP64_VECTOR_PEAK_GFLOPS / 1e3, "unit": "TFLOP/s",
+                "frac": achieved / FP64_VECTOR_PEAK_GFLOPS, "traffic": None,
+                "flops_per_instance": flops_inst, "flops_per_instance_iteration_node": flops_inst / leg["iterations_mean"] / nodes,
+                "flops_source": c["source"], "measured_in_run": False,
+                "mfma_f64_share_of_flops": c.get("fp64_flops_mfma_share"), "mfma_f64_peak_tflops": MFMA_F64_PEAK_GFLOPS / 1e3,
+                "dependent_chain": "k_mt_kkt eliminates the lap's block-tridiagonal KKT system node by node from both ends: "
+                                   f"(N-1)/2 = {(nodes - 1) // 2} sequential 16x16 block steps per call whatever the batch"
+                                   + (f"; measured {chain_us:.0f} us per call = {chain_us / ((nodes - 1) // 2):.1f} us per block step"
+                                      if chain_us else "")
+                                   + f" -> >= {leg['iterations_mean']:.0f} x that per solve: the floor under wall_s for small batches",
+                "actual_limiter": "FP64 VALU issue of the derivative kernels (transcendental / division sequences of the tyre model) "
+                                  "and the latency of the node-by-node elimination (DESIGN.md 3d)"}
+    except Exception as e:
+        leg["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+    if with_cpu:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from mintime_problem import mgkt_problem
+            from oracle import sqp_twin as tw
+            from spline_trajectory_optimization_amd.min_time_optm import defaults
+            d = mgkt_problem(1.0, defaults.ESTIMATES)
+            P = tw.Problem(defaults.MODEL, d["s"], d["kappa"], d["left"], d["right"], d["L"],
+                           defaults.SOLVER["average_track_width"], defaults.SOLVER["speed_cap"])
+            w0 = tw.initial_point(P, d["speed"], d["seg_time"])
+            iters = 5
+            t0 = time.perf_counter()
+            tw.solve(P, w0, max_iter=iters, tol=1e-6)
+            dt = time.perf_counter() - t0
+            per_solve = dt / iters * leg["iterations_mean"]
+            leg["cpu_baseline"] = {"value": 1.0 / per_solve, "unit": "NLP solves/s", "cores": 1, "kind": "port",
+                                   "sample": f"{iters} iterations of the CPU twin on the unperturbed N={P.N} problem ({dt:.1f} s), "
+                                             f"scaled to the GPU batch's mean of {leg['iterations_mean']:.1f} iterations per solve "
+                                             f"(twin and kernel take the same iterations to within one, tests/test_mintime.py)"}
+        except Exception as e:
+            leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return leg
 
 
 def valu_block(prof, kernel_ms):
@@ -280,6 +331,19 @@ def run_rank(args):
     b_monza = B if args.workload == "monza" else B - B // 2
     groups.append({"name": "monza", "t": t, "cx": cx, "cy": cy, "k": k, "length": line.get_length(),
                    "widths": batch.width_batch(wl, wr, b_monza, seed=1234 + rank)})
+    # Instances 0 and 3 of rank 0's Monza batch exist as a run of the REFERENCE's own loop (fixture G7b,
+    # tests/golden/make_golden.py): take their widths from the fixture bit for bit (the batch's own base widths come from
+    # this GPU's fill_bounds and agree with the fixture's to ~1e-10 m only), so that the result can be laid beside that run.
+    ref_run = {}
+    g7b_path = os.path.join(ROOT, "tests", "golden", "G7b_benchmarked_config.npz")
+    if rank == 0 and b_monza > 3 and os.path.exists(g7b_path):
+        g7b = np.load(g7b_path)
+        for key in [str(k_) for k_ in g7b["cases"] if "bench" in str(k_)]:
+            bi = int(key.split("bench")[1])
+            if np.abs(groups[0]["widths"][bi] - g7b[f"{key}_widths"]).max() < 1e-6 and \
+                    np.array_equal(g7b[f"{key}_i_start"], batch.default_i_start(len(cx), k, MAX_ITER, seed=0)):
+                groups[0]["widths"][bi] = g7b[f"{key}_widths"]
+                ref_run[bi] = (g7b[f"{key}_cx"], g7b[f"{key}_cy"])
     if args.workload == "mixed":
         oval = batch.oval_centerline(SPLINE_S, SPLINE_K)
         ot, ocx, ocy, ok_ = oval._tck()
@@ -377,6 +441,30 @@ def run_rank(args):
         assert np.isfinite(xy).all()
         assert np.array_equal(status, 2 * MAX_ITER * (g["n"] - g["k"]) - ns.reshape(bg, -1).sum(axis=1))
         xy_gpu.append(xy); ns_gpu.append(ns)
+        if gi == 0 and ref_run:
+            ctrl0 = last["ctrl"].cpu().numpy()
+            dev_ref = {bi: float(np.hypot(ctrl0[bi, :, 0] - rc[0], ctrl0[bi, :, 1] - rc[1]).max()) for bi, rc in ref_run.items()}
+
+    # N > 1: every rank's shard of EVERY group arrived on rank 0 unchanged -- each rank publishes two checksums of what it
+    # sent (sum, sum of squares: same reduction kernel on the same shape, so equal bytes give equal sums), rank 0 recomputes
+    # them on what it received.  Outside the timed region.
+    gather_check = None
+    if world > 1:
+        chk = torch.stack([torch.stack([g["out"][last_slot]["xy"].sum(), (g["out"][last_slot]["xy"] ** 2).sum(),
+                                        g["out"][last_slot]["status"].to(torch.float64).sum()]) for g in groups])
+        all_chk = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(all_chk, chk)
+        if rank == 0:
+            n_ok = 0
+            for gi, g in enumerate(groups):
+                bg = g["widths"].shape[0]
+                for r in range(world):
+                    shard = gathered[last_slot][gi][r * bg:(r + 1) * bg]
+                    got = torch.stack([shard.sum(), (shard ** 2).sum()])
+                    assert torch.equal(got, all_chk[r][gi, :2]), f"group {gi}: the shard of rank {r} changed in the gather"
+                    n_ok += 1
+            gather_check = {"groups": len(groups), "ranks": world, "shards_equal": n_ok,
+                            "skipped_qps_per_rank": [[float(all_chk[r][gi, 2]) for gi in range(len(groups))] for r in range(world)]}
 
     if rank == 0:
         total_solves = world * B * args.steps
@@ -404,7 +492,8 @@ def run_rank(args):
                 "spline": f"s={SPLINE_S:g} k={SPLINE_K} n={[g['n'] for g in groups]}", "batch_per_gpu": B,
                 "control_point_qps_per_s": qps_per_step * world * args.steps / elapsed, "search": args.search,
                 "parallelism": f"{world} rank(s) x independent instances"
-                               + (f", 1 gather to rank 0 per step and group over {'gloo (test hook)' if args.share_gpu else 'RCCL'}"
+                               + (f", 1 gather to rank 0 per step and group over torch.distributed backend "
+                                  f"'{dist.get_backend()}' ({'gloo: --share-gpu test hook' if args.share_gpu else 'nccl = RCCL over xGMI'})"
                                   f" (overlapped with the next step), world size {dist.get_world_size()}" if world > 1 else ""),
                 "lds_bytes_per_workgroup": int(stats.lds_bytes), "block_threads": int(stats.block_threads),
             },
@@ -420,13 +509,24 @@ def run_rank(args):
                                            "is not HBM bound (DESIGN.md section 3)",
                          "valu": valu_block(prof, kernel_ms)},
         }
+        if gather_check is not None:
+            res["gather_check"] = gather_check
         if world == 1 and args.workload == "monza" and not args.no_global:
             res["global_qp"] = global_qp_leg(groups[0]["trk"], groups[0]["d_widths"], groups[0], args, torch,
                                              with_cpu=not args.no_cpu_baseline)
         if world == 1 and args.workload == "monza" and not args.no_mintime:
-            res["mintime_nlp"] = mintime_leg(args.mintime_batch)
+            res["mintime_nlp"] = mintime_leg(args.mintime_batch, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
+        if ref_run:
+            res["gpu_vs_reference_run"] = {
+                "what": "instances of THIS batch that also exist as a run of the reference's own run_min_curvature_qp loop "
+                        "(fixture tests/golden/G7b_benchmarked_config.npz: same widths bit for bit, same sweep order); "
+                        "max control-point deviation [m]",
+                "instances": sorted(dev_ref), "dev_m": [dev_ref[b_] for b_ in sorted(dev_ref)],
+                "within_1e-4": int(sum(v <= 1e-4 for v in dev_ref.values())),
+                "note": "an instance outside 1e-4 m must be one the oracle's re-roundings certify as ill-conditioned "
+                        "(cpu_baseline.gpu_vs_oracle; tests/test_hip_parity.py::test_benchmarked_configuration_vs_reference_run)"}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

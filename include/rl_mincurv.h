@@ -19,7 +19,14 @@
  *   - device memory is owned by the context: host entry points stage through a pool of blocks that is
  *     reused from call to call (a repeated call of the same shape allocates nothing), the *_dev entry
  *     points of the simulator and the min-time solve carve their work arrays out of one grow-only arena;
- *     both are released by rl_ctx_destroy.  One context = one stream = one caller at a time;
+ *     both are released by rl_ctx_destroy.  One context = one caller at a time.  The stream of a context may be
+ *     changed between calls (rl_ctx_set_stream): the *_dev calls that use the arena order themselves behind the
+ *     previous user of the arena with an event when the stream has changed, so two such calls enqueued on different
+ *     streams without a host synchronisation in between run one after the other, never on the same scratch at once;
+ *   - the only environment variables the product library reads are RL_GLOBAL_V1, RL_MT_HES_SWEEP, RL_MT_GROUPS (test
+ *     hooks selecting a second implementation, read once in rl_ctx_create) and RL_FORCE_RESIDENCY / RL_FORCE_GLOBAL_RINGS
+ *     (residency of the sweep's per-instance state; all variants are bit-identical): INTEGRATION.md lists them.  Solver
+ *     strategy constants are compile-time; RL_MT_* / RL_DEBUG_FLAGS overrides exist only in a -DRL_ABLATION diagnostic build;
  *   - there is NO CPU fallback: without a usable HIP device rl_ctx_create fails.
  */
 #ifndef RL_MINCURV_H
@@ -63,7 +70,8 @@ typedef struct rl_stats {
 int rl_version(void);
 /* Test aids (no effect on results).  rl_debug_dump_enable(m), m > 0: the next sweep calls record what
  * they assembled and decided -- the sliding-window variant for instance 0, per window (48 header doubles
- * + 9 per row, tests/test_hip_parity.py::test_joint_window_qps_replayed); the degree-5 sweep for the first
+ * + 9 per row of 768 rows + the control points the window started from, cx[n], cy[n];
+ * tests/test_hip_parity.py::test_joint_window_qps_replayed, ::test_joint_windows_teacher_forced); the degree-5 sweep for the first
  * min(m, B) instances, per step: [idx, H_xx, H_yy, g_x, g_y, lo_x, hi_x, lo_y, hi_y, zero-row flag,
  * accepted, new x, new y, 3 reserved] + the control points the step started from, cx[n], cy[n]
  * (tests/test_sweep_replay.py re-derives every step with the oracle from those control points).
@@ -189,7 +197,8 @@ int rl_mincurv_global_batch_host(rl_ctx* ctx, const rl_track* trk, const double*
  * curvilinear frame), :143-204 (add_constraints: Hermite-Simpson defect, tyre ellipses, load
  * transfer, actuator limits) and min_time_optimizer.py:93-163 (node pairing i-1 -> i, curvature at the
  * left node, abscissa pin, lateral bounds, objective) in PHYSICAL units (the reference's variable
- * scaling, :109-113, is the caller's).  The solve itself is not part of this library yet.
+ * scaling, :109-113, is the caller's).  The solve on these functions is rl_mintime_solve_batch[_dev] below; this
+ * entry point evaluates a given point (used to CHECK solutions against the reference's own functions, fixture G8).
  *   model   [RL_DT_NPARAM] in the order of rl_dt_param
  *   s, kappa, left (> 0), right (< 0): [N] abscissa, centre-line curvature, boundary distances
  *   X [B,N,6] = s, n, xi, omega, beta, v    U [B,N,4] = force, unused, delta, gamma_y    T [B,N]

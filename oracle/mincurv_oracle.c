@@ -1072,6 +1072,127 @@ void orc_run_joint_min_curvature_qp(const double* t, int nt, double* cx, double*
   free(ti); free(bj); free(lx); free(Ax); free(u);
 }
 
+/* ---------------------------------------------------------------- teacher-forced replay of sliding windows
+ * TEST INSTRUMENT (like orc_replay_steps): ONE window of run_joint_min_curvature_qp (optimizer.py:184-210) re-derived
+ * from control points supplied by the caller (the state the GPU kernel started that window from), so that a wrong
+ * window cannot hide behind the chaos of the windows before it.  Per window:
+ *   head[0..1]   status of the x / y QP on the rows as assembled (0 solved, 2 infeasible, 3 bad)
+ *   head[2]      number of samples OUTSIDE the union support that lie outside their own bound box (their rows read
+ *                0 in [l, u]; one such sample makes the window infeasible, optimizer.py:150-159)
+ *   head[3..4]   union support [u0, u1)
+ *   head[5..14]  new control points x[5], y[5] (when both QPs were solved)
+ *   head[15..34] hx[5], hy[5], gx[5], gy[5]   (joint_min_curvature_cost, :88-110)
+ *   head[35]     1 if the window is feasible with every bound RELAXED by eps_b (l - eps_b, u + eps_b), else 0
+ *   head[36]     1 if it is feasible with every bound TIGHTENED by eps_b, else 0
+ *   head[37..39] objective (x and y QP together) of the relaxed / tightened / as-assembled optimum (NaN if infeasible)
+ *   head[40]     smallest slack min(-l, u) over the zero rows (negative: a sample outside its box)
+ *   rows[N][9]   b_0..b_4, lx, ux, ly, uy for every sample (:129-159)
+ * eps_b = 8 * 2^-52 * 2048 m is the absolute rounding noise of a bound of an O(1e3) m coordinate (as orc_replay_steps).
+ * Any implementation whose rows agree with these to eps_b must find the window feasible if the tightened problem is,
+ * infeasible if the relaxed one is not, and an optimum whose objective lies between the two. */
+static double joint_objective(const double* h, const double* g, const double* x) {
+  double f = 0.0;
+  for (int j = 0; j < 5; ++j) f += 0.5 * h[j] * x[j] * x[j] + g[j] * x[j];
+  return f;
+}
+
+void orc_replay_joint_windows(const double* t, int nt, int k, int N, const double* ringL, int nL,
+                              const double* ringR, int nR, int n_win, const int* kks,
+                              const double* cxs /*[n_win][n]*/, const double* cys /*[n_win][n]*/,
+                              double* head /*[n_win][ORC_JREPLAY_HEAD]*/, double* rows /*[n_win][N][9]*/, int nthreads) {
+  const int span = 5, n = nt - k - 1;
+  const double eps_b = 8.0 * 2.220446049250313e-16 * 2048.0;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int w = 0; w < n_win; ++w) {
+    const double* cx = cxs + (size_t)w * n;
+    const double* cy = cys + (size_t)w * n;
+    const int kk = kks[w];
+    double* o = head + (size_t)w * ORC_JREPLAY_HEAD;
+    double* R = rows + (size_t)w * N * 9;
+    for (int q = 0; q < ORC_JREPLAY_HEAD; ++q) o[q] = 0.0;
+    double* points = (double*)calloc((size_t)N * ORC_NCOL, sizeof(double));
+    double* u = (double*)malloc((size_t)N * sizeof(double));
+    double* Ax = (double*)calloc((size_t)N * span, sizeof(double));
+    double* lx = (double*)malloc((size_t)N * 8 * sizeof(double));
+    double *ux = lx + N, *ly = lx + 2 * N, *uy = lx + 3 * N;
+    double *l2 = lx + 4 * N, *u2 = lx + 5 * N;
+    double* bj = (double*)malloc((size_t)N * sizeof(double));
+    double* ti = (double*)malloc((size_t)N * sizeof(double));
+    for (int i = 0; i < N; ++i) u[i] = grid_u(i, N);
+    orc_trajectory_init(points, N);
+    sample_geometry(t, nt, cx, cy, k, u, N, points);                  /* :207 of the previous window */
+    orc_fill_bounds(points, N, ringL, nL, ringR, nR, 100.0);          /* :210 */
+    double hx[5], hy[5], gx[5], gy[5], zx[5], zy[5];
+    for (int j = 0; j < span; ++j) {
+      double z0[2] = {cx[kk + j], cy[kk + j]}, H[4], g[2];
+      orc_min_curvature_cost(z0, kk + j, t, nt, cx, cy, k, N, H, g);
+      hx[j] = H[0]; hy[j] = H[3]; gx[j] = g[0]; gy[j] = g[1];
+      zx[j] = z0[0]; zy[j] = z0[1];
+      o[15 + j] = hx[j]; o[20 + j] = hy[j]; o[25 + j] = gx[j]; o[30 + j] = gy[j];
+    }
+    int u0 = N, u1 = 0;
+    for (int j = 0; j < span; ++j) {
+      int i0, i1;
+      support_range(t, k, kk + j, N, &i0, &i1);
+      int M = i1 - i0;
+      if (j == 0) u0 = i0;
+      if (j == span - 1) u1 = i1;
+      for (int q = 0; q < M; ++q) ti[q] = grid_u(i0 + q, N);
+      if (M > 0) orc_basis_element(t + kk + j, k, ti, M, 0, bj);
+      for (int q = 0; q < M; ++q) Ax[(size_t)(i0 + q) * span + j] = bj[q];
+    }
+    o[3] = (double)u0; o[4] = (double)u1;
+    int n_out = 0;
+    double zslack = INFINITY;
+    for (int s = 0; s < N; ++s) {
+      const double* p = points + (size_t)s * ORC_NCOL;
+      double azx = 0.0, azy = 0.0, nn = 0.0;
+      for (int j = 0; j < span; ++j) {
+        const double a = Ax[(size_t)s * span + j];
+        azx += a * zx[j]; azy += a * zy[j]; nn += a * a;
+        R[(size_t)s * 9 + j] = a;
+      }
+      double nzx = p[ORC_X] - azx, nzy = p[ORC_Y] - azy; /* :148 */
+      lx[s] = fmin(p[ORC_LBX], p[ORC_RBX]) - nzx; ux[s] = fmax(p[ORC_LBX], p[ORC_RBX]) - nzx;
+      ly[s] = fmin(p[ORC_LBY], p[ORC_RBY]) - nzy; uy[s] = fmax(p[ORC_LBY], p[ORC_RBY]) - nzy;
+      R[(size_t)s * 9 + 5] = lx[s]; R[(size_t)s * 9 + 6] = ux[s]; R[(size_t)s * 9 + 7] = ly[s]; R[(size_t)s * 9 + 8] = uy[s];
+      if (nn == 0.0) {
+        const double sl = fmin(fmin(-lx[s], ux[s]), fmin(-ly[s], uy[s]));
+        if (sl < zslack) zslack = sl;
+        if ((s < u0 || s >= u1) && sl < 0.0) ++n_out;
+      }
+    }
+    o[2] = (double)n_out; o[40] = zslack;
+    double nx_[5], ny_[5];
+    const int stx = orc_qp_diag_rows(span, hx, gx, N, Ax, lx, ux, nx_, NULL);
+    const int sty = orc_qp_diag_rows(span, hy, gy, N, Ax, ly, uy, ny_, NULL);
+    o[0] = (double)stx; o[1] = (double)sty;
+    o[39] = NAN;
+    if (stx == 0 && sty == 0) {
+      for (int j = 0; j < span; ++j) { o[5 + j] = nx_[j]; o[10 + j] = ny_[j]; }
+      o[39] = joint_objective(hx, gx, nx_) + joint_objective(hy, gy, ny_);
+    }
+    for (int variant = 0; variant < 2; ++variant) {   /* 0: relaxed, 1: tightened */
+      const double e = variant == 0 ? eps_b : -eps_b;
+      double f = 0.0;
+      int ok = 1;
+      for (int c = 0; c < 2 && ok; ++c) {
+        const double* lo = c ? ly : lx; const double* hi = c ? uy : ux;
+        for (int s = 0; s < N; ++s) { l2[s] = lo[s] - e; u2[s] = hi[s] + e; }
+        double xx[5];
+        if (orc_qp_diag_rows(span, c ? hy : hx, c ? gy : gx, N, Ax, l2, u2, xx, NULL) != 0) ok = 0;
+        else f += joint_objective(c ? hy : hx, c ? gy : gx, xx);
+      }
+      o[35 + variant] = (double)ok;
+      o[37 + variant] = ok ? f : NAN;
+    }
+    free(ti); free(bj); free(lx); free(Ax); free(u); free(points);
+  }
+}
+
 /* ---------------------------------------------------------------- global min-curvature QP (own formulation) */
 
 /* NOT a restatement of reference code: the reference's only global formulation is the Julia notebook

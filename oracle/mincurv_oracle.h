@@ -150,6 +150,12 @@ void orc_solve_width_batch_seeded(const double* t, int nt, const double* cx0, co
                                   double* kappa, const unsigned long long* seeds);
 
 /* Teacher-forced replay of recorded sweep steps (see the comment block in mincurv_oracle.c). */
+/* teacher-forced replay of sliding windows (test instrument, see mincurv_oracle.c) */
+#define ORC_JREPLAY_HEAD 48
+void orc_replay_joint_windows(const double* t, int nt, int k, int N, const double* ringL, int nL,
+                              const double* ringR, int nR, int n_win, const int* kks,
+                              const double* cxs, const double* cys, double* head, double* rows, int nthreads);
+
 #define ORC_REPLAY_STRIDE 20
 void orc_width_rings(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
                      const double* widths, double* ringL, double* ringR);

@@ -157,8 +157,9 @@ def qp_solve_separable(H, g, A, lba, uba):
     return st, x
 
 
-def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None):
-    """Returns (cx, cy, points[N,19], n_success[max_iter,2])."""
+def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None, rerounding=0):
+    """Returns (cx, cy, points[N,19], n_success[max_iter,2]).  rerounding: seed of mincurv_oracle.c:
+    orc_set_rerounding for this run (0 = the unperturbed oracle)."""
     t, tp = _d(t)
     cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
     ringL, lp = _d(ringL); ringR, rp = _d(ringR)
@@ -168,9 +169,16 @@ def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_ite
     lib().orc_trajectory_init(pts.ctypes.data_as(_dp), N)
     ns = np.zeros(2 * max_iter, dtype=np.int32)
     lib().orc_reset_kappa()
-    lib().orc_run_min_curvature_qp(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k),
-                                   float(length), pts.ctypes.data_as(_dp), int(N), lp, len(ringL),
-                                   rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
+    setr = lib().orc_set_rerounding
+    setr.argtypes = [ctypes.c_ulonglong]
+    setr.restype = None
+    setr(int(rerounding))                      # thread-local in the oracle
+    try:
+        lib().orc_run_min_curvature_qp(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k),
+                                       float(length), pts.ctypes.data_as(_dp), int(N), lp, len(ringL),
+                                       rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
+    finally:
+        setr(0)
     return cx, cy, pts, ns.reshape(max_iter, 2)
 
 
@@ -295,3 +303,24 @@ def replay_steps(t, k, N, ringL, ringR, idx, cxs, cys, nthreads=8):
     f.restype = None
     f(tp, len(t), int(k), int(N), lp, len(ringL), rp, len(ringR), S, ip, xp, yp, out.ctypes.data_as(_dp), int(nthreads))
     return out
+
+
+JREPLAY_HEAD = 48
+
+
+def replay_joint_windows(t, k, N, ringL, ringR, kks, cxs, cys, nthreads=8):
+    """Teacher-forced re-derivation of sliding windows (mincurv_oracle.c: orc_replay_joint_windows).
+    kks [W] first control point of each window, cxs/cys [W,n] = the control points BEFORE each window.
+    Returns (head [W, JREPLAY_HEAD], rows [W, N, 9])."""
+    t, tp = _d(t); ringL, lp = _d(ringL); ringR, rp = _d(ringR)
+    kks, ip = _i(kks); cxs, xp = _d(cxs); cys, yp = _d(cys)
+    W = len(kks)
+    assert cxs.shape == (W, len(t) - k - 1) and cys.shape == cxs.shape
+    head = np.zeros((W, JREPLAY_HEAD)); rows = np.zeros((W, N, 9))
+    f = lib().orc_replay_joint_windows
+    f.argtypes = [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int,
+                  ctypes.c_int, _ip, _dp, _dp, _dp, _dp, ctypes.c_int]
+    f.restype = None
+    f(tp, len(t), int(k), int(N), lp, len(ringL), rp, len(ringR), W, ip, xp, yp, head.ctypes.data_as(_dp),
+      rows.ctypes.data_as(_dp), int(nthreads))
+    return head, rows

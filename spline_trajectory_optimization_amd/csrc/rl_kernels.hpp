@@ -668,9 +668,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
             n_out_union += outside[i];
           }
         }
-        constexpr int DBG_STRIDE = 48 + 9 * kJointRowsPerThread * 256;
+        // test aid (rl_debug_dump_enable): per window 48 header doubles, 9 per row of the union support, then the control
+        // points the window STARTED from, cx[n], cy[n] (tests/test_hip_parity.py re-derives every window with the oracle)
+        const int DBG_ROWS = 48 + 9 * kJointRowsPerThread * 256, DBG_STRIDE = DBG_ROWS + 2 * n;
         double* dbg = (a.dbg && b == 0) ? a.dbg + (size_t)(it * (j_max - i_min) + stp) * DBG_STRIDE : nullptr;
         if (dbg) {
+          for (int j = tid; j < n; j += BLOCK) { dbg[DBG_ROWS + j] = cx[j]; dbg[DBG_ROWS + n + j] = cy[j]; }
 #pragma unroll
           for (int q = 0; q < RPT; ++q) {
             const int r_ = tid + q * BLOCK;
@@ -1065,6 +1068,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
 // appended at the end), so the propagation is sequential per instance: ONE lane per instance walks
 // the list (the other lanes of its wave do the embarrassingly parallel seeding and the time fill);
 // instances are the parallel axis.
+constexpr int kQssTabMax = 5 * 2 * 24 + 2;   // two tables of up to 24 cubic pieces each in the kernel arguments
+
 struct QssArgs {
   double* points;        // [B,N,19] in place
   int B, N;
@@ -1076,6 +1081,10 @@ struct QssArgs {
   double* cst;           // [B][3][N] scratch: segment length |p_i - p_{i-1}|, turn radius, 9.81 sin(bank)
   int cap;
   int* iters;            // [B] out: global iterations, -1 where the reference would have raised
+  // The lookup tables BY VALUE (acc_x [m+1], acc_c [4m], dcc_x [m'+1], dcc_c [4m'] back to back) when they fit: the
+  // launch then reads no host memory after the call returns.  tab_n = 0: the four pointers above are device arrays.
+  int tab_n;
+  double tab[kQssTabMax];
 };
 
 // scipy PPoly.evaluate (extrapolate=True): power basis summed from the constant term
@@ -1145,10 +1154,14 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
   constexpr int kFree = 0x7fffffff;
   const double lat0 = qss_acc_circle_lon(a, 0.0);
   for (int i = lane; i < kQssStamp; i += 64) STAMP[i] = kFree;
-  for (int i = lane; i <= a.acc_m; i += 64) t_ax[i] = a.acc_x[i];
-  for (int i = lane; i < 4 * a.acc_m; i += 64) t_ac[i] = a.acc_c[i];
-  for (int i = lane; i <= a.dcc_m; i += 64) t_dx[i] = a.dcc_x[i];
-  for (int i = lane; i < 4 * a.dcc_m; i += 64) t_dc[i] = a.dcc_c[i];
+  if (a.tab_n > 0) {
+    for (int i = lane; i < a.tab_n; i += 64) tab[i] = a.tab[i];      // same order as the LDS image
+  } else {
+    for (int i = lane; i <= a.acc_m; i += 64) t_ax[i] = a.acc_x[i];
+    for (int i = lane; i < 4 * a.acc_m; i += 64) t_ac[i] = a.acc_c[i];
+    for (int i = lane; i <= a.dcc_m; i += 64) t_dx[i] = a.dcc_x[i];
+    for (int i = lane; i < 4 * a.dcc_m; i += 64) t_dc[i] = a.dcc_c[i];
+  }
   for (int i = lane; i < N; i += 64) {  // simulator.py:133-147
     const double* p = P + (size_t)i * 19;
     const double* q = P + (size_t)(i == 0 ? N - 1 : i - 1) * 19;

@@ -27,7 +27,6 @@ thread_local std::string g_err;
 double* g_dbg_buf = nullptr;   // rl_debug_dump_enable: step / window dump of the sweep kernels (tests)
 size_t g_dbg_len = 0;
 int g_dbg_instances = 0;
-thread_local bool g_mt_poll = false;   // set by the host entry point of the min-time solve: poll for early exit
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -76,10 +75,17 @@ struct rl_ctx {
   // min-time solve carve their work arrays out of it, so that steady-state calls allocate nothing.
   void* arena = nullptr;
   size_t arena_cap = 0;
+  // The arena is handed out from offset 0 by every *_dev call, so two calls may only overlap in time if they are
+  // ordered on the device: each call records `arena_ev` behind its last use, and a call made after
+  // rl_ctx_set_stream switched to another stream first makes that stream wait for the event (Arena::begin).
+  hipEvent_t arena_ev = nullptr;
+  hipStream_t arena_stream = nullptr;
+  bool arena_busy = false;       // arena_ev has been recorded at least once
   // second in-order queue of the min-time solve (half batches side by side), forked from / joined into `stream`
   static constexpr int kMaxGroups = 4;
   hipStream_t aux_stream[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+  bool mt_poll = false;          // set by the HOST entry point of the min-time solve around its call of the _dev one: poll for early exit
   bool mt_hes_sweep = false;     // RL_MT_HES_SWEEP=1: the Hessian by k_mt_derivs<2> instead of the chain-rule kernels
   int mt_groups = 3;             // RL_MT_GROUPS=1..4 (measured at 256 / 1024 instances: 3.66 / 11.55 s, 3.31 / 11.05, 3.14 / 10.53, 3.11 / 10.59)
   // Device staging blocks of the HOST-pointer entry points (PoolBuf): handed out best-fit, returned at the end of
@@ -105,14 +111,21 @@ struct PoolBuf {
     const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
     int best = -1;
     for (int i = 0; i < (int)ctx->pool.size(); ++i)
-      if (!ctx->pool[i].used && ctx->pool[i].cap >= bytes && (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = i;
+      if (!ctx->pool[i].used && ctx->pool[i].cap >= bytes && ctx->pool[i].cap <= 4 * bytes + 4096 &&   // never park a small request on a huge block
+          (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = i;
     if (best < 0) {
       if (ctx->pool.size() >= 96) {   // shapes keep changing: drop what is idle before growing further
         for (auto& blk : ctx->pool)
           if (!blk.used && blk.p) { (void)hipFree(blk.p); blk.p = nullptr; blk.cap = 0; }
       }
       void* q = nullptr;
-      const hipError_t e = hipMalloc(&q, bytes);
+      hipError_t e = hipMalloc(&q, bytes);
+      if (e != hipSuccess) {          // out of memory: give back what is idle, then try once more
+        (void)hipGetLastError();
+        for (auto& blk : ctx->pool)
+          if (!blk.used && blk.p) { (void)hipFree(blk.p); blk.p = nullptr; blk.cap = 0; }
+        e = hipMalloc(&q, bytes);
+      }
       if (e != hipSuccess) return e;
       for (int i = 0; i < (int)ctx->pool.size() && best < 0; ++i)
         if (!ctx->pool[i].p) { ctx->pool[i] = {q, bytes, false}; best = i; }
@@ -127,7 +140,12 @@ struct PoolBuf {
     if (slot >= 0) ctx->pool[slot].used = false;
     slot = -1; p = nullptr; n = 0;
   }
-  ~PoolBuf() { release(); }
+  // Success paths end with a stream synchronisation, so the block is idle here.  An early error return does not: wait for
+  // whatever was already enqueued (copies into / out of this block) before the block can be handed to the next call.
+  ~PoolBuf() {
+    if (slot >= 0 && hipStreamQuery(ctx->stream) == hipErrorNotReady) (void)hipStreamSynchronize(ctx->stream);
+    release();
+  }
   PoolBuf(const PoolBuf&) = delete;
   PoolBuf& operator=(const PoolBuf&) = delete;
 };
@@ -137,9 +155,27 @@ struct Arena {
   rl_ctx* ctx; size_t off = 0;
   explicit Arena(rl_ctx* c) : ctx(c) {}
   static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+  // order this call behind the previous user of the arena if that one ran on another stream
+  hipError_t begin() {
+    if (!ctx->arena_ev) {
+      const hipError_t e = hipEventCreateWithFlags(&ctx->arena_ev, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    if (ctx->arena_busy && ctx->arena_stream != ctx->stream) return hipStreamWaitEvent(ctx->stream, ctx->arena_ev, 0);
+    return hipSuccess;
+  }
+  // record "the arena is free again once everything enqueued so far on the context's stream has run"
+  hipError_t end() {
+    const hipError_t e = hipEventRecord(ctx->arena_ev, ctx->stream);
+    if (e == hipSuccess) { ctx->arena_busy = true; ctx->arena_stream = ctx->stream; }
+    return e;
+  }
   hipError_t reserve(size_t bytes) {
+    hipError_t e = begin();
+    if (e != hipSuccess) return e;
     if (bytes <= ctx->arena_cap) return hipSuccess;
-    hipError_t e = hipStreamSynchronize(ctx->stream);          // nothing in flight may still use the old block
+    if (ctx->arena_busy) { e = hipEventSynchronize(ctx->arena_ev); if (e != hipSuccess) return e; }   // the last user, whatever its stream
+    e = hipStreamSynchronize(ctx->stream);                     // nothing in flight may still use the old block
     if (e != hipSuccess) return e;
     if (ctx->arena) (void)hipFree(ctx->arena);
     ctx->arena = nullptr; ctx->arena_cap = 0;
@@ -331,6 +367,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
 void rl_ctx_destroy(rl_ctx* ctx) {
   if (!ctx) return;
   if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->arena_ev) (void)hipEventDestroy(ctx->arena_ev);
   for (auto& blk : ctx->pool)
     if (blk.p) (void)hipFree(blk.p);
   for (int g = 0; g < rl_ctx::kMaxGroups - 1; ++g) {
@@ -646,7 +683,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
 #endif
   if (g_dbg_instances > 0 && (joint || k == 5)) {
     const int ninst = std::min(g_dbg_instances, B);
-    size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256)
+    size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256 + 2 * n)
                         : (size_t)ninst * max_iter * 2 * (size_t)(i_max - i_min) * (rl::kSweepDumpHead + 2 * n);
 #ifdef RL_STAMPS
     need = std::max(need, (size_t)B * 4 * 8);   // diagnostic build: per-wave phase stamps of every instance
@@ -935,19 +972,26 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   const size_t lds = ((size_t)2 * N + 5 * (acc_m + dcc_m) + 2) * sizeof(double) + (size_t)rl::kQssStamp * sizeof(int) +
                      (((size_t)N * sizeof(unsigned short) + 7) & ~(size_t)7);  // speed, lon acc, tables, stamp buckets, owner
   if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "qss: trajectory too long for the LDS-resident profile");
+  // The lookup tables are tiny host arrays (scipy CubicSpline pieces).  When they fit they travel BY VALUE in the kernel
+  // arguments, so the call is asynchronous and keeps no pointer to caller memory; longer tables are staged through the arena
+  // with pageable copies (the runtime then blocks the host until it has read them).
+  const int tab_n = (acc_m + 1) + 4 * acc_m + (dcc_m + 1) + 4 * dcc_m;
+  const bool by_value = tab_n <= rl::kQssTabMax;
   Arena ar(ctx);
-  RL_HIP(ar.reserve(Arena::pad((acc_m + 1) * 8) + Arena::pad((size_t)4 * acc_m * 8) + Arena::pad((dcc_m + 1) * 8) +
-                    Arena::pad((size_t)4 * dcc_m * 8) + Arena::pad((size_t)B * cap * 5 * 4) + Arena::pad((size_t)B * cap * 4) +
-                    Arena::pad((size_t)B * 3 * N * 8)));
-  double* dax = ar.take<double>(acc_m + 1); double* dac = ar.take<double>((size_t)4 * acc_m);
-  double* ddx = ar.take<double>(dcc_m + 1); double* ddc = ar.take<double>((size_t)4 * dcc_m);
+  RL_HIP(ar.reserve((by_value ? 0 : Arena::pad((acc_m + 1) * 8) + Arena::pad((size_t)4 * acc_m * 8) + Arena::pad((dcc_m + 1) * 8) +
+                                    Arena::pad((size_t)4 * dcc_m * 8)) +
+                    Arena::pad((size_t)B * cap * 5 * 4) + Arena::pad((size_t)B * cap * 4) + Arena::pad((size_t)B * 3 * N * 8)));
+  double *dax = nullptr, *dac = nullptr, *ddx = nullptr, *ddc = nullptr;
+  if (!by_value) {
+    dax = ar.take<double>(acc_m + 1); dac = ar.take<double>((size_t)4 * acc_m);
+    ddx = ar.take<double>(dcc_m + 1); ddc = ar.take<double>((size_t)4 * dcc_m);
+    RL_HIP(hipMemcpyAsync(dax, acc_x, (acc_m + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RL_HIP(hipMemcpyAsync(dac, acc_c, (size_t)4 * acc_m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RL_HIP(hipMemcpyAsync(ddx, dcc_x, (dcc_m + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RL_HIP(hipMemcpyAsync(ddc, dcc_c, (size_t)4 * dcc_m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
   int* dfl = ar.take<int>((size_t)B * cap * 5); int* dnw = ar.take<int>((size_t)B * cap);
   double* dcst = ar.take<double>((size_t)B * 3 * N);
-  // the lookup tables are tiny host arrays (scipy CubicSpline pieces): pageable copies are staged by the runtime
-  RL_HIP(hipMemcpyAsync(dax, acc_x, (acc_m + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RL_HIP(hipMemcpyAsync(dac, acc_c, (size_t)4 * acc_m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RL_HIP(hipMemcpyAsync(ddx, dcc_x, (dcc_m + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RL_HIP(hipMemcpyAsync(ddc, dcc_c, (size_t)4 * dcc_m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   rl::QssArgs a;
   a.points = points; a.B = B; a.N = N;
   a.acc_x = dax; a.acc_c = dac; a.acc_m = acc_m;
@@ -955,9 +999,19 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   a.max_lon_acc = params[0]; a.max_lon_dcc = params[1]; a.max_left_acc = params[2];
   a.max_right_acc = params[3]; a.max_speed = params[4]; a.max_jerk = params[5];
   a.flags = dfl; a.fresh = dnw; a.cst = dcst; a.cap = cap; a.iters = iters;
+  a.tab_n = 0;
+  if (by_value) {
+    double* q = a.tab;
+    for (int i = 0; i <= acc_m; ++i) *q++ = acc_x[i];
+    for (int i = 0; i < 4 * acc_m; ++i) *q++ = acc_c[i];
+    for (int i = 0; i <= dcc_m; ++i) *q++ = dcc_x[i];
+    for (int i = 0; i < 4 * dcc_m; ++i) *q++ = dcc_c[i];
+    a.tab_n = tab_n;
+  }
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_sim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(rl::k_qss_sim, dim3(B), dim3(64), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
+  RL_HIP(ar.end());
   return RL_OK;
 }
 
@@ -1091,10 +1145,17 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
   st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]);
   st.tol = tol;
+  double mt_mu0, mt_delta0;
   {
-    // measured on 1024 width-perturbed MGKT tracks (tools/mintime_knobs.sh): (d_up, a_lo, mu_kappa) = (5, 0.3, 10) 96.5
-    // iterations on average, (3, 0.2, 30) 77.8, every single change of d_down, mu_fac, mu_pow or mu0 worse or failing
+    // Strategy constants of the line search / barrier update.  Measured on 1024 width-perturbed MGKT tracks
+    // (tools/mintime_knobs.sh): (d_up, a_lo, mu_kappa) = (5, 0.3, 10) 96.5 iterations on average, (3, 0.2, 30) 77.8, every
+    // single change of d_down, mu_fac, mu_pow or mu0 worse or failing.  They are COMPILE-TIME constants of the product;
+    // only a diagnostic build (hipcc -DRL_ABLATION, tools/mintime_knobs.sh) reads RL_MT_* overrides from the environment.
+#ifdef RL_ABLATION
     auto knob = [](const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; };
+#else
+    auto knob = [](const char*, double dflt) { return dflt; };
+#endif
     st.d_down = knob("RL_MT_D_DOWN", 0.4); st.d_up = knob("RL_MT_D_UP", 3.0);
     st.a_hi = knob("RL_MT_A_HI", 0.9); st.a_lo = knob("RL_MT_A_LO", 0.2);
     st.mu_fac = knob("RL_MT_MU_FAC", 0.2); st.mu_pow = knob("RL_MT_MU_POW", 1.5); st.mu_kappa = knob("RL_MT_MU_KAPPA", 30.0);
@@ -1103,6 +1164,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     // iterations on the benchmark batch
     st.dual_cap = knob("RL_MT_DUAL_CAP", 1.0);
     st.th_filter = knob("RL_MT_TH_FILTER", 1e-4);   // 2e-5 .. 1e-3 all converge for mu0 = 0.05, 0.1, 0.2; 1e-2 blocks the early phase
+    mt_mu0 = knob("RL_MT_MU0", 1e-1); mt_delta0 = knob("RL_MT_DELTA0", 1e-4);
   }
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
   RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
@@ -1150,7 +1212,6 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     return hipSuccess;
   };
   const dim3 bn64(64);
-  const double mt_mu0 = getenv("RL_MT_MU0") ? atof(getenv("RL_MT_MU0")) : 1e-1, mt_delta0 = getenv("RL_MT_DELTA0") ? atof(getenv("RL_MT_DELTA0")) : 1e-4;
   for (int g = 0; g < ngrp; ++g) {
     const Grp& G = grp[g];
     const dim3 gn((N + 63) / 64, G.nb);
@@ -1180,7 +1241,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_step, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
     }
-    if (g_mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
+    if (ctx->mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
       std::vector<double> h((size_t)B * 16);
       RL_HIP(join());
       RL_HIP(hipMemcpyAsync(h.data(), st.scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1208,6 +1269,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   }
   RL_HIP(hipGetLastError());
   RL_HIP(join());
+  RL_HIP(ar.end());
   return RL_OK;
 }
 
@@ -1216,7 +1278,7 @@ int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const
                            double track_length, double average_track_width, double speed_cap, double* X, double* U,
                            double* T, int max_iter, double tol, double* stats) {
   if (!ctx || !model || !s || !kappa || !left || !right || !X || !U || !T || !stats) return fail(RL_ERR_ARG, "null argument");
-  if (B <= 0 || N < 4) return fail(RL_ERR_ARG, "bad sizes");
+  if (B <= 0 || N < 8) return fail(RL_ERR_ARG, "bad sizes (N >= 8 nodes)");
   RL_HIP(hipSetDevice(ctx->device));
   const size_t bn = (size_t)B * N, nb_ = bounds_per_instance ? bn : (size_t)N;
   for (size_t i = 0; i < nb_; ++i)
@@ -1227,10 +1289,10 @@ int rl_mintime_solve_batch(rl_ctx* ctx, const double* model, int B, int N, const
   auto up = [&](PoolBuf<double>& d, const double* h) { return hipMemcpyAsync(d.p, h, d.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream); };
   RL_HIP(up(ds, s)); RL_HIP(up(dk, kappa)); RL_HIP(up(dl, left)); RL_HIP(up(dr, right));
   RL_HIP(up(dX, X)); RL_HIP(up(dU, U)); RL_HIP(up(dT, T));
-  g_mt_poll = true;
+  ctx->mt_poll = true;
   const int rc = rl_mintime_solve_batch_dev(ctx, model, B, N, ds.p, dk.p, dl.p, dr.p, bounds_per_instance, margin, track_length,
                                             average_track_width, speed_cap, dX.p, dU.p, dT.p, max_iter, tol, dst.p);
-  g_mt_poll = false;
+  ctx->mt_poll = false;
   if (rc) return rc;
   RL_HIP(hipMemcpyAsync(X, dX.p, dX.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RL_HIP(hipMemcpyAsync(U, dU.p, dU.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

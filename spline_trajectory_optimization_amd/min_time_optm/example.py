@@ -75,7 +75,7 @@ def timed_batch_solve(B, max_iter=300, tol=1e-6):
     X, U, T, st = prob.solve_batch(left, right, max_iter=max_iter, tol=tol)
     dt = time.perf_counter() - t0
     return {"metric": "min-time double-track NLP solves/sec (MGKT, N=%d nodes, 9 unknowns + 7 equalities + 17 inequalities "
-                      "per node)" % prob.N, "value": B / dt, "unit": "NLP solves/s", "batch": B, "wall_s": dt,
+                      "per node)" % prob.N, "value": B / dt, "unit": "NLP solves/s", "batch": B, "nodes": int(prob.N), "wall_s": dt,
             "converged": int((st[:, 5] == 1).sum()), "iterations_mean": float(st[:, 0].mean()),
             "iterations_max": float(st[:, 0].max()), "kkt_max": float(st[:, 1].max()), "viol_max": float(st[:, 2].max()),
             "lap_s_min_max": [float(st[:, 4].min()), float(st[:, 4].max())], "tol": tol,

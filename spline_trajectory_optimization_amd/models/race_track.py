@@ -38,6 +38,14 @@ def _make_ring(xy):
         return Ring(xy)
 
 
+class _DMLike(np.ndarray):
+    """ndarray that also answers casadi.DM's `.full()`: the reference's CLI reads `frenet_to_global(...)[:, 2].full()`
+    (entrypoints/traj_opt_double_track.py:78)."""
+
+    def full(self):
+        return np.asarray(self)
+
+
 class RaceTrack:
     def __init__(self, name: str, left: np.ndarray, right: np.ndarray, centerline: np.ndarray,
                  s=10.0, interval=2.0) -> None:
@@ -92,7 +100,9 @@ class RaceTrack:
         yaw0 = self.yaw_intp(s)
         phi = yaw0 + np.asarray(xi, dtype=np.float64)
         phi = np.arctan2(np.sin(phi), np.cos(phi))                                                # align_yaw(., 0)
-        return np.stack([self.x_intp(s) - np.sin(yaw0) * t, self.y_intp(s) + np.cos(yaw0) * t, phi], axis=-1)
+        s, t = np.asarray(s, dtype=np.float64).reshape(-1), np.asarray(t, dtype=np.float64).reshape(-1)
+        return np.stack([self.x_intp(s) - np.sin(yaw0).reshape(-1) * t, self.y_intp(s) + np.cos(yaw0).reshape(-1) * t,
+                         phi.reshape(-1)], axis=-1).view(_DMLike)
 
     def fill_trajectory_boundaries(self, traj: Trajectory):
         """Fills the boundary properties of a trajectory in place (race_track.py:98-104)."""

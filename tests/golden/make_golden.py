@@ -75,6 +75,11 @@ def install_shims():
     sys.modules["importlib_resources"].files = lambda *a, **k: None
     sys.modules["importlib_resources"].as_file = lambda *a, **k: None
     sys.path.insert(0, REF)
+    # The reference's spline_traj_optm is a namespace package (no __init__.py); this repo's compatibility
+    # namespace of the same name (a regular package on ROOT) would win the import.  Pin the name to the reference.
+    pkg = types.ModuleType("spline_traj_optm")
+    pkg.__path__ = [os.path.join(REF, "spline_traj_optm")]
+    sys.modules["spline_traj_optm"] = pkg
 
 
 class Infeasible(Exception):
@@ -250,6 +255,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--fast", action="store_true", help="skip the slow N=500 end-to-end run")
+    ap.add_argument("--case", type=int, default=None, help="G7b only: run ONE case and write it to --out")
+    ap.add_argument("--out", default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present; fixtures are generated in the build container only")
@@ -265,6 +272,8 @@ def main():
     right = load_xy("MONZA_RIGHT_BOUNDARY_enu.csv")
 
     def want(tag):
+        if tag == "G7b":                 # ~6 CPU-minutes per case: only on request
+            return args.only == "G7b"
         return args.only is None or args.only == tag
 
     def save(name, **kw):
@@ -420,6 +429,76 @@ def main():
             kw[f"{key}_n_success"] = np.array(succ, dtype=np.int32).reshape(-1, 2)
             kw[f"{key}_cx"] = cx; kw[f"{key}_cy"] = cy
         save("G7_run_min_curvature_qp.npz", **kw)
+
+    # ---- G7b: run_min_curvature_qp (optimizer.py:256-341) AT THE BENCHMARKED CONFIGURATION (N = 2000, max_iter = 5),
+    # executed by the reference's own loop: three runs on the real Monza rings and two on instances of bench.py's own
+    # width-perturbed batch (rings p0 +- w n0, sweep order of batch.default_i_start(seed 0) = np.random.seed(0)).
+    # One subprocess per case (python make_golden.py --only G7b); ~6 minutes each.
+    if want("G7b"):
+        from spline_trajectory_optimization_amd import batch as amd_batch
+        cases = [("rings", 2000, 5, 11, -1), ("rings", 2000, 5, 12, -1), ("rings", 1929, 5, 13, -1),
+                 ("bench", 2000, 5, 0, 0), ("bench", 2000, 5, 0, 3)]
+        names = [f"c100_N{N}_it{it}_seed{sd}" + (f"_bench{b}" if kind == "bench" else "") for kind, N, it, sd, b in cases]
+        if args.case is None:
+            import subprocess
+            import tempfile
+            tmp = tempfile.mkdtemp()
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--only", "G7b", "--case", str(ci),
+                                       "--out", os.path.join(tmp, f"{ci}.npz")]) for ci in range(len(cases))]
+            assert all(p.wait() == 0 for p in procs)
+            kw = {"cases": np.array(names)}
+            for ci in range(len(cases)):
+                d = np.load(os.path.join(tmp, f"{ci}.npz"))
+                kw.update({k_: d[k_] for k_ in d.files})
+            save("G7b_benchmarked_config.npz", **kw)
+        else:
+            kind, N, max_iter, seed, b = cases[args.case]
+            key = names[args.case]
+            sp = fits["c100"][0].copy()
+            us = np.linspace(0.0, 1.0, N, endpoint=False)
+            td = sp.sample_along(ts=us)
+            trk = track
+            kw = {}
+            if kind == "bench":
+                t0_, cx0_, cy0_, k0_ = spl_arrays(sp)
+                base = td.copy() if hasattr(td, "copy") else td
+                track.fill_trajectory_boundaries(base)
+                wl, wr = amd_batch.half_widths_from_bounds(base.points)
+                w = amd_batch.width_batch(wl, wr, b + 1, seed=1234)[b]
+                rl, rr = orc.width_rings(t0_, cx0_, cy0_, k0_, N, w)
+                trk = types.SimpleNamespace(name="Monza", left_s=track.left_s, right_s=track.right_s, left_d=track.left_d,
+                                            right_d=track.right_d, ringL=rl, ringR=rr)
+                trk.fill_trajectory_boundaries = lambda traj: orc.fill_bounds(traj.points, rl, rr, 100.0)
+                kw[f"{key}_widths"] = w
+            o = ref_opt.TrajectoryOptimizer(trk, sp.copy(), veh)
+            old = np.geterr()
+            np.seterr(all="warn")
+            draws = []
+            real_randint = np.random.randint
+
+            def rec(*a, **k):
+                v = real_randint(*a, **k)
+                draws.append(int(v))
+                return v
+            np.random.seed(seed)
+            np.random.randint = rec
+            buf = io.StringIO()
+            t0 = time.time()
+            try:
+                with contextlib.redirect_stdout(buf):
+                    out = o.run_min_curvature_qp(sp, td, visualize=False, max_iter=max_iter)
+            finally:
+                np.random.randint = real_randint
+                np.seterr(**old)
+            succ = [int(x) for x in re.findall(r"successfully updated: (\d+)", buf.getvalue())]
+            print(f"G7b {key}: {time.time() - t0:.1f}s i_start={draws} successes={succ}", flush=True)
+            if kind == "bench":
+                assert draws == list(amd_batch.default_i_start(len(sp._spl_x.c), 5, max_iter, seed=0)), draws
+            t, cx, cy, k = spl_arrays(out)
+            kw[f"{key}_i_start"] = np.array(draws, dtype=np.int32)
+            kw[f"{key}_n_success"] = np.array(succ, dtype=np.int32).reshape(-1, 2)
+            kw[f"{key}_cx"] = cx; kw[f"{key}_cy"] = cy
+            np.savez_compressed(args.out, **kw)
 
     # ---- G8: the reference's double-track model, evaluated through the numeric casadi stand-in
     # (models/double_track.py:10-204, utils/utils.py:10-18, min_time_optm/min_time_optimizer.py:93-163)

@@ -201,3 +201,54 @@ def test_g10_files_written_by_the_reference(tmp_path, built):
     from spline_traj_optm.models.vehicle import Vehicle, VehicleParams  # noqa: F401
     from spline_traj_optm.optimization.optimizer import TrajectoryOptimizer  # noqa: F401
     from spline_traj_optm.simulator.simulator import Simulator  # noqa: F401
+
+
+def test_set_up_double_track_problem_returns_the_reference_contract():
+    """`(X, U, T), (scale_x, scale_u, scale_t), opti = set_up_double_track_problem(params)`
+    (min_time_optm/min_time_optimizer.py:163; consumed at entrypoints/traj_opt_double_track.py:56-69): handles,
+    scalings of :109-113, and an opti facade whose values are the reference's SCALED variables; the default initial
+    guess is :146-151 as written.  No GPU: solve() must fail loudly (no CPU fallback), the guess stays readable."""
+    import types
+    from spline_traj_optm.min_time_optm.min_time_optimizer import set_up_double_track_problem
+    from spline_trajectory_optimization_amd.min_time_optm import defaults
+    from spline_trajectory_optimization_amd.models.trajectory import Trajectory
+    N, L = 40, 200.0
+    s0 = np.arange(N) * (L / N)
+    rt = types.SimpleNamespace(abscissa=s0, center_s=types.SimpleNamespace(get_length=lambda: L),
+                               left_intp=lambda s: 4.0 + 0 * np.asarray(s), right_intp=lambda s: -3.5 + 0 * np.asarray(s),
+                               curvature_intp=lambda s: 2 * np.pi / L + 0 * np.asarray(s))
+    traj = Trajectory(N)
+    rng = np.random.default_rng(5)
+    traj[:, Trajectory.SPEED] = rng.uniform(5, 20, N); traj[:, Trajectory.TIME] = rng.uniform(0.2, 0.9, N)
+    params = {"N": N, "model": defaults.MODEL, "race_track": rt, "traj_d": traj, "average_track_width": 7.0,
+              "speed_cap": 30.0, "verbose": False, "max_iter": 500, "tol": 0.1}
+    (X, U, T), (scale_x, scale_u, scale_t), opti = set_up_double_track_problem(params)
+    assert X.shape == (N, 6) and U.shape == (N, 4) and T.shape == (N,)
+    m = defaults.MODEL
+    np.testing.assert_array_equal(np.ravel(scale_x), [1.0, 7.0, 1.0, 1.0, 0.5, 30.0])                     # :109
+    np.testing.assert_array_equal(np.ravel(scale_u), [m["Fd_max"], abs(m["Fb_max"]), m["delta_max"], m["mass"] * 50.0])
+    assert scale_t == 1.0
+    # the CLI's read-back (entrypoints/traj_opt_double_track.py:66-69) of the initial point = :146-151 as written
+    x = opti.debug.value(X) * scale_x + np.hstack([s0[:, np.newaxis], np.zeros((N, 5))])
+    u = opti.debug.value(U) * scale_u
+    t = opti.debug.value(T) * scale_t
+    np.testing.assert_allclose(x[:, 0], s0, rtol=0, atol=0)
+    assert not x[:, 1:5].any()
+    np.testing.assert_allclose(x[:, 5], traj[:, Trajectory.SPEED], rtol=1e-15)
+    np.testing.assert_allclose(u, np.tile([1.0, -1.0, 0.001, 0.0], (N, 1)), rtol=1e-15)
+    np.testing.assert_array_equal(t, traj[:, Trajectory.TIME])
+    # the build's own variant stays available as an explicit option
+    (_, _, T2), _, opti2 = set_up_double_track_problem(dict(params, initial_guess="clipped"))
+    np.testing.assert_array_equal(opti2.debug.value(T2), np.roll(traj[:, Trajectory.TIME], -1))
+    # x0 / u0 / t0 (:152-155)
+    x0 = x.copy(); x0[:, 1] = 0.3
+    (X3, _, _), _, opti3 = set_up_double_track_problem(dict(params, x0=x0, u0=u, t0=t.reshape(-1, 1)))
+    np.testing.assert_allclose(opti3.debug.value(X3)[:, 1], 0.3 / 7.0, rtol=1e-15)
+    opti.set_initial(T, 0.5 * np.ones(N))
+    assert (opti.value(T) == 0.5).all()
+    opti.solver("ipopt", {"expand": True}, {"max_iter": 7, "tol": 1e-3, "print_level": 0})                 # :158-161
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception, match="no HIP device|librl_mincurv"):
+            opti.solve()
+        assert opti.stats()["success"] is False

@@ -99,6 +99,17 @@ def test_mintime_solve_vs_twin(coarse):
     eq, g, cost = ops.dt_eval_nodes(P.m, P.s, P.kappa, P.left, P.right, P.margin, P.L, X, U, T)
     assert np.abs(eq[0, :, :6] / P.scale_x).max() <= 1e-6 and np.abs(eq[0, :, 6]).max() / P.scale_u[3] <= 1e-6
     assert np.abs(eq[0, :, 7]).max() == 0.0 and g[0, :, :4].max() <= 1e-6 and g[0, :, 12:].max() <= 1e-6
+    # ... ALL of them: 8 equalities and 14 inequality columns of rl_dt_eval_nodes, each in the reference's own scaling
+    # (power / Pmax, speed / speed_cap, forces / Fd_max, steering / delta_max; rates as the reference scales u)
+    m, sx, su = P.m, P.scale_x, P.scale_u
+    gs = np.array([1, 1, 1, 1, m["Pmax"], sx[5], su[0], su[0], su[2], su[2], su[0], su[2], sx[1], sx[1]])
+    worst = (g[0] / gs).max(axis=0)
+    print("scaled inequality maxima per column:", np.array2string(worst, precision=2))
+    assert (worst <= 1e-6).all(), worst
+    es = np.r_[P.scale_x, su[3], 1.0]
+    assert (np.abs(eq[0] / es).max(axis=0) <= 1e-6).all(), np.abs(eq[0] / es).max(axis=0)
+    # and the active set is not empty: power, tyre and track limits are what shapes a minimum-time lap
+    assert (worst[:5] >= -1e-3).any() and worst[12:].max() >= -1e-3
 
 
 @pytest.mark.gpu
@@ -304,3 +315,76 @@ def test_config5_chain_on_the_device(coarse):
     np.testing.assert_array_equal(X.cpu().numpy(), Xh); np.testing.assert_array_equal(T.cpu().numpy(), Th)
     np.testing.assert_array_equal(st.cpu().numpy()[:, :6], sth[:, :6])
     assert (sth[:, 5] == 1.0).all()
+
+
+@pytest.mark.gpu
+def test_cli_lines_against_the_facade(tmp_path):
+    """entrypoints/traj_opt_double_track.py:24-86 line by line against the mirror: RaceTrack, QSS warm start,
+    `(X, U, T), (scale_x, scale_u, scale_t), opti = set_up_double_track_problem(params)`, `opti.solve()` in try/except,
+    read-back through `opti.debug.value(.) * scale + offset`, frenet_to_global, bounds, distances, save_ttl.  (The
+    casadi.DM text dumps of :72, :83-86 are the caller's casadi; np.savetxt stands in.)  Coarser nodes than the yaml's
+    1 m so that the test stays short; the yaml's solver settings (max_iter 500, tol 0.1) and the reference's own default
+    initial guess (:146-151)."""
+    from mintime_problem import _load
+    from spline_traj_optm.min_time_optm import min_time_optimizer as optm
+    from spline_traj_optm.models.race_track import RaceTrack
+    from spline_traj_optm.models.trajectory import Trajectory, load_ttl, save_ttl
+    from spline_traj_optm.models.vehicle import Vehicle, VehicleParams
+    from spline_traj_optm.simulator.simulator import Simulator
+    params = {"interval": 4.0, "estimates": defaults.ESTIMATES, "model": defaults.MODEL, "verbose": False,
+              "max_iter": defaults.SOLVER["max_iter"], "tol": defaults.SOLVER["tol"],
+              "average_track_width": defaults.SOLVER["average_track_width"], "speed_cap": defaults.SOLVER["speed_cap"],
+              "output": str(tmp_path / "optm.ttl")}
+    interval = params["interval"]                                                                            # :23
+    race_track = RaceTrack("Test track", _load("MGKT_OUT_BOUND_enu.csv"), _load("MGKT_IN_BOUND_enu.csv"),
+                           _load("MGKT_CENTER_enu.csv"), s=1.0, interval=interval)                          # :24-31
+    traj_d = race_track.center_d.copy()
+    race_track.fill_trajectory_boundaries(traj_d)                                                            # :32-33
+    estimates = params["estimates"]                                                                          # :35-49
+    vp = VehicleParams(np.array(estimates["acc_speed_loopup"]), np.array(estimates["dcc_speed_lookup"]),
+                       estimates["max_lon_acc_mpss"], estimates["max_lon_dcc_mpss"], estimates["max_left_acc_mpss"],
+                       estimates["max_right_acc_mpss"], estimates["max_speed_mps"], estimates["max_jerk_mpsc"])
+    result = Simulator(Vehicle(vp)).run_simulation(traj_d, False)
+    traj_d = result.trajectory
+    params["N"] = len(traj_d); params["traj_d"] = traj_d; params["race_track"] = race_track                  # :54-56
+    (X, U, T), (scale_x, scale_u, scale_t), opti = optm.set_up_double_track_problem(params)                  # :58-59
+    try:
+        sol = opti.solve()                                                                                   # :60-63
+    except Exception as e:
+        sol = None
+        print(e)
+    x = opti.debug.value(X) * scale_x + np.hstack([race_track.abscissa[:, np.newaxis], np.zeros((len(traj_d), 5))])  # :65-66
+    u = opti.debug.value(U) * scale_u
+    t = opti.debug.value(T) * scale_t
+    print(f"[Optimal lap time: {np.sum(t) * scale_t}]  stats {opti.stats()}")                                # :70
+    opt_traj_d = traj_d.copy()                                                                               # :74-82
+    global_pose = race_track.frenet_to_global(x[:, 0].T, x[:, 1].T, x[:, 2].T)
+    opt_traj_d[:, 0:2] = global_pose[:, 0:2]
+    opt_traj_d[:, Trajectory.YAW] = global_pose[:, 2].full().squeeze()
+    opt_traj_d[:, Trajectory.SPEED] = x[:, 5]
+    race_track.fill_trajectory_boundaries(opt_traj_d)
+    opt_traj_d.fill_distance()
+    opt_traj_d.ttl_num, opt_traj_d.origin = 1, (0.0, 0.0, 0.0)
+    save_ttl(params["output"], opt_traj_d)
+    np.savetxt(str(tmp_path / "x_optm.txt"), x); np.savetxt(str(tmp_path / "u_optm.txt"), u); np.savetxt(str(tmp_path / "t_optm.txt"), t)
+    # --- what a user of the reference expects to hold afterwards
+    assert sol is not None and opti.stats()["success"], opti.stats()
+    np.testing.assert_array_equal(sol.value(X), opti.value(X))
+    qss_lap = float(traj_d[:, Trajectory.TIME].sum())
+    assert x.shape == (len(traj_d), 6) and u.shape == (len(traj_d), 4) and t.shape == (len(traj_d),)
+    np.testing.assert_array_equal(x[:, 0], race_track.abscissa)                     # the abscissa pin (:130)
+    assert t.min() > 0.0 and t.sum() < qss_lap
+    margin = defaults.MODEL["vehicle_width"] / 2 + defaults.MODEL["safety_margin"]
+    assert (x[:, 1] <= race_track.left_intp(race_track.abscissa) - margin + 1e-3).all()
+    assert (x[:, 1] >= race_track.right_intp(race_track.abscissa) + margin - 1e-3).all()
+    back = load_ttl(params["output"])
+    np.testing.assert_allclose(back.points[:, :17], opt_traj_d.points[:, :17], rtol=0, atol=0)
+    # the yaml's tolerance (0.1) was the stopping rule; a second solve from that point at the build's default
+    # tolerance refines the same lap
+    opti.solver("ipopt", {}, {"max_iter": 300, "tol": 1e-6})
+    sol2 = opti.solve()
+    assert abs(float(np.sum(sol2.value(T))) - float(np.sum(t))) < 0.5
+    # the build's own guess variant reaches the same lap time
+    (_, _, Tc), _, opti_c = optm.set_up_double_track_problem(dict(params, initial_guess="clipped", tol=1e-6))
+    opti_c.solve()
+    assert abs(float(np.sum(opti_c.value(Tc))) - float(np.sum(sol2.value(T)))) < 1e-4

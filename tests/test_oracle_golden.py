@@ -214,6 +214,37 @@ def test_g7_run_min_curvature_qp_large(fits, rings):
         assert dev < 1e-6
 
 
+def g7b_rings(g, key, t, cx, cy, k, N, rings):
+    """Rings of a G7b case: the real Monza rings, or those of an instance of bench.py's width-perturbed batch."""
+    if f"{key}_widths" in g.files:
+        return orc.width_rings(t, cx, cy, k, N, g[f"{key}_widths"])
+    return rings
+
+
+@pytest.mark.slow
+def test_g7b_benchmarked_configuration(fits, rings):
+    """Fixture G7b: the reference's OWN run_min_curvature_qp loop (optimizer.py:256-341) at the benchmarked configuration
+    -- N = 2000 (and the reference test's N = 1929), max_iter = 5, three runs on the real Monza rings and instances 0 and 3
+    of bench.py's width-perturbed batch in bench.py's sweep order.  The oracle reproduces every one of them: same
+    per-pass success counts, lines within 1e-5 m (measured 2e-11 .. 4e-6 m)."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = golden("G7b_benchmarked_config.npz")
+    t, cx, cy, k, length = spline(fits, "c100")
+
+    def run(key):
+        N = int(key.split("_")[1][1:])
+        rl_, rr_ = g7b_rings(g, key, t, cx, cy, k, N, rings)
+        ocx, ocy, pts, ns = orc.run_min_curvature_qp(t, cx, cy, k, length, N, rl_, rr_, g[f"{key}_i_start"])
+        return key, ns, float(np.hypot(ocx - g[f"{key}_cx"], ocy - g[f"{key}_cy"]).max())
+    keys = [str(k_) for k_ in g["cases"]]
+    assert len(keys) == 5 and sum("bench" in k_ for k_ in keys) == 2
+    with ThreadPoolExecutor(len(keys)) as ex:       # ctypes releases the GIL: one case per thread
+        for key, ns, dev in ex.map(run, keys):
+            print(key, "oracle vs the reference's run [m]:", dev, "successes", ns.ravel().tolist())
+            np.testing.assert_array_equal(ns, g[f"{key}_n_success"])
+            assert len(g[f"{key}_i_start"]) == 5 and dev < 1e-5, (key, dev)
+
+
 def test_g6_qss_simulator():
     """The oracle's port of Simulator.run_simulation against the reference's own run (fixture G6)."""
     from scipy.interpolate import CubicSpline

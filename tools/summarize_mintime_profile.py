@@ -9,8 +9,13 @@ dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "stats_kernel_stats.csv")))}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
-for r in csv.DictReader(open(os.path.join(src, "pmc_counter_collection.csv"))):
-    agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+for f in ("pmc_counter_collection.csv", "fp64_counter_collection.csv"):
+    if not os.path.exists(os.path.join(src, f)):
+        continue
+    for r in csv.DictReader(open(os.path.join(src, f))):
+        if f.startswith("fp64") and r["Counter_Name"] == "SQ_INSTS_VALU_MFMA_F64":
+            continue                     # already in the first PMC pass
+        agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
 out = {"command": f"rocprofv3 --kernel-trace --stats / --pmc ... -- python3 tools/bench_mintime.py (tag {tag})",
        "units": "SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_ACTIVE_INST_VALU, SQ_WAIT_ANY in quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES in cycles",
        "kernels": {}}
@@ -25,6 +30,32 @@ for name, r in stats.items():
         if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             k["mfma_busy_of_wave_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"])
             k["cycles_per_mfma"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_VALU_MFMA_F64"]
+    if "SQ_INSTS_VALU_FMA_F64" in c:
+        # executed FP64 flops: 64 lanes x (ADD + MUL + TRANS + 2 FMA) wave-instructions (masked lanes count as full: an
+        # upper bound) + 2048 per v_mfma_f64_16x16x4_f64 (16 x 16 x 4 multiply-adds)
+        k["fp64_flops"] = 64.0 * (c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
+                                  c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + 2.0 * c["SQ_INSTS_VALU_FMA_F64"]) + \
+            2048.0 * c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
+        k["fp64_flops_mfma"] = 2048.0 * c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
     out["kernels"][name] = k
+# the run the counters belong to (tools/bench_mintime.py prints one JSON line): batch, nodes, iterations
+for log in ("fp64.log", "pmc.log", "stats.log"):
+    try:
+        line = [l for l in open(os.path.join(src, log)) if l.startswith('{"metric"')][-1]
+        run = json.loads(line)
+        out["run"] = {k_: run[k_] for k_ in ("batch", "wall_s", "converged", "iterations_mean", "iterations_max") if k_ in run}
+        break
+    except Exception:
+        pass
+tot = sum(k.get("fp64_flops", 0.0) for k in out["kernels"].values())
+if tot > 0 and "run" in out:
+    out["fp64_flops_per_call"] = tot
+    out["fp64_flops_mfma_per_call"] = sum(k.get("fp64_flops_mfma", 0.0) for k in out["kernels"].values())
+    out["fp64_flops_per_instance"] = tot / out["run"]["batch"]
+    json.dump({"source": f"profiles/{tag}_kernels.json", "batch": out["run"]["batch"], "iterations_mean": out["run"]["iterations_mean"],
+               "fp64_flops_per_instance": out["fp64_flops_per_instance"],
+               "fp64_flops_mfma_share": out["fp64_flops_mfma_per_call"] / tot,
+               "kkt_avg_us": next((k["avg_us"] for n_, k in out["kernels"].items() if "k_mt_kkt" in n_), None)},
+              open(os.path.join(dst, "mintime_counters_latest.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, f"{tag}_kernels.json"), "w"), indent=1)
 print(json.dumps({n: {a: b for a, b in k.items() if a != "counters"} for n, k in out["kernels"].items()}, indent=1))
