@@ -612,7 +612,8 @@ def main():
         # max_iter) combinations tried, the strict oracle reproduces the reference's run to <= 2.5e-8 m with
         # identical window counts on 23 and ends metres away on the rest.  The cases below are five of the
         # reproducible ones (they pin the driver logic: window order, wrap, skip semantics, the simulator call
-        # not feeding back) and one chaotic one (N=200, seed 3), flagged per case in `<key>_well_conditioned`.
+        # not feeding back) and one chaotic one (N=200, seed 3), flagged per case in `<key>_oracle_reproduces_run` (a statement about the
+        # oracle's roundings happening to equal numpy's on that case, NOT about the case's conditioning).
         cases = [("c100", 200, 2, 0), ("c100", 200, 2, 1), ("c100", 300, 2, 1), ("c100", 400, 2, 0), ("c100", 400, 2, 3),
                  ("c100", 200, 2, 3)]
         kw = {"cases": np.array([f"{a}_N{b}_it{c}_seed{d}" for a, b, c, d in cases])}
@@ -660,7 +661,7 @@ def main():
                 t0_, cx0_, cy0_, k0_ = spl_arrays(fits[tag][0])
                 ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t0_, cx0_, cy0_, k0_, fits[tag][5], N, track.ringL, track.ringR, draws)
                 dev = float(np.hypot(ocx - cx, ocy - cy).max())
-                kw[f"{key}_well_conditioned"] = np.bool_(dev < 1e-6 and int(ons.sum()) == nwin * max_iter - n_skipped)
+                kw[f"{key}_oracle_reproduces_run"] = np.bool_(dev < 1e-6 and int(ons.sum()) == nwin * max_iter - n_skipped)
                 print(f"   strict oracle vs this run: {dev:.2e} m, windows {ons.tolist()} vs {nwin * max_iter - n_skipped}")
         finally:
             ref_opt.conic = real_conic

@@ -603,22 +603,37 @@ JOINT_CASES = [(200, [28]), (400, [15]), (500, [25]), (1000, [17]), (2000, [24])
                (200, [10, 30, 45]), (500, [20, 40]), (500, [7, 52])]
 
 
+N_REROUND = 12     # re-roundings of the oracle per case (seeds 1..12 of orc_set_rerounding); fixed, not tuned per case
+
+
+def _joint_conditioning(run_oracle):
+    """How well the REFERENCE'S formulation defines the answer of a sliding-window case, measured on the oracle alone
+    (independently of the HIP result): the strict oracle and its N_REROUND seeded +-1 ulp re-roundings.
+    Returns (strict cx, cy, window counts, spread [m])."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:                     # ctypes releases the GIL; the re-rounding state is thread-local
+        runs = list(ex.map(run_oracle, range(0, N_REROUND + 1)))
+    ocx, ocy, ons = runs[0]
+    spread = max(float(np.hypot(rcx - ocx, rcy - ocy).max()) for rcx, rcy, _ in runs[1:])
+    return ocx, ocy, ons, spread
+
+
 def _joint_rule(label, hcx, hcy, run_oracle):
-    """Per-case rule of tests/parity_rule.py for the sliding-window driver: within 1e-4 m of the strict
-    oracle, or the oracle's own re-roundings (seeded +-1 ulp, FMA build) spread by more than 1e-4 m on the
-    case and the HIP line is within 10x that spread."""
-    ocx, ocy, ons = run_oracle(0)
-    dev = np.hypot(hcx - ocx, hcy - ocy).max()
-    if dev <= TOL_M:
-        return dev, 0.0, True
-    spread = 0.0
-    for seed in range(1, 13):
-        rcx, rcy, _ = run_oracle(seed)
-        spread = max(spread, np.hypot(rcx - ocx, rcy - ocy).max())
-        if spread > TOL_M and dev <= 10.0 * spread:
-            break
-    assert spread > TOL_M and dev <= 10.0 * spread, (label, dev, spread)
-    return dev, spread, False
+    """Per-case rule for the sliding-window driver, with no constant to tune after a run:
+      * ROBUST case -- all N_REROUND re-roundings of the oracle end within 1e-4 m of the strict oracle: the reference's
+        arithmetic defines the answer there, and the HIP line MUST be within 1e-4 m of it;
+      * otherwise the case is chaotic in the rounding (the oracle itself cannot reproduce it under a +-1 ulp change): the
+        HIP line must stay within 10x the oracle's own spread, and what pins the kernel is the teacher-forced replay of
+        every window (test_joint_windows_teacher_forced), which runs on every case either way.
+    Returns (dev, spread, robust, within)."""
+    ocx, ocy, ons, spread = _joint_conditioning(run_oracle)
+    dev = float(np.hypot(hcx - ocx, hcy - ocy).max())
+    robust = spread <= TOL_M
+    if robust:
+        assert dev <= TOL_M, (label, "robust case: HIP must agree with the oracle", dev, spread)
+    else:
+        assert dev <= TOL_M or dev <= 10.0 * spread, (label, dev, spread)
+    return dev, spread, robust, dev <= TOL_M
 
 
 def test_joint_sweep_vs_oracle(rl, fits, rings):
@@ -627,14 +642,13 @@ def test_joint_sweep_vs_oracle(rl, fits, rings):
 
     The window QP has a row for EVERY sample of the track, so it is infeasible as soon as one sample
     anywhere sits outside its own bound box -- and after a clamp samples sit ON a ring, where "inside
-    or outside by one ulp" is decided by rounding.  Together with the noise-amplified binding rows
-    this makes the reference's joint driver chaotic in the rounding on part of the cases (fixture G9:
-    the strict oracle reproduces the reference's own run on 23 of 40 combinations tried).  Every case must be
-    within 1e-4 m of the oracle or be certified chaotic by the oracle's own re-roundings; the kernel's logic is
-    pinned exactly by test_joint_window_qps_replayed and, end to end, by test_joint_sweep_vs_reference_run."""
+    or outside by one ulp" is decided by rounding (tools/joint_divergence.py shows the mechanism on fixture G9: the
+    states of kernel and oracle stay 1e-11 m apart for 60 windows, then ONE window whose verdict the oracle itself
+    reverses when its bounds move by 4e-12 m is accepted by one and rejected by the other, and the lines are 5 m apart).
+    Rule per case: _joint_rule -- agreement is REQUIRED wherever the oracle's own re-roundings agree."""
     t, cx, cy, k, length = spline(fits, "c100")
     n = len(cx)
-    agree = 0
+    agree = n_robust = 0
     for N, i_start in JOINT_CASES:
         trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
         trk.set_rings(rings[0], rings[1])
@@ -643,25 +657,28 @@ def test_joint_sweep_vs_oracle(rl, fits, rings):
         def run_oracle(seed):
             ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start, rerounding=seed)
             return ocx, ocy, ons
-        dev, spread, within = _joint_rule((N, i_start), hcx, hcy, run_oracle)
-        agree += within
-        print(f"joint N={N} i_start={i_start}: windows HIP {ns.tolist()}  HIP-oracle {dev:.1e} m  "
-              f"{'within 1e-4' if within else f'certified chaotic (oracle re-rounding spread {spread:.1e} m)'}  kernel {st.kernel_ms:.2f} ms")
+        dev, spread, robust, within = _joint_rule((N, i_start), hcx, hcy, run_oracle)
+        agree += within; n_robust += robust
+        print(f"joint N={N} i_start={i_start}: windows HIP {ns.tolist()}  HIP-oracle {dev:.1e} m  oracle re-rounding spread "
+              f"{spread:.1e} m ({'robust' if robust else 'chaotic'})  kernel {st.kernel_ms:.2f} ms")
         assert np.isfinite(hcx).all() and np.isfinite(hcy).all() and np.isfinite(pts[:, :2]).all()
         assert hcx[0] == hcx[n - 5] and hcx[1] == hcx[n - 4] and hcx[n - 3] == hcx[2] and hcx[n - 1] == hcx[4]
         assert 0 <= ns.min() and ns.max() <= n - 8 - 2        # windows per iteration: i_max - i_min
         assert np.hypot(hcx - cx, hcy - cy).max() > 0.5        # the line moved
-    print(f"joint driver: {agree} of {len(JOINT_CASES)} cases inside 1e-4 m")
+    print(f"joint driver: {agree} of {len(JOINT_CASES)} cases inside 1e-4 m; {n_robust} robust under re-rounding (all of those agree)")
+    assert agree >= n_robust
 
 
 def test_joint_sweep_vs_reference_run(rl, fits, rings):
-    """a13 end to end against the REFERENCE'S OWN run (fixture G9: run_joint_min_curvature_qp executed by
-    the reference's loop, tests/golden/make_golden.py): on the well-conditioned cases the HIP line is within
-    1e-4 m of the reference-run line -- or, where the HIP path lands on another rounding, certified by the
-    oracle's re-roundings like everywhere else; the number of accepted windows is compared as well."""
+    """a13 end to end against the REFERENCE'S OWN run (fixture G9: run_joint_min_curvature_qp executed by the reference's
+    loop, tests/golden/make_golden.py; the QP solver and fill_bounds inside that loop are stand-ins).
+    Per case, no tuned count: where the oracle's re-roundings all agree (the reference's arithmetic defines the answer) AND
+    the oracle reproduces the reference's run, the HIP line must reproduce it too -- within 1e-4 m, equal window counts;
+    every other case must be explained by the oracle's own spread.  The flag `<key>_oracle_reproduces_run` of the fixture
+    only says that the oracle's roundings happened to equal numpy's on that case."""
     g = golden("G9_run_joint_min_curvature_qp.npz")
     t, cx, cy, k, length = spline(fits, "c100")
-    exact = 0
+    exact = n_robust = 0
     for key in g["cases"]:
         key = str(key)
         N = int(key.split("_")[1][1:])
@@ -669,18 +686,21 @@ def test_joint_sweep_vs_reference_run(rl, fits, rings):
         trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
         trk.set_rings(rings[0], rings[1])
         hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, ist)
-        dev_ref = np.hypot(hcx - g[f"{key}_cx"], hcy - g[f"{key}_cy"]).max()
+        dev_ref = float(np.hypot(hcx - g[f"{key}_cx"], hcy - g[f"{key}_cy"]).max())
         same = dev_ref <= TOL_M and int(ns.sum()) == int(g[f"{key}_n_ok"])
         exact += bool(same)
-        print(f"G9 {key}: HIP vs the reference's run {dev_ref:.2e} m, windows {int(ns.sum())} vs {int(g[f'{key}_n_ok'])}"
-              f"{'' if bool(g[f'{key}_well_conditioned']) else '  (chaotic case)'}")
-        if not same:
-            def run_oracle(seed):
-                ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist, rerounding=seed)
-                return ocx, ocy, ons
-            _joint_rule(key, hcx, hcy, run_oracle)
-    print(f"G9: the HIP line reproduces the reference's own run on {exact} of {len(g['cases'])} cases")
-    assert exact >= 2, exact
+
+        def run_oracle(seed):
+            ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist, rerounding=seed)
+            return ocx, ocy, ons
+        dev, spread, robust, within = _joint_rule(key, hcx, hcy, run_oracle)
+        n_robust += robust
+        print(f"G9 {key}: HIP vs the reference's run {dev_ref:.2e} m, windows {int(ns.sum())} vs {int(g[f'{key}_n_ok'])}; "
+              f"oracle re-rounding spread {spread:.1e} m ({'robust' if robust else 'chaotic'}); the oracle "
+              f"{'reproduces' if bool(g[f'{key}_oracle_reproduces_run']) else 'does not reproduce'} the run")
+        if robust and bool(g[f"{key}_oracle_reproduces_run"]):
+            assert same, (key, "robust case reproduced by the oracle: HIP must reproduce the reference's run", dev_ref)
+    print(f"G9: the HIP line reproduces the reference's own run on {exact} of {len(g['cases'])} cases ({n_robust} robust under re-rounding)")
 
 
 def test_joint_sweep_search_modes_and_api(rl, fits, rings, monkeypatch):

@@ -368,7 +368,7 @@ def test_g9_run_joint_min_curvature_qp(fits, rings):
         ist = g[f"{key}_i_start"]
         ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist)
         dev = np.hypot(ocx - g[f"{key}_cx"], ocy - g[f"{key}_cy"]).max()
-        if bool(g[f"{key}_well_conditioned"]):
+        if bool(g[f"{key}_oracle_reproduces_run"]):
             assert dev < 1e-6 and int(ons.sum()) == int(g[f"{key}_n_ok"]), (key, dev, ons)
             n_good += 1
         else:
