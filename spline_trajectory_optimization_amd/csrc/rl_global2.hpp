@@ -43,7 +43,8 @@ __host__ __device__ inline Global2Layout global2_layout(int k, int n, int np, in
   L.cxs = take(n); L.cys = take(n); L.nus = take(2 * np);
   L.Pc = take(np * K1);
   L.Ssum = take(np * NO);
-  const int spart = nrow * g2_round(groups), mf = NS * 64 * groups;  // the folded matrix aliases the staging area
+  // the folded matrix aliases the staging area; one group: the two-front image [NS][64] + the middle block [NS][32]
+  const int spart = nrow * g2_round(groups), mf = groups == 1 ? NS * 64 + NS * 32 + 128 : NS * 64 * groups;  // + 128: broadcast scratch
   L.Spart = take(spart > mf ? spart : mf);
   L.lohi = take(2 * N);
   L.red = take(4 * 16);
@@ -185,6 +186,261 @@ __device__ __forceinline__ int fold_pos(int j, int np) { return j < (np + 1) / 2
 __device__ __forceinline__ int fold_inv(int p, int np) { return (p & 1) ? np - 1 - (p >> 1) : (p >> 1); }
 
 // ------------------------------------------------------------------------------------------------
+// np <= 64: TWO ELIMINATION FRONTS IN ONE WAVE.  The folded band is a plain band (half-bandwidth BW) of np rows; a
+// column step only touches the BW rows below its pivot, so two fronts that start at the two ends of the band -- columns
+// 0, 1, 2, ... and columns np-1, np-2, ... -- are independent until they come within BW rows of each other.  One wave runs
+// both with ONE instruction stream: lanes 0..31 hold rows 0..31 of the matrix, lanes 32..63 rows 0..31 of the
+// index-REVERSED matrix (row p~ = np-1-p, column q~ = np-1-q), both in the slot layout of FoldBand (slot = column mod NS), so
+// step t of either front reads and writes the same register slots; what differs between the halves is only WHICH lane a
+// value is fetched from (lane t + j or 32 + t + j: broadcast reads from a 1 KB LDS scratch instead of v_readlane).  After
+// T = (np - 2 BW) / 2 steps each front has reached the MIDDLE block of np - 2T <= 2 BW + 1 rows: its Schur complement is
+// gathered through LDS into a dense image (lane = row, slot = column) and eliminated by the same wave.  The dependent
+// chain of a factorisation is T + (np - 2T) = 41 column steps instead of np = 61 (Monza, s = 100), of a solve 92 instead
+// of 122, and no second wave, no extra workgroup barrier and no row wave is given up for it.
+//   measured   (Monza N = 2000, 1024 instances, per interior-point iteration, -DRL_G2_PROFILE): factorisation 11.2 us ->
+//              8.9 us INCLUDING the forward substitution of the first right-hand side, the remaining solve work 6.6 -> 5.7 us;
+//              kernel 14.5 -> 14.3 ms.  The steps were halved-ish, the time was not: a wave that is alone on its SIMD issues
+//              one FP64 VALU / LDS instruction per ~8 cycles whatever it depends on (timing builds without the Newton steps
+//              of 1/sqrt, or without any cross-lane traffic at all, are 6 % / 17 % faster only), so the linear algebra of an
+//              instance costs (instructions) x 8 cycles on 1/8 of the CU's issue slots while the row waves wait.  What would
+//              change that is a second INSTANCE in the workgroup whose row passes fill those slots.
+//   ordering   P M P' = L D L' with P = (top columns, bottom columns, middle): an ordinary symmetric permutation, so
+//              the factorisation is as stable as the one-front one; rounding differs (another elimination order).
+//   storage    as FoldBand: below the pivot L[r][c]; above it the mirrored entry times 1/d_c for eliminated columns,
+//              unscaled (d_r L[c][r]) for the middle columns, which the fronts never reach.
+template <int BW>
+struct TwoFront {
+  static constexpr int NS = 2 * BW + 1, MID = 2 * BW + 1;
+  double S[NS];    // fronts image
+  double Sb[NS];   // after the factorisation: the bottom front's rows once more, in lanes 0..31 (for the solves)
+  double Sm[MID];  // middle image: lane i < mid holds row T + i of the Schur complement, slot j = column T + j
+  double dinv, dinvb, dinvm;
+  double yp, ym;   // L^-1 (first right-hand side): fronts (lane packed) and middle block, formed DURING the factorisation
+
+  static __host__ __device__ __forceinline__ int fronts(int np) { return np > 2 * BW ? (np - 2 * BW) / 2 : 0; }
+
+  static __device__ __forceinline__ double perm(double v, int src_lane) {  // per-lane source: v of lane src_lane
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+  // value of lane t for the top half, of lane 32 + t for the bottom half (t wave-uniform): two scalar broadcasts and a
+  // select -- a handful of cycles, where ds_bpermute would put its ~100 cycles on the dependent chain of the pivots
+  static __device__ __forceinline__ double half_bcast(double v, int t, bool bottom) {
+    const double a = lane_bcast(v, t), b = lane_bcast(v, 32 + t);
+    return bottom ? b : a;
+  }
+  // lanes 32..63 of v in lanes 0..31 (v_permlane32_swap: a half exchange, no LDS)
+  static __device__ __forceinline__ double upper_half(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)r1[1], (int)r0[1]);
+  }
+  // column (front orientation) that slot s of row i holds: the one == s (mod NS) in [i - BW, i + BW]
+  static __device__ __forceinline__ int slot_col(int i, int s) {
+    int m = (s - i + BW) % NS;
+    if (m < 0) m += NS;
+    return i - BW + m;
+  }
+  // 1 / sqrt(x) to double precision (x positive, normal): v_rsq_f64 + two Newton steps, no division
+  static __device__ __forceinline__ double frsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(fma(-hx * y, y, 0.5), y, y);
+    y = fma(fma(-hx * y, y, 0.5), y, y);
+    return y;
+  }
+
+  __device__ __forceinline__ void load(const double* Mf, int lane) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) S[s] = Mf[s * 64 + lane];
+    dinv = 0.0; dinvm = 0.0;
+  }
+
+  // One column of both fronts.  The update is z z' with z = (pivot column) / sqrt(d): ONE fma per entry, and bitwise
+  // symmetric because z_r z_q is the same product in both triangles.  What is STORED is the L D L' form of FoldBand (the
+  // solves are unchanged): below the pivot z / sqrt(d) = L[r][c], above it the mirrored entry times 1/d, dinv = 1/d.
+  // The pivots form the one dependent chain of the factorisation (d_t -> 1/sqrt -> column t -> d_t+1); everything else hangs
+  // off it.  So the NEXT pivot is taken out of the update loop: lane t+1 holds both its diagonal and its entry of column t,
+  // d_t+1 = S[t+1][t+1] - z_t+1^2 is one lane-local fma, and its 1/sqrt is under way while the BW row updates of column t
+  // wait for their LDS operands.  rs = 1/sqrt(d_t) comes in, 1/sqrt(d_t+1) goes out.
+  // s = t mod NS: a constant in every caller's unrolled loop, so that all register indices are static.
+  __device__ __forceinline__ double front_col(int s, int t, int i, bool bottom, int half, double rs, double* zb, int lane) {
+    const double inv = rs * rs;
+    const bool below = (unsigned)(i - t - 1) < (unsigned)BW, above = (unsigned)(t - 1 - i) < (unsigned)BW;
+    const double z = below ? S[s] * rs : 0.0;
+    const double rs_next = frsqrt(half_bcast(fma(-z, z, S[(s + 1) % NS]), t + 1, bottom));
+    // The BW rows below the pivot need z of the BW lanes after the pivot's, per half: through LDS -- every lane stores its z
+    // (and its y, for the forward substitution that rides along), then reads the values it needs at addresses that are the
+    // same for a whole half (broadcast reads, two per instruction): 7 LDS instructions where per-lane ds_bpermute takes 22,
+    // and a lone wave pays ~8 cycles for each
+    double u[BW];
+    zb[lane] = z; zb[64 + lane] = yp;
+    wave_lds_fence();
+    const double* zr = zb + half + t;
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) u[j - 1] = zr[j];
+    const double yt = zr[64];
+    const double w = z * rs;                     // L[r][t]
+    dinv = i == t ? inv : dinv;
+    S[s] = below ? w : (above ? S[s] * inv : S[s]);
+#pragma unroll
+    for (int j = 1; j <= BW; ++j) S[(s + j) % NS] = fma(-z, u[j - 1], S[(s + j) % NS]);
+    yp = fma(-w, yt, yp);
+    return rs_next;
+  }
+
+  template <int c>
+  __device__ __forceinline__ double mid_col(int lane, double rs) {
+    const double inv = rs * rs;
+    const bool below = lane > c && lane < MID;
+    const double z = below ? Sm[c] * rs : 0.0;
+    double rs_next = 0.0;
+    if constexpr (c + 1 < MID) rs_next = frsqrt(lane_bcast(fma(-z, z, Sm[c + 1]), c + 1));
+    const double w = z * rs;
+    const double yc = lane_bcast(ym, c);
+    dinvm = lane == c ? inv : dinvm;
+    Sm[c] = below ? w : (lane < c ? Sm[c] * inv : Sm[c]);
+    if constexpr (c + 1 < MID) {
+#pragma unroll
+      for (int j = c + 1; j < MID; ++j) Sm[j] = fma(-z, lane_bcast(z, j), Sm[j]);
+    }
+    ym = fma(-w, yc, ym);
+    return rs_next;
+  }
+  template <int c>
+  __device__ __forceinline__ void mid_cols(int lane, double rs) {
+    const double rs_next = mid_col<c>(lane, rs);
+    if constexpr (c + 1 < MID) mid_cols<c + 1>(lane, rs_next);
+  }
+
+  // right-hand side of the middle block: what the fronts left in its first / last BW rows, the original elsewhere
+  static __device__ __forceinline__ double mid_rhs(int np, int T, int mid, int lane, double from_top_v, double from_bot_v,
+                                                   const double* rhs) {
+    const int pm = T + lane;                              // matrix row of middle lane `lane`
+    const bool from_top = T > 0 && lane < BW, from_bot = T > 0 && lane < mid && pm >= np - T - BW;
+    return lane < mid ? (from_top ? from_top_v : (from_bot ? from_bot_v : rhs[fold_inv(pm, np)])) : 0.0;
+  }
+
+  // Factorisation + L^-1 rhs.  Mm: the middle block as assembled (g2_assemble_tf), [slot j][32 lanes]; the blocks the
+  // fronts have updated are written over it here, then the whole block is read back one row per lane.
+  __device__ __forceinline__ void factor(int np, int lane, double* Mm, const double* rhs) {
+    const int T = fronts(np), mid = np - 2 * T, i = lane & 31, half = lane & 32;
+    const bool bottom = half != 0;
+    yp = (T > 0 && i < T + BW) ? rhs[fold_inv(bottom ? np - 1 - i : i, np)] : 0.0;
+    double rs = T > 0 ? frsqrt(half_bcast(S[0], 0, bottom)) : 0.0;
+    for (int t0 = 0; t0 < T; t0 += NS) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int t = t0 + s;
+        if (t < T) rs = front_col(s, t, i, bottom, half, rs, Mm + NS * 32, lane);   // (a guard, not a break: the loop must unroll completely)
+      }
+    }
+    if (T > 0) {
+      if (i >= T && i < T + BW) {
+        // slot s of row i holds column i - BW + ((s - s0) mod NS), s0 = (i - BW) mod NS: one modulo per lane, then the
+        // columns of consecutive slots are consecutive (with one wrap)
+        int s0 = (i - BW) % NS;
+        if (s0 < 0) s0 += NS;
+        const int qb = i - BW - s0, base = bottom ? (np - 1 - T) * 33 - i : i - T * 33;   // element (mr, mc) at mc * 32 + mr
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int q = qb + s + (s < s0 ? NS : 0);
+          if (q >= T && q < T + BW) Mm[bottom ? base - 32 * q : base + 32 * q] = S[s];
+        }
+      }
+      wave_lds_fence();
+    }
+#pragma unroll
+    for (int j = 0; j < MID; ++j) Sm[j] = Mm[j * 32 + i];
+    {
+      const int pm = T + lane;
+      const double g1 = perm(yp, (T > 0 && lane < BW) ? pm : 0);
+      const double g2 = perm(yp, (T > 0 && lane < mid && pm >= np - T - BW) ? 32 + (np - 1 - pm) : 0);
+      ym = mid_rhs(np, T, mid, lane, g1, g2, rhs);
+    }
+    mid_cols<0>(lane, frsqrt(lane_bcast(Sm[0], 0)));
+    // The factorisation packs the two fronts into the two halves of the wave because it is ISSUE bound: one instruction
+    // updates both.  The triangular solves are LATENCY bound (one dependent fma per column), so for them the bottom front's
+    // rows are laid beside the top front's in lanes 0..31: two independent chains that hide each other's latency, and the
+    // value a column needs is a plain v_readlane of lane t for both.
+#pragma unroll
+    for (int s = 0; s < NS; ++s) Sb[s] = upper_half(S[s]);
+    dinvb = upper_half(dinv);
+  }
+
+  // L y = rhs for a further right-hand side: (top front, bottom front, middle) parts of y
+  __device__ __forceinline__ void forward(int np, int lane, const double* rhs, double& bt, double& bb, double& bm) const {
+    const int T = fronts(np), mid = np - 2 * T, i = lane & 31;
+    const bool rowok = T > 0 && i < T + BW;
+    bt = rowok ? rhs[fold_inv(i, np)] : 0.0;            // top front: matrix row i
+    bb = rowok ? rhs[fold_inv(np - 1 - i, np)] : 0.0;   // bottom front: matrix row np-1-i
+    for (int t0 = 0; t0 < T; t0 += NS) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int t = t0 + s;
+        if (t < T) {
+          const double ct = lane_bcast(bt, t), cb = lane_bcast(bb, t);
+          const bool below = (unsigned)(i - t - 1) < (unsigned)BW;
+          bt = fma(-(below ? S[s] : 0.0), ct, bt);
+          bb = fma(-(below ? Sb[s] : 0.0), cb, bb);
+        }
+      }
+    }
+    {
+      const int pm = T + lane;
+      const double g1 = perm(bt, (T > 0 && lane < BW) ? pm : 0);
+      const double g2 = perm(bb, (T > 0 && lane < mid && pm >= np - T - BW) ? np - 1 - pm : 0);
+      bm = mid_rhs(np, T, mid, lane, g1, g2, rhs);
+    }
+#pragma unroll
+    for (int c = 0; c < MID; ++c) {
+      const double bc = lane_bcast(bm, c);
+      bm = fma(-((lane > c && lane < MID) ? Sm[c] : 0.0), bc, bm);
+    }
+  }
+  // the y of the first right-hand side, as the factorisation left it, in the layout of forward()
+  __device__ __forceinline__ void first_y(double& bt, double& bb, double& bm) const { bt = yp; bb = upper_half(yp); bm = ym; }
+
+  // D L' x = y; x to LDS in the natural order of the unknowns (fold_inv of the matrix row)
+  __device__ __forceinline__ void backward(int np, int lane, double bt, double bb, double bm, double* x) const {
+    const int T = fronts(np), mid = np - 2 * T, i = lane & 31;
+#pragma unroll
+    for (int c = MID - 1; c >= 0; --c) {
+      const double tc = lane_bcast(bm, c);
+      bm = fma(-(lane < c ? Sm[c] : 0.0), tc, bm);
+    }
+    bm *= dinvm;
+    if (lane < mid) x[fold_inv(T + lane, np)] = bm;
+    if (T > 0) {
+      // the solution of the middle rows next to each front goes where the fronts' columns expect it
+      const bool blk = i >= T && i < T + BW;
+      const double g1 = perm(bm, blk ? i - T : 0), g2 = perm(bm, blk ? np - 1 - i - T : 0);
+      bt = blk ? g1 : bt;
+      bb = blk ? g2 : bb;
+      // middle columns first (unscaled entries times x), then the fronts' own columns (scaled entries times d x)
+      for (int t0 = ((T + BW - 1) / NS) * NS; t0 >= 0; t0 -= NS) {
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) {
+          const int t = t0 + s;
+          if (t < T + BW) {
+            const double ct = lane_bcast(bt, t), cb = lane_bcast(bb, t);
+            const bool above = (unsigned)(t - 1 - i) < (unsigned)BW && i < T;
+            bt = fma(-(above ? S[s] : 0.0), ct, bt);
+            bb = fma(-(above ? Sb[s] : 0.0), cb, bb);
+          }
+        }
+      }
+      if (lane < T) {
+        x[fold_inv(lane, np)] = bt * dinv;
+        x[fold_inv(np - 1 - lane, np)] = bb * dinvb;
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // pieces shared by both roles (every thread of the workgroup calls them with its own tid)
 
 // Ssum[sp * NO + out0 + o] = sum over the chunks of span sp, in chunk order, of Spart[ch * GR + o]
@@ -236,6 +492,51 @@ __device__ __forceinline__ void g2_assemble(int tid, int nt, int np, const doubl
       if (d < 0) d += np;
       if (d <= K) v = g2_band_entry<K>(Pc, Ssum, np, j1, d);
       else if (np - d <= K) v = g2_band_entry<K>(Pc, Ssum, np, j2, np - d);
+    }
+    Mf[task] = v;
+  }
+  for (int j = tid; j < np; j += nt) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int al = 0; al <= K; ++al) {
+      int sp = j - al;
+      if (sp < 0) sp += np;
+      s1 += Ssum[sp * NO + NE + al]; s2 += Ssum[sp * NO + NE + K1 + al];
+    }
+    rd[j] = rdP[j] + s2;
+    rhs[j] = s1 - rdP[j];
+  }
+}
+
+// the same for the two-front factorisation (np <= 64): the fronts image Mf[s][64 lanes] (lanes 0..31 rows of the folded
+// matrix, lanes 32..63 rows of the index-reversed one; only the T + BW rows a front touches) and the middle block
+// Mm[j][32] = M[T + i][T + j] (dense, padded with the identity up to MID rows)
+template <int K>
+__device__ __forceinline__ void g2_assemble_tf(int tid, int nt, int np, const double* Pc, const double* Ssum,
+                                               const double* rdP, double* Mf, double* rd, double* rhs) {
+  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1, BW = 2 * K, NS = 2 * BW + 1, MID = NS;
+  const int T = TwoFront<BW>::fronts(np), mid = np - 2 * T;
+  auto entry = [&](int p, int col) {
+    const int j1 = fold_inv(p, np), j2 = fold_inv(col, np);
+    int d = j1 - j2;
+    if (d < 0) d += np;
+    if (d <= K) return g2_band_entry<K>(Pc, Ssum, np, j1, d);
+    if (np - d <= K) return g2_band_entry<K>(Pc, Ssum, np, j2, np - d);
+    return 0.0;
+  };
+  double* Mm = Mf + NS * 64;
+  for (int task = tid; task < NS * 64 + MID * 32; task += nt) {
+    double v = 0.0;
+    if (task < NS * 64) {
+      const int s = task >> 6, l = task & 63, i = l & 31;
+      const bool bottom = l >= 32;
+      if (T > 0 && i < T + BW) {
+        const int q = TwoFront<BW>::slot_col(i, s);
+        if (q >= 0 && q < T + BW) v = entry(bottom ? np - 1 - i : i, bottom ? np - 1 - q : q);
+      }
+    } else {
+      const int m = task - NS * 64, j = m >> 5, i = m & 31;
+      if (i < mid && j < mid) v = entry(T + i, T + j);
+      else if (i == j && i < MID) v = 1.0;
     }
     Mf[task] = v;
   }
@@ -524,7 +825,8 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         }
         G2_LAP(0);
         // [I2]
-        g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        if constexpr (G == 1) g2_assemble_tf<K>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        else g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
         __syncthreads();
         // [I3]
         __syncthreads();
@@ -683,7 +985,8 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
     __syncthreads();
   } else {
     // ========================================================================= linear-algebra wave
-    FoldBand<BW, G> fb;
+    FoldBand<BW, G> fb;   // np > 64 (G == 3): the folded band over G groups of 64 rows (unused, hence eliminated, for G == 1)
+    TwoFront<BW> tf;      // np <= 64 (G == 1): two fronts in this one wave
     double last_step = 0.0;
 #ifdef RL_G2_PROFILE
     long long tF = 0, tS = 0, tA = 0, tk = 0;
@@ -774,7 +1077,8 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         }
         // [I2]
         const double mu_sum = red_sum(0), rpmax = red_max(2);
-        g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        if constexpr (G == 1) g2_assemble_tf<K>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        else g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
         __syncthreads();
         // [I3]
         bool conv;
@@ -788,17 +1092,29 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         }
         double bx[G];
         if (!conv) {
-          G2_TIC();
-          fb.load(Mf, lane);
-          fb.factor(np, lane);
-          G2_TOC(tF);
-          G2_TIC();
+          if constexpr (G == 1) {
+            G2_TIC();
+            tf.load(Mf, lane);
+            tf.factor(np, lane, Mf + (2 * BW + 1) * 64, rhs);   // + forward substitution of the affine right-hand side
+            G2_TOC(tF);
+            G2_TIC();
+            double yt_, yb_, ym_;
+            tf.first_y(yt_, yb_, ym_);
+            tf.backward(np, lane, yt_, yb_, ym_, dxa);
+            G2_TOC(tS);
+          } else {
+            G2_TIC();
+            fb.load(Mf, lane);
+            fb.factor(np, lane);
+            G2_TOC(tF);
+            G2_TIC();
 #pragma unroll
-          for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; bx[q] = p < np ? rhs[fold_inv(p, np)] : 0.0; }
-          fb.solve(np, lane, bx);
-          G2_TOC(tS);
+            for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; bx[q] = p < np ? rhs[fold_inv(p, np)] : 0.0; }
+            fb.solve(np, lane, bx);
+            G2_TOC(tS);
 #pragma unroll
-          for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; if (p < np) dxa[fold_inv(p, np)] = bx[q]; }
+            for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; if (p < np) dxa[fold_inv(p, np)] = bx[q]; }
+          }
         }
         __syncthreads();
         if (conv) break;
@@ -818,28 +1134,49 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
           smu = ratio * ratio * ratio * mu;
           if (lane == 0) ctl[1] = smu;
         }
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-          const int p = lane + 64 * q;
-          double v = 0.0;
-          if (p < np) {
-            const int j = fold_inv(p, np);
-            double v1 = 0.0;
+        if constexpr (G == 1) {
+          // second right-hand side in the natural order of the unknowns, through LDS (rhs is free after the first solve)
+          if (lane < np) {
+            const int j = lane;
+            double v = 0.0, v1 = 0.0;
             for (int al = 0; al <= K; ++al) {
               int sp = j - al;
               if (sp < 0) sp += np;
               v += Ssum[sp * NO + NE + al];
               v1 += Ssum[sp * NO + NE + K1 + al];
             }
-            v = fma(smu, v1, v) - rd[j];
+            rhs[j] = fma(smu, v1, v) - rd[j];
           }
-          bx[q] = v;
-        }
-        G2_TIC();
-        fb.solve(np, lane, bx);
-        G2_TOC(tS);
+          wave_lds_fence();
+          G2_TIC();
+          double yt_, yb_, ym_;
+          tf.forward(np, lane, rhs, yt_, yb_, ym_);
+          tf.backward(np, lane, yt_, yb_, ym_, dxs);
+          G2_TOC(tS);
+        } else {
 #pragma unroll
-        for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; if (p < np) dxs[fold_inv(p, np)] = bx[q]; }
+          for (int q = 0; q < G; ++q) {
+            const int p = lane + 64 * q;
+            double v = 0.0;
+            if (p < np) {
+              const int j = fold_inv(p, np);
+              double v1 = 0.0;
+              for (int al = 0; al <= K; ++al) {
+                int sp = j - al;
+                if (sp < 0) sp += np;
+                v += Ssum[sp * NO + NE + al];
+                v1 += Ssum[sp * NO + NE + K1 + al];
+              }
+              v = fma(smu, v1, v) - rd[j];
+            }
+            bx[q] = v;
+          }
+          G2_TIC();
+          fb.solve(np, lane, bx);
+          G2_TOC(tS);
+#pragma unroll
+          for (int q = 0; q < G; ++q) { const int p = lane + 64 * q; if (p < np) dxs[fold_inv(p, np)] = bx[q]; }
+        }
         __syncthreads();
         // [I7]
         __syncthreads();
