@@ -350,14 +350,23 @@ template <typename RingPtr, typename CirclePtr>
 __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, CirclePtr circ,
                                                     CirclePtr sep, int nchunk, bool active, int hint,
                                                     double px, double py, double dx, double dy,
-                                                    double dlen, bool skip_guard = false) {
+                                                    double dlen, bool skip_guard = false,
+                                                    unsigned long long* stamps = nullptr) {
   const int lane = threadIdx.x & (kWave - 1);
   Hit h{INFINITY, 0.0, kNoEdge};
   const bool windowed = active && hint >= 0 && hint < nr;
   int cs = hint / kChunk - 1;  // first chunk of the window
   if (cs < 0) cs += nchunk;
   const int lo = cs * kChunk;  // first edge of the window (the lanes of one chunk read the same addresses)
+#ifdef RL_STAMPS
+  unsigned long long w0 = 0, w1 = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0) :: "memory");
+#endif
   if (windowed) scan_window(ring, nr, lo, px, py, dx, dy, h);
+#ifdef RL_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1) :: "memory");
+  if (stamps) stamps[0] += w1 - w0;   // window scan (loads, sign pass, exact tests)
+#endif
   if (skip_guard) return h;
   const bool found = h.best <= 1.0;
   const double di = active ? ((found ? h.best * dlen : dlen) * (1.0 + 1e-9) + 1e-9) : 0.0;

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
       rL = reinterpret_cast<double2*>(smem + L.off_rL);
       rR = reinterpret_cast<double2*>(smem + L.off_rR);
     } else {
+      if (RL_ABLATE(a, 8)) g = a.gscratch + (SIGMA_LDS ? 0 : (size_t)2 * ((N + 1) & ~1));   // timing only: every instance reads instance 0's rings (L2-hot)
       rL = reinterpret_cast<double2*>(g);
       rR = rL + a.nL + kRingPad;
     }
@@ -494,6 +495,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
     __syncthreads();
   }
 
+#ifdef RL_STAMPS
+  unsigned long long st_fine[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sf0 = 0, sf1 = 0;   // inside the refresh: evaluation, left ring, right ring, stores
+#define RL_FSTAMP(slot) do { RL_STAMP(sf1); st_fine[slot] += sf1 - sf0; sf0 = sf1; } while (0)
+#else
+#define RL_FSTAMP(slot) do { } while (0)
+#endif
   // refresh(i0,i1,j0,j1): new p, normal and closest ring crossings for the samples of two ranges
   // l_first: the knot interval of sample i0 + tid if the caller has it already (the cost pass of the same step), else -1
   auto refresh = [&](int i0, int i1, int j0, int j1, int mode, int l_first = -1) {
@@ -509,15 +516,30 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
         // the refresh of a step starts where its cost pass started: same thread, same sample, same knot interval --
         // one dependent look-up less on the longest chain of the step (9.52 -> 9.25 ms per 1024 solves)
         const int l = (l_first >= 0 && wt == wave && r < m0) ? l_first : tr.ell[i];
+#ifdef RL_STAMPS
+        RL_STAMP(sf0);
+#endif
         CurvePoint<K, 1> c;
         eval_sample<K, 1>(tr, cx, cy, i, l, c);
         double dx, dy, inv_s2;
         scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);  // max_dist * (cos, sin)(yaw + pi/2)
+        RL_FSTAMP(0);
         const bool skip = RL_ABLATE(a, 2);
+#ifdef RL_STAMPS
+        unsigned long long ws[2] = {0, 0};
+        const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
+                                            dx, dy, a.max_dist, skip, ws);
+        RL_FSTAMP(1);
+        const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
+                                            c.y, -dx, -dy, a.max_dist, skip, ws);  // yaw - pi/2
+        RL_FSTAMP(2);
+        st_fine[4] += ws[0];
+#else
         const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
                                             dx, dy, a.max_dist, skip);
         const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
                                             c.y, -dx, -dy, a.max_dist, skip);  // yaw - pi/2
+#endif
         if (active) {
           sL[i] = hl.best_s;
           sR[i] = hr.best_s;
@@ -525,6 +547,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
           hints[Npad + i] = (unsigned short)(hr.edge == kNoEdge ? 0xFFFF : hr.edge);
           if (JOINT) note_outside(i, c.x, c.y, dx, dy, hl.best_s, hr.best_s);
         }
+        RL_FSTAMP(3);
       }
       return;
     }
@@ -1026,8 +1049,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
 #ifdef RL_STAMPS
   RL_STAMP(st_t1);
   if (a.dbg && lane == 0) {
-    double* o = a.dbg + ((size_t)b * NW + wave) * 8;
+    double* o = a.dbg + ((size_t)b * NW + wave) * 16;
     for (int q = 0; q < 6; ++q) o[q] = (double)st_acc[q];
+    for (int q = 0; q < 8; ++q) o[8 + q] = (double)st_fine[q];
     o[6] = (double)(st_t1 - st_begin);
   }
 #endif

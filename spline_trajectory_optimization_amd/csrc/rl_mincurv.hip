@@ -686,7 +686,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256 + 2 * n)
                         : (size_t)ninst * max_iter * 2 * (size_t)(i_max - i_min) * (rl::kSweepDumpHead + 2 * n);
 #ifdef RL_STAMPS
-    need = std::max(need, (size_t)B * 4 * 8);   // diagnostic build: per-wave phase stamps of every instance
+    need = std::max(need, (size_t)B * 4 * 16);   // diagnostic build: per-wave phase stamps of every instance
 #endif
     a.dbg_instances = ninst;
     if (g_dbg_len < need) {

@@ -21,13 +21,17 @@ lib = _lib.load()
 _lib.check(lib.rl_debug_dump_enable(1))
 for _ in range(2):
     out = ops.solve_batch_host(trk, _lib.BOUNDS_WIDTHS, W, ist)
-buf = np.zeros(B * 4 * 8)
+buf = np.zeros(B * 4 * 16)
 _lib.check(lib.rl_debug_read(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(buf)))
-s = buf.reshape(B, 4, 8)
+s = buf.reshape(B, 4, 16)
 tot = s[:, :, 6]
 names = ["phase 1 (cost + constraints + reductions)", "barrier A", "phase 2 (QP, wave 0)", "barrier B", "phase 3 (refresh)", "barrier C"]
 res = {"kernel_ms": out[4].kernel_ms, "B": B, "cycles_per_wave_mean": float(tot.mean())}
 for q, nm in enumerate(names):
     res[nm] = {"share_all_waves": float((s[:, :, q] / tot).mean()), "share_wave0": float((s[:, 0, q] / tot[:, 0]).mean()),
                "cycles_per_step_mean": float(s[:, :, q].mean() / 610)}
+fine = ["refresh: curve evaluation + normal", "refresh: left ring search", "refresh: right ring search", "refresh: stores (+ loop)",
+        "  of the two searches: window scan (loads, sign pass, exact tests)"]
+for q, nm in zip((0, 1, 2, 3, 4), fine):
+    res[nm] = {"share_wave0": float((s[:, 0, 8 + q] / tot[:, 0]).mean()), "cycles_per_step_wave0": float(s[:, 0, 8 + q].mean() / 610)}
 print(json.dumps(res, indent=1))
