@@ -330,13 +330,14 @@ __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>
 // pass active = false).
 //
 // Fast path, per lane, no cross-lane traffic:
-//   * scan the 2*kWin+1 edges around the hint (the edge of the last crossing); consecutive lanes ->
+//   * scan the kWinChunks = 3 whole chunks (24 edges) around the chunk of the hint (the edge of the last crossing): a
+//     chunk-ALIGNED window, so the lanes of one chunk read the same addresses; consecutive lanes ->
 //     consecutive LDS addresses.  This yields a crossing at distance d_i on an
 //     edge of chunk ce.
 //   * certificate that nothing closer exists anywhere else on the ring:
 //       - chunks further than kNear chunks (in ring order) from ce:  sep[ce] > 2 d_i, where sep[c] is the
 //         smallest gap between chunk c's bounding circle and the circle of any chunk outside
-//         [c-3, c+3] (precomputed once per instance).  A point q of such a chunk has
+//         [c-kNear, c+kNear] = [c-1, c+1] (precomputed once per instance, k_sweep's prologue).  A point q of such a chunk has
 //         |q - h_i| >= sep[ce] (h_i = the crossing found, inside circle ce), hence
 //         |q - p_i| >= sep[ce] - d_i > d_i.
 //       - the chunks of [ce-kNear, ce+kNear] that are not entirely inside the window: their circles must

@@ -315,7 +315,9 @@ struct SweepArgs {
 #define RL_STAMP_ADD(slot, t1, t0) do { } while (0)
 #endif
 
-// Timing-ablation switches exist only in a diagnostic build (hipcc -DRL_ABLATION, tools/profile_bench.sh):
+// Timing-ablation switches exist only in a diagnostic build (hipcc -DRL_ABLATION, loaded through RL_LIB_PATH with
+// RL_DEBUG_FLAGS=<bits>: 1 no refresh, 2 no certificate / slow path, 4 no cost pass, 8 every instance reads instance 0's rings;
+// measured in profiles/r03_sweep_experiments.json):
 // the shipped library has no way to skip a phase.
 #ifdef RL_ABLATION
 #define RL_ABLATE(a, bit) (((a).debug & (bit)) != 0)

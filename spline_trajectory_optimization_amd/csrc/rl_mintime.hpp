@@ -185,7 +185,7 @@ struct MtState {       // per-batch device arrays, instance-major
   double* hes;    // [B,N,18,18] Hessian of y.eq + z.g of the pair
   double* dw;     // [B,N,9]
   double* dy;     // [B,N,7]
-  double* blk;    // [B,N,3,256] factor blocks: S^-1, P, Q
+  double* blk;    // [B,N,3,256] factor blocks of k_mt_kkt, per node: P [256], Q [256], a' [16] (+ padding)
   double* vec;    // [B,N,16] right-hand side / solution scratch
   double* dblk;   // [B,N,256] assembled diagonal blocks D_j (without delta)
   double* eblk;   // [B,N,256] assembled coupling blocks E_j = M[j+1][j]

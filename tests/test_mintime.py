@@ -389,3 +389,45 @@ def test_cli_lines_against_the_facade(tmp_path):
     (_, _, Tc), _, opti_c = optm.set_up_double_track_problem(dict(params, initial_guess="clipped", tol=1e-6))
     opti_c.solve()
     assert abs(float(np.sum(opti_c.value(Tc))) - float(np.sum(sol2.value(T)))) < 0.05
+
+
+@pytest.mark.gpu
+def test_dev_calls_on_two_torch_streams_do_not_share_scratch(coarse):
+    """The *_dev entry points carve their work arrays out of ONE arena per context, from offset 0.  Two solves enqueued on
+    DIFFERENT torch streams without a host synchronisation in between must still run one after the other on that scratch
+    (rl_mincurv.hip: Arena::begin orders a call behind the arena's previous user with an event when the stream has
+    changed): both give, bit for bit, what they give when run alone."""
+    import torch
+    from spline_trajectory_optimization_amd import ops
+    d, P, w0 = coarse
+    dev = torch.device("cuda", 0)
+    X0, U0, T0 = P.unpack(w0)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    B = 4
+    scale = np.array([1.0, 0.92, 1.1, 1.2])
+    left = g(P.left[None] * scale[:, None]); right = g(P.right[None] * scale[:, None])
+    s_, k_ = g(P.s), g(P.kappa)
+
+    def fresh():
+        return (g(np.repeat(X0[None], B, axis=0)), g(np.repeat(U0[None], B, axis=0)), g(np.repeat(T0[None], B, axis=0)))
+    # reference: each solve alone
+    alone = []
+    for sl in (slice(0, 2), slice(2, 4)):
+        X, U, T = fresh()
+        st = ops.mintime_solve_torch(P.m, s_, k_, left[sl].contiguous(), right[sl].contiguous(), P.margin, P.L,
+                                     X[sl].contiguous(), U[sl].contiguous(), T[sl].contiguous(), max_iter=40, tol=1e-6)
+        torch.cuda.synchronize()
+        alone.append(st.cpu().numpy())
+    # the same two solves on two streams, enqueued back to back
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    outs = []
+    for stream, sl in ((sa, slice(0, 2)), (sb, slice(2, 4))):
+        with torch.cuda.stream(stream):
+            X, U, T = fresh()
+            st = ops.mintime_solve_torch(P.m, s_, k_, left[sl].contiguous(), right[sl].contiguous(), P.margin, P.L,
+                                         X[sl].contiguous(), U[sl].contiguous(), T[sl].contiguous(), max_iter=40, tol=1e-6)
+            outs.append(st)
+    torch.cuda.synchronize()
+    for a_, o_ in zip(alone, outs):
+        np.testing.assert_array_equal(o_.cpu().numpy(), a_)
