@@ -399,3 +399,36 @@ def test_replay_of_the_first_steps_equals_the_plain_pipeline(fits, rings):
             assert x[0] == rep[j, 9] and x[1] == rep[j, 10]
             assert rep[j, 5] <= x[0] <= rep[j, 6] and rep[j, 7] <= x[1] <= rep[j, 8]
     assert (rep[:, 11:15] > 0).all() and (rep[:, 11:15] < 1.0).all()
+
+
+def test_joint_window_replay_instrument(fits, rings):
+    """orc_replay_joint_windows (the teacher-forced instrument of tests/test_hip_parity.py::test_joint_windows_teacher_forced)
+    pinned on the CPU: fed window by window with ITS OWN state it must reproduce orc_run_joint_min_curvature_qp bit for
+    bit; relaxing / tightening every bound by eps_b can only make a window easier / harder, and the optimum of the
+    window as assembled lies between the two."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    n, N, ist = len(cx), 200, [28]
+    j_max, i_min = n - 3 - 5, 2
+    ox, oy = cx.copy(), cy.copy()
+    n_ok = n_noise = 0
+    for stp in range(j_max - i_min):
+        kk = stp + ist[0]
+        if kk >= j_max:
+            kk = kk - j_max + i_min
+        head, rows = orc.replay_joint_windows(t, k, N, rings[0], rings[1], [kk], ox[None], oy[None], nthreads=1)
+        o = head[0]
+        strict_ok, relaxed_ok, tight_ok = (o[0] == 0.0 and o[1] == 0.0), o[35] == 1.0, o[36] == 1.0
+        assert (not tight_ok or strict_ok) and (not strict_ok or relaxed_ok), (stp, o[:2], o[35:37])
+        n_noise += relaxed_ok and not tight_ok
+        if strict_ok:
+            fscale = 1e-12 + abs(o[39])
+            assert o[37] <= o[39] + 1e-9 * fscale and (not tight_ok or o[39] <= o[38] + 1e-9 * fscale), (stp, o[37:40])
+            ox[kk:kk + 5], oy[kk:kk + 5] = o[5:10], o[10:15]
+            ox[0], oy[0] = ox[n - 5], oy[n - 5]; ox[1], oy[1] = ox[n - 4], oy[n - 4]
+            ox[n - 3], oy[n - 3] = ox[2], oy[2]; ox[n - 2], oy[n - 2] = ox[3], oy[3]; ox[n - 1], oy[n - 1] = ox[4], oy[4]
+            n_ok += 1
+        assert rows.shape == (1, N, 9) and int(o[3]) < int(o[4]) <= N
+    fcx, fcy, _, fns = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist)
+    np.testing.assert_array_equal(fcx, ox); np.testing.assert_array_equal(fcy, oy)
+    assert int(fns.sum()) == n_ok and n_ok > 5
+    print(f"joint replay instrument: {n_ok} windows accepted, {n_noise} windows whose verdict an eps_b change of the bounds reverses")
