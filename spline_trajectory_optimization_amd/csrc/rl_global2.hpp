@@ -30,7 +30,7 @@ __host__ __device__ constexpr int g2_round(int groups) { return groups == 1 ? 17
 constexpr int kG2Block = 512;  // 7 row waves + 1 linear-algebra wave; 256 VGPRs per lane
 
 struct Global2Layout {  // offsets in doubles
-  int xs, xs2, dxa, dxs, avs, qv, rdP, rd, rhs, cxs, cys, nus, Pc, Ssum, Spart, lohi, red, ctl, sch, total;
+  int xs, xs2, dxa, dxs, avs, qv, rdP, rd, rhs, cxs, cys, nus, Pc, band, itab, Ssum, Spart, lohi, red, ctl, sch, total;
 };
 
 __host__ __device__ inline Global2Layout global2_layout(int k, int n, int np, int N, int groups, int nrow) {
@@ -42,6 +42,8 @@ __host__ __device__ inline Global2Layout global2_layout(int k, int n, int np, in
   L.rd = take(np); L.rhs = take(np);
   L.cxs = take(n); L.cys = take(n); L.nus = take(2 * np);
   L.Pc = take(np * K1);
+  L.band = take(np * K1);   // the normal matrix as a cyclic band, band[j][d] = M[j][j-d]: the np (K+1) DISTINCT values of it
+  L.itab = take(groups == 1 ? (NS * 64 + NS * 32 + 3) / 4 : 0);   // int16 index of every image entry in the band (TwoFront)
   L.Ssum = take(np * NO);
   // the folded matrix aliases the staging area; one group: the two-front image [NS][64] + the middle block [NS][32]
   const int spart = nrow * g2_round(groups), mf = groups == 1 ? NS * 64 + NS * 32 + 128 : NS * 64 * groups;  // + 128: broadcast scratch
@@ -252,6 +254,45 @@ struct TwoFront {
     return y;
   }
 
+  static __device__ __forceinline__ int band_index(int p, int col, int np, int K) {   // matrix (folded) row / column -> band[]
+    const int j1 = fold_inv(p, np), j2 = fold_inv(col, np);
+    int d = j1 - j2;
+    if (d < 0) d += np;
+    if (d <= K) return j1 * (K + 1) + d;
+    if (np - d <= K) return j2 * (K + 1) + (np - d);
+    return -1;
+  }
+  // Where every entry of the two register images comes from in the cyclic band (instance independent; built once per
+  // kernel into LDS by all threads): >= 0 index into band[], -1 zero, -2 one (identity padding of the middle block).
+  // Entry order = the images' order: fronts [NS][64 lanes], then middle block [MID][32].
+  static __device__ __forceinline__ void build_index_table(int tid, int nt, int np, short* itab) {
+    constexpr int K = BW / 2;
+    const int T = fronts(np), mid = np - 2 * T;
+    for (int task = tid; task < NS * 64 + MID * 32; task += nt) {
+      int ix = -1;
+      if (task < NS * 64) {
+        const int s = task >> 6, l = task & 63, i = l & 31;
+        const bool bottom = l >= 32;
+        if (T > 0 && i < T + BW) {
+          const int q = slot_col(i, s);
+          if (q >= 0 && q < T + BW) ix = band_index(bottom ? np - 1 - i : i, bottom ? np - 1 - q : q, np, K);
+        }
+      } else {
+        const int m = task - NS * 64, j = m >> 5, i = m & 31;
+        if (i < mid && j < mid) ix = band_index(T + i, T + j, np, K);
+        else if (i == j && i < MID) ix = -2;
+      }
+      itab[task] = (short)ix;
+    }
+  }
+  // the images from the band (all threads; after the band is complete)
+  static __device__ __forceinline__ void fill_images(int tid, int nt, const short* itab, const double* band, double* Mf) {
+    for (int task = tid; task < NS * 64 + MID * 32; task += nt) {
+      const int ix = itab[task];
+      const double v = band[ix < 0 ? 0 : ix];
+      Mf[task] = ix >= 0 ? v : (ix == -2 ? 1.0 : 0.0);
+    }
+  }
   __device__ __forceinline__ void load(const double* Mf, int lane) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) S[s] = Mf[s * 64 + lane];
@@ -507,38 +548,16 @@ __device__ __forceinline__ void g2_assemble(int tid, int nt, int np, const doubl
   }
 }
 
-// the same for the two-front factorisation (np <= 64): the fronts image Mf[s][64 lanes] (lanes 0..31 rows of the folded
-// matrix, lanes 32..63 rows of the index-reversed one; only the T + BW rows a front touches) and the middle block
-// Mm[j][32] = M[T + i][T + j] (dense, padded with the identity up to MID rows)
+// np <= 64 (two-front factorisation): the normal matrix P + A'DA has only np (K+1) distinct entries -- the cyclic band
+// band[j][d] = M[j][j-d] -- so that is all that is assembled; the linear-algebra wave picks its register image out of it
+// (TwoFront::load).  Plus the dual residual rd and the first right-hand side.
 template <int K>
-__device__ __forceinline__ void g2_assemble_tf(int tid, int nt, int np, const double* Pc, const double* Ssum,
-                                               const double* rdP, double* Mf, double* rd, double* rhs) {
-  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1, BW = 2 * K, NS = 2 * BW + 1, MID = NS;
-  const int T = TwoFront<BW>::fronts(np), mid = np - 2 * T;
-  auto entry = [&](int p, int col) {
-    const int j1 = fold_inv(p, np), j2 = fold_inv(col, np);
-    int d = j1 - j2;
-    if (d < 0) d += np;
-    if (d <= K) return g2_band_entry<K>(Pc, Ssum, np, j1, d);
-    if (np - d <= K) return g2_band_entry<K>(Pc, Ssum, np, j2, np - d);
-    return 0.0;
-  };
-  double* Mm = Mf + NS * 64;
-  for (int task = tid; task < NS * 64 + MID * 32; task += nt) {
-    double v = 0.0;
-    if (task < NS * 64) {
-      const int s = task >> 6, l = task & 63, i = l & 31;
-      const bool bottom = l >= 32;
-      if (T > 0 && i < T + BW) {
-        const int q = TwoFront<BW>::slot_col(i, s);
-        if (q >= 0 && q < T + BW) v = entry(bottom ? np - 1 - i : i, bottom ? np - 1 - q : q);
-      }
-    } else {
-      const int m = task - NS * 64, j = m >> 5, i = m & 31;
-      if (i < mid && j < mid) v = entry(T + i, T + j);
-      else if (i == j && i < MID) v = 1.0;
-    }
-    Mf[task] = v;
+__device__ __forceinline__ void g2_assemble_band(int tid, int nt, int np, const double* Pc, const double* Ssum,
+                                                 const double* rdP, double* band, double* rd, double* rhs) {
+  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, NO = NE + 2 * K1;
+  for (int task = tid; task < np * K1; task += nt) {
+    const int j = task / K1, d = task - j * K1;
+    band[task] = g2_band_entry<K>(Pc, Ssum, np, j, d);
   }
   for (int j = tid; j < np; j += nt) {
     double s1 = 0.0, s2 = 0.0;
@@ -621,13 +640,15 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
   const Global2Layout L = global2_layout(K, n, np, N, G, nrow);
   double *xsA = lds + L.xs, *xsB = lds + L.xs2, *dxa = lds + L.dxa, *dxs = lds + L.dxs, *avs = lds + L.avs, *qv = lds + L.qv, *rdP = lds + L.rdP;
   double *rd = lds + L.rd, *rhs = lds + L.rhs, *cxs = lds + L.cxs, *cys = lds + L.cys, *nus = lds + L.nus;
-  double *Pc = lds + L.Pc, *Ssum = lds + L.Ssum, *Spart = lds + L.Spart, *Mf = lds + L.Spart;
+  double *Pc = lds + L.Pc, *band = lds + L.band, *Ssum = lds + L.Ssum, *Spart = lds + L.Spart, *Mf = lds + L.Spart;
+  short* itab = reinterpret_cast<short*>(lds + L.itab);
   double *lohi = lds + L.lohi, *red = lds + L.red, *ctl = lds + L.ctl;
   int* sch = reinterpret_cast<int*>(lds + L.sch);
   const double* __restrict__ wid = a.widths + (size_t)b * N * 2;
 
   for (int j = tid; j < np; j += nt) { nus[2 * j] = a.nu[2 * j]; nus[2 * j + 1] = a.nu[2 * j + 1]; avs[j] = 0.0; }
   for (int j = tid; j <= np; j += nt) sch[j] = a.span_ch0[j];
+  if constexpr (G == 1) TwoFront<BW>::build_index_table(tid, nt, np, itab);
   for (int i = tid; i < N; i += nt) {
     const double2 w = reinterpret_cast<const double2*>(wid)[i];
     reinterpret_cast<double2*>(lohi)[i] = make_double2(-(w.y - a.margin), w.x - a.margin);
@@ -825,9 +846,13 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         }
         G2_LAP(0);
         // [I2]
-        if constexpr (G == 1) g2_assemble_tf<K>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
-        else g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        if constexpr (G == 1) {
+          g2_assemble_band<K>(tid, nt, np, Pc, Ssum, rdP, band, rd, rhs);
+          __syncthreads();
+          TwoFront<BW>::fill_images(tid, nt, itab, band, Mf);
+        } else g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
         __syncthreads();
+        G2_LAP(2);   // assembly of the normal matrix (all threads) up to its barrier
         // [I3]
         __syncthreads();
         G2_LAP(1);
@@ -1077,8 +1102,11 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
         }
         // [I2]
         const double mu_sum = red_sum(0), rpmax = red_max(2);
-        if constexpr (G == 1) g2_assemble_tf<K>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
-        else g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
+        if constexpr (G == 1) {
+          g2_assemble_band<K>(tid, nt, np, Pc, Ssum, rdP, band, rd, rhs);
+          __syncthreads();
+          TwoFront<BW>::fill_images(tid, nt, itab, band, Mf);
+        } else g2_assemble<K, G>(tid, nt, np, Pc, Ssum, rdP, Mf, rd, rhs);
         __syncthreads();
         // [I3]
         bool conv;
