@@ -176,6 +176,41 @@ def test_global_kernel_vs_twin(rl, fits, tag, N, n_outer):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["k3_np56", "oval_np27", "k5_few_knots", "k3_few_knots"])
+def test_two_front_factorisation_shapes(rl, shape):
+    """The two-front factorisation of k_global_qp2 (n_p <= 64) on the shapes the Monza fixtures do not reach: degree 3
+    (half-bandwidth 6, TwoFront<6>), few fronts (oval: n_p = 27 -> 3 front columns + a 21-row middle block) and no front
+    at all (n_p <= 2 * bandwidth: the whole matrix is the middle block).  Splines are fitted here (host FITPACK, as
+    everywhere); against the CPU twin."""
+    from spline_trajectory_optimization_amd.models.trajectory import BSplineTrajectory
+    N, n_outer = 1000, 3
+    if shape == "oval_np27":
+        line = rl.batch.oval_centerline(100.0, 5)
+        wl, wr = rl.batch.oval_half_widths(N)
+        n_outer = 1   # (the Gauss-Newton step of the first linearisation is 21 m on the oval's straights, where the curvature
+        #               vanishes; the second linearisation is singular in the formulation itself -- the twin returns NaN too)
+    else:
+        centre, _, _ = rl.batch.load_monza()
+        s_, k_ = {"k3_np56": (100.0, 3), "k5_few_knots": (1e5, 5), "k3_few_knots": (1e5, 3)}[shape]
+        line = BSplineTrajectory(centre, s_, k_)
+        wl = np.full(N, 5.0) + np.sin(np.arange(N) * 0.02); wr = np.full(N, 4.5) + np.cos(np.arange(N) * 0.03)
+    t, cx, cy, k = line._tck()
+    n_p = len(cx) - k
+    assert n_p <= 64, n_p
+    if shape.endswith("few_knots"):
+        assert n_p <= 4 * k, n_p      # no front column: T = 0
+    ocx, ocy, oxy, oa, ost = orc.global_mincurv(t, cx, cy, k, N, wl, wr, MARGIN, n_outer)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    ctrl, xy, a, st, rs = rl.ops.global_batch_host(trk, np.stack([wl, wr], 1)[None], MARGIN, n_outer)
+    da, dxy = np.abs(a[0] - oa).max(), np.abs(xy[0] - oxy).max()
+    print(f"[two-front {shape}: k={k} n_p={n_p}] |da| {da:.2e} m |dxy| {dxy:.2e} m  ipm {int(st[0, 0])}/{int(ost[0])}  "
+          f"block {rs.block_threads} lds {rs.lds_bytes}  {rs.kernel_ms:.2f} ms")
+    assert rs.block_threads > 64 and rs.block_threads % 64 == 0          # the wave-specialised kernel ran
+    assert da <= 1e-6 and dxy <= 1e-6 and st[0, 3] <= 1e-9
+    assert abs(int(st[0, 0]) - int(ost[0])) <= 1
+
+
+@pytest.mark.gpu
 def test_global_batch_properties_full_size(rl, fits):
     """BASELINE configs[1] shape (Monza N=2000, 1024 width-perturbed instances): properties that need
     no CPU run -- inside the bounds, cost decreased, bit-reproducible, position-independent -- plus a
