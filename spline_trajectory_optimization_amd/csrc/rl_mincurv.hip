@@ -1230,10 +1230,10 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
         hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, G.nb, rl::kMtHesSlices), bn64, 0, G.q, G.P, G.st);
       } else {
         hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + 63) / 64, G.nb, 24), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + rl::kMtJacNodes - 1) / rl::kMtJacNodes, G.nb, 3), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3((N + 63) / 64, G.nb, rl::kMtPairs8), bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_hes_point<1>, dim3((N + 63) / 64, G.nb, 2 * rl::kMtPairs8), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3(rl::mt_hes_blocks(N), G.nb, rl::kMtHesZ), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_point<1>, dim3(rl::mt_hes_blocks(N), G.nb, 2 * rl::kMtHesZ), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_hes_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
       }
       hipLaunchKernelGGL(rl::k_mt_prepare, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
@@ -1260,7 +1260,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, G.nb, rl::kMtJacSlices), bn64, 0, G.q, G.P, G.st);
     } else {
       hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + 63) / 64, G.nb, 24), bn64, 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + rl::kMtJacNodes - 1) / rl::kMtJacNodes, G.nb, 3), bn64, 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
     }
     hipLaunchKernelGGL(rl::k_mt_residuals, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);

@@ -427,11 +427,14 @@ __device__ __forceinline__ void mt_own_rows_each(const MtProblem& P, const S (&Y
   r[5] = (Y[4] * fd - p[DT_PMAX]) / p[DT_PMAX];
 }
 
-// grid (node blocks, B, 24): Jacobians of f at the two ends and at the midpoint, one direction per thread; the
-// first end also differentiates its own curved rows, the midpoint leaves the value of f there
+// grid (blocks of 8 nodes, B, 3): Jacobians of f at the two ends and at the midpoint, one direction per thread; the
+// first end also differentiates its own curved rows, the midpoint leaves the value of f there.  Lane = (node, direction):
+// the eight directions of a node write eight consecutive doubles of its row (64 B segments instead of lone 8 B words
+// 2.7 KB apart), and read the node's unknowns as broadcasts.
+constexpr int kMtJacNodes = 8;
 __global__ void __launch_bounds__(64) k_mt_jac_dirs(MtProblem P, MtState st) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
-  const int pt = blockIdx.z >> 3, d = blockIdx.z & 7;
+  const int j = blockIdx.x * kMtJacNodes + ((int)threadIdx.x >> 3), b = blockIdx.y, N = P.N;
+  const int pt = blockIdx.z, d = threadIdx.x & 7;
   if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
   const int jn = j + 1 == N ? 0 : j + 1;
   double Y[5], Yn[5], U[3], t;
@@ -540,12 +543,17 @@ __global__ void __launch_bounds__(64) k_mt_jac_assemble(MtProblem P, MtState st)
   }
 }
 
-// grid (node blocks, B, 36 [MID] or 72 [ENDS]): one pair of directions of one dynamics evaluation per thread
+// grid (blocks of 7 nodes, B, 4 [MID] or 8 [ENDS]): one pair of directions of one dynamics evaluation per thread.
+// Lane = (node, pair): nine consecutive pairs of a node per wave (63 lanes), so that a node's results leave as 72 B
+// segments and its unknowns arrive as broadcasts.
+constexpr int kMtHesNodes = 7, kMtHesPairs = 9, kMtHesZ = kMtPairs8 / kMtHesPairs;
+__host__ __device__ constexpr int mt_hes_blocks(int N) { return (N + kMtHesNodes - 1) / kMtHesNodes; }
 template <int ENDS>
-__global__ void __launch_bounds__(64) k_mt_hes_point(MtProblem P, MtState st) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
-  const int pt = ENDS ? (int)blockIdx.z / kMtPairs8 : 0, q = ENDS ? (int)blockIdx.z % kMtPairs8 : (int)blockIdx.z;
-  if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+__global__ void __launch_bounds__(64, 2) k_mt_hes_point(MtProblem P, MtState st) {
+  const int nl = (int)threadIdx.x / kMtHesPairs, ql = (int)threadIdx.x - kMtHesPairs * nl;
+  const int j = blockIdx.x * kMtHesNodes + nl, b = blockIdx.y, N = P.N;
+  const int pt = ENDS ? (int)blockIdx.z / kMtHesZ : 0, q = ((int)blockIdx.z % kMtHesZ) * kMtHesPairs + ql;
+  if (nl >= kMtHesNodes || j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
   const int jn = j + 1 == N ? 0 : j + 1;
   const size_t o = (size_t)b * N + j;
   double Y[5], Yn[5], U[3], t;
