@@ -87,6 +87,7 @@ struct rl_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
   bool mt_poll = false;          // set by the HOST entry point of the min-time solve around its call of the _dev one: poll for early exit
   bool mt_hes_sweep = false;     // RL_MT_HES_SWEEP=1: the Hessian by k_mt_derivs<2> instead of the chain-rule kernels
+  bool mt_unfused = false;       // RL_MT_UNFUSED=1: Jacobian / Hessian / block assembly by the four separate kernels instead of k_mt_node
   int mt_groups = 3;             // RL_MT_GROUPS=1..4 (measured at 256 / 1024 instances: 3.66 / 11.55 s, 3.31 / 11.05, 3.14 / 10.53, 3.11 / 10.59)
   // Device staging blocks of the HOST-pointer entry points (PoolBuf): handed out best-fit, returned at the end of
   // the call, freed with the context -- a second call of the same shape allocates nothing.
@@ -355,6 +356,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
   c->num_cu = prop.multiProcessorCount;
   if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
   if (const char* v = getenv("RL_MT_HES_SWEEP")) c->mt_hes_sweep = v[0] == '1';
+  if (const char* v = getenv("RL_MT_UNFUSED")) c->mt_unfused = v[0] == '1';
   if (const char* v = getenv("RL_MT_GROUPS")) { const int g = atoi(v); if (g >= 1 && g <= rl_ctx::kMaxGroups) c->mt_groups = g; }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
@@ -1131,7 +1133,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   const size_t bn = (size_t)B * N;
   const size_t counts[] = {bn * rl::kMtNv, bn * rl::kMtNi, bn * rl::kMtNe, bn * rl::kMtNi, bn * rl::kMtNf,
                            bn * rl::kMtNf * rl::kMtLoc, bn * rl::kMtLoc * rl::kMtLoc, bn * rl::kMtNv, bn * rl::kMtNe,
-                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16, (size_t)B * 2 * rl::kMtFilter, bn * rl::kMtHw};
+                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16, (size_t)B * 2 * rl::kMtFilter, bn * rl::kMtHw, bn * 16};
   size_t total = 0;
   for (size_t c : counts) total += Arena::pad(c * sizeof(double));
   Arena ar(ctx);
@@ -1143,7 +1145,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.hes = ar.take<double>(counts[6]); st.dw = ar.take<double>(counts[7]); st.dy = ar.take<double>(counts[8]);
   st.blk = ar.take<double>(counts[9]); st.vec = ar.take<double>(counts[10]); st.scal = ar.take<double>(counts[11]);
   st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
-  st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]);
+  st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]); st.r1 = ar.take<double>(counts[17]);
   st.tol = tol;
   double mt_mu0, mt_delta0;
   {
@@ -1167,7 +1169,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     mt_mu0 = knob("RL_MT_MU0", 1e-1); mt_delta0 = knob("RL_MT_DELTA0", 1e-4);
   }
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
-  RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
+  if (ctx->mt_hes_sweep) RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
   // A few sub-batches on as many streams: the KKT elimination is one wave per instance and latency bound (its time
   // does not depend on the batch), the derivative kernels are throughput bound -- with the sub-batches offset by the
   // in-order queues one's elimination runs beside another's derivatives.  Instances are independent, so the split
@@ -1195,7 +1197,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     G.st.w = st.w + o * rl::kMtNv; G.st.s = st.s + o * rl::kMtNi; G.st.y = st.y + o * rl::kMtNe; G.st.z = st.z + o * rl::kMtNi;
     G.st.fun = st.fun + o * rl::kMtNf; G.st.jac = st.jac + o * rl::kMtNf * rl::kMtLoc; G.st.hes = st.hes + o * rl::kMtLoc * rl::kMtLoc;
     G.st.dw = st.dw + o * rl::kMtNv; G.st.dy = st.dy + o * rl::kMtNe; G.st.blk = st.blk + o * 3 * 256; G.st.vec = st.vec + o * 16;
-    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.filt = st.filt + (size_t)G.b0 * 2 * rl::kMtFilter; G.st.hw = st.hw + o * rl::kMtHw; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16;
+    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.filt = st.filt + (size_t)G.b0 * 2 * rl::kMtFilter; G.st.hw = st.hw + o * rl::kMtHw; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16; G.st.r1 = st.r1 + o * 16;
     G.X = X + o * 6; G.U = U + o * 4; G.T = T + o; G.stats = stats + (size_t)G.b0 * 12;
   }
   if (ngrp > 1) {   // fork: the other streams start after everything already enqueued on the first
@@ -1231,13 +1233,20 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       } else {
         hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + rl::kMtJacNodes - 1) / rl::kMtJacNodes, G.nb, 3), bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
+        if (ctx->mt_unfused) hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3(rl::mt_hes_blocks(N), G.nb, rl::kMtHesZ), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_hes_point<1>, dim3(rl::mt_hes_blocks(N), G.nb, 2 * rl::kMtHesZ), bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_hes_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
+        if (ctx->mt_unfused) {
+          hipLaunchKernelGGL(rl::k_mt_hes_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
+        } else {   // Jacobian, Hessian, blocks and right-hand side in one pass over the pairs
+          hipLaunchKernelGGL(rl::k_mt_node, dim3((N + rl::kMtRun - 1) / rl::kMtRun, G.nb), bn64, 0, G.q, G.P, G.st);
+          hipLaunchKernelGGL(rl::k_mt_prepare2, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
+        }
       }
-      hipLaunchKernelGGL(rl::k_mt_prepare, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
+      if (ctx->mt_hes_sweep || ctx->mt_unfused) {
+        hipLaunchKernelGGL(rl::k_mt_prepare, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
+      }
       hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_step, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
     }

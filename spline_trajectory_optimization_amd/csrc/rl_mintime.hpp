@@ -190,6 +190,7 @@ struct MtState {       // per-batch device arrays, instance-major
   double* dblk;   // [B,N,256] assembled diagonal blocks D_j (without delta)
   double* eblk;   // [B,N,256] assembled coupling blocks E_j = M[j+1][j]
   double* rhs;    // [B,N,16]  assembled right-hand sides
+  double* r1;     // [B,N,16]  k_mt_node: 0..8 the coefficient of mu in the right-hand side, 9 the node's max |r_d|
   double* hw;     // [B,N,kMtHw] work array of the chain-rule Hessian (k_mt_hes_*)
   double* filt;   // [B,16] filter: (infeasibility, barrier objective) of up to 8 earlier iterates of the current barrier problem
   double* scal;   // [B,16] per-instance scalars: 0 mu, 1 delta, 2 kkt, 3 viol, 4 compl, 5 status (0 run, 1 converged,
@@ -918,6 +919,278 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
   }
 }
 
+// k_mt_node: Jacobian, Hessian and KKT blocks of the node pairs in ONE pass (the default; k_mt_jac_assemble,
+// k_mt_hes_assemble, k_mt_prepare and k_mt_assemble stay as the path of the forward-over-forward cross-check).
+// The three kernels it replaces were bound by memory: every pair's 24 x 18 Jacobian and 18 x 18 Hessian went to HBM
+// and came back twice (for the pair itself and for its successor, which needs the "next node" columns):
+// 25 KB per node and iteration, 4 TB/s in k_mt_assemble.  Here one wave walks kMtRun consecutive pairs; Jacobian and
+// Hessian of the pair live in LDS, and what the NEXT node's diagonal block and right-hand side need of them
+// (Dn = Hess_nn + Gn' W Gn, An' y + Gn' zeta, ...) is carried to the next pair in LDS -- the wave starts one pair
+// early to have the carry of its first node (1 / kMtRun more work).  The Jacobian is still written (k_mt_step and
+// the final residuals read it), the Hessian is not.  The work array of the next pair is fetched into registers
+// while the current pair is processed.
+//   The barrier parameter is updated from the residuals of ALL nodes (k_mt_prepare2, afterwards), so the right-hand
+// side leaves in two pieces: rhs0 (everything but the mu / s term of zeta) and r1 = G' (1 / s); k_mt_prepare2 forms
+// rhs = rhs0 - mu r1 with the mu it has just chosen.  r1[9] carries the node's max |r_d| to the convergence test.
+constexpr int kMtRun = 8;
+struct MtNodeLds {
+  double hw[kMtHw];
+  double M[kMtPv][14], JM[6][14], T[kMtPv][14], gpsi[14], gphi[2][kMtPv], gF[2][kMtPv];
+  double J[kMtNf][kMtLoc], H[kMtLoc][kMtLoc];
+  double P3[3][81];                       // Do, Ct, Dn of the pair
+  double cDn[81];                         // Dn of the previous pair
+  double wo[kMtNv], wn[kMtNv], y[kMtNe], z[kMtNi], s[kMtNi], fun[kMtNf];
+  double W[kMtNi], zeta[kMtNi], is[kMtNi];
+  double vo[3][kMtNv], vn[3][kMtNv], cvn[3][kMtNv];   // (A' y + G' W (g + s), G' (1 / s), A' y + G' z): own columns, next node's, carried
+  double up[3];                           // controls of the previous node (cost gradient)
+};
+
+__global__ void __launch_bounds__(64) k_mt_node(MtProblem P, MtState st) {
+  __shared__ MtNodeLds L;
+  const int b = blockIdx.y, lane = threadIdx.x, N = P.N;
+  if (st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  const int j0 = blockIdx.x * kMtRun;
+  const int cnt = N - j0 < kMtRun ? N - j0 : kMtRun;
+  auto pair_of = [&](int it) { return it < 0 ? (j0 == 0 ? N - 1 : j0 - 1) : j0 + it; };
+  // the inputs of a pair: 336 doubles of work array, and 83 of unknowns / multipliers / slacks / functions
+  double pre[8];
+  auto fetch = [&](int j) {
+    const size_t o = (size_t)b * N + j;
+    const int jn = j + 1 == N ? 0 : j + 1;
+    const double* hw = st.hw + o * kMtHw;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pre[k] = lane + 64 * k < kMtHw ? hw[lane + 64 * k] : 0.0;
+    const double* src = lane < 9    ? st.w + o * kMtNv + lane
+                        : lane < 18 ? st.w + ((size_t)b * N + jn) * kMtNv + (lane - 9)
+                        : lane < 25 ? st.y + o * kMtNe + (lane - 18)
+                        : lane < 42 ? st.z + o * kMtNi + (lane - 25)
+                                    : st.s + o * kMtNi + (lane - 42);
+    pre[6] = lane < 59 ? *src : 0.0;
+    pre[7] = lane < kMtNf ? st.fun[o * kMtNf + lane] : 0.0;
+  };
+  auto deposit = [&]() {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (lane + 64 * k < kMtHw) L.hw[lane + 64 * k] = pre[k];
+    if (lane < 9) L.wo[lane] = pre[6];
+    else if (lane < 18) L.wn[lane - 9] = pre[6];
+    else if (lane < 25) L.y[lane - 18] = pre[6];
+    else if (lane < 42) L.z[lane - 25] = pre[6];
+    else if (lane < 59) L.s[lane - 42] = pre[6];
+    if (lane < kMtNf) L.fun[lane] = pre[7];
+  };
+  auto map2 = [](int zi) { return zi >= 9 ? zi - 9 : (zi >= 5 && zi < 8 ? zi : -1); };
+  fetch(pair_of(-1));
+  for (int it = -1; it < cnt; ++it) {
+    const int j = pair_of(it);
+    const size_t o = (size_t)b * N + j;
+    const bool own = it >= 0;
+    deposit();
+    __syncthreads();
+    if (it + 1 < cnt) fetch(pair_of(it + 1));
+    const double* hw = L.hw;
+    const double* J1 = hw + kMtHwJ1;
+    const double* J2 = hw + kMtHwJ2;
+    const double* Jm = hw + kMtHwJm;
+    const double t = L.wo[8] * P.sw[8];
+    // ---- A: M = d(Ym, U) / d(Y, U, t, Y'), gradients at the ends, weights of the inequality rows
+    if (lane < 2 * kMtPv) {
+      const int pt = lane >> 3, a = lane & 7;
+      const double* J = pt ? J2 : J1;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s1 += L.y[c] * P.se[c] * J[c * kMtPv + a];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) s2 += hw[kMtHwGm + r] * J[(1 + r) * kMtPv + a];
+      L.gphi[pt][a] = s1; L.gF[pt][a] = s2;
+    } else if (lane >= 32 && lane < 32 + kMtNi) {
+      const int i = lane - 32;
+      const double s_ = L.s[i], z_ = L.z[i], wgt = z_ / s_;
+      L.W[i] = wgt; L.zeta[i] = wgt * (L.fun[kMtNe + i] + s_); L.is[i] = 1.0 / s_;
+    }
+    for (int e = lane; e < kMtPv * 14; e += 64) {
+      const int r = e / 14, zi = e - 14 * r;
+      double v = 0.0;
+      if (r < 5) {
+        if (zi < 5) v = (zi == r ? 0.5 : 0.0) + (t / 8.0) * J1[(1 + r) * kMtPv + zi];
+        else if (zi < 8) v = (t / 8.0) * (J1[(1 + r) * kMtPv + zi] - J2[(1 + r) * kMtPv + zi]);
+        else if (zi == 8) v = hw[kMtHwDf + r] / 8.0;
+        else v = (zi - 9 == r ? 0.5 : 0.0) - (t / 8.0) * J2[(1 + r) * kMtPv + (zi - 9)];
+      } else {
+        v = zi == r ? 1.0 : 0.0;
+      }
+      L.M[r][zi] = v;
+    }
+    __syncthreads();
+    // ---- B: Jm M, Hm M, M' gm
+    for (int e = lane; e < 6 * 14; e += 64) {
+      const int c = e / 14, zi = e - 14 * c;
+      double v = 0.0;
+#pragma unroll
+      for (int p = 0; p < kMtPv; ++p) v += Jm[c * kMtPv + p] * L.M[p][zi];
+      L.JM[c][zi] = v;
+    }
+    for (int e = lane; e < kMtPv * 14; e += 64) {
+      const int r = e / 14, zi = e - 14 * r;
+      double v = 0.0;
+#pragma unroll
+      for (int p = 0; p < kMtPv; ++p) v += hw[kMtHwHm + mt_tri8(r, p)] * L.M[p][zi];
+      L.T[r][zi] = v;
+    }
+    if (lane < 14) {
+      double v = 0.0;
+#pragma unroll
+      for (int p = 0; p < kMtPv; ++p) v += L.M[p][lane] * hw[kMtHwGm + p];
+      L.gpsi[lane] = v;
+    }
+    __syncthreads();
+    // ---- C: the 24 x 18 Jacobian (as k_mt_jac_assemble) and the 18 x 18 Hessian (as k_mt_hes_assemble)
+    {
+      const double ru = (L.wn[5] - L.wo[5]) * P.sw[5] / t, rd = (L.wn[6] - L.wo[6]) * P.sw[6] / t;
+      double* Jout = st.jac + o * kMtNf * kMtLoc;
+      for (int e = lane; e < kMtNf * kMtLoc; e += 64) {
+        const int row = e / kMtLoc, col = e - kMtLoc * row;
+        double v = 0.0;
+        if (row < 6) {
+          const int c = row;
+          if (col < 14) {
+            const int zi = col;
+            double dv = 4.0 * L.JM[c][zi];
+            if (zi < 5) dv += J1[c * kMtPv + zi];
+            else if (zi < 8) dv += J1[c * kMtPv + zi] + J2[c * kMtPv + zi];
+            else if (zi >= 9) dv += J2[c * kMtPv + (zi - 9)];
+            v = (t / 6.0) * dv;
+            if (zi == 8) v += (hw[kMtHwF + c] + 4.0 * hw[kMtHwF + 12 + c] + hw[kMtHwF + 6 + c]) / 6.0;
+            if (zi < 5 && c == 1 + zi) v += 1.0;
+            if (zi >= 9 && c == 1 + (zi - 9)) v -= 1.0;
+            v *= P.se[c];
+          }
+        } else if (row <= 11) {
+          if (col < kMtPv) v = hw[kMtHwOw + (row - 6) * kMtPv + col];
+        } else {
+          const int gq = row - kMtNe;
+          const double su0 = P.sw[5], su2 = P.sw[6];
+          if (gq == 5) v = col == 4 ? -1.0 / P.sw[4] : 0.0;
+          else if (gq == 6) v = col == 5 ? -1.0 / su0 : 0.0;
+          else if (gq == 7) v = col == 5 ? 1.0 / su0 : 0.0;
+          else if (gq == 8) v = col == 6 ? -1.0 / su2 : 0.0;
+          else if (gq == 9) v = col == 6 ? 1.0 / su2 : 0.0;
+          else if (gq == 10 || gq == 11) {
+            double dr = col == 5 ? -1.0 / t : (col == 14 ? 1.0 / t : (col == 8 ? -ru / t : 0.0));
+            v = (gq == 10 ? -dr : dr) / su0;
+          } else if (gq == 12 || gq == 13) {
+            double dr = col == 6 ? -1.0 / t : (col == 15 ? 1.0 / t : (col == 8 ? -rd / t : 0.0));
+            v = (gq == 12 ? -dr : dr) / su2;
+          } else if (gq == 14) v = col == 0 ? -1.0 / P.sw[0] : 0.0;
+          else if (gq == 15) v = col == 0 ? 1.0 / P.sw[0] : 0.0;
+          else v = col == 8 ? -1.0 : 0.0;
+        }
+        v *= P.sw[col % kMtNv];
+        (&L.J[0][0])[e] = v;
+        if (own) Jout[e] = v;
+      }
+      const double su0 = P.sw[5], su2 = P.sw[6];
+      const double k1 = (L.z[11] - L.z[10]) / su0, k2 = (L.z[13] - L.z[12]) / su2;
+      const double dF = (L.wn[5] - L.wo[5]) * P.sw[5], dD = (L.wn[6] - L.wo[6]) * P.sw[6];
+      for (int e = lane; e < kMtLoc * kMtLoc; e += 64) {
+        const int la = e / kMtLoc, lb = e - kMtLoc * la;
+        double v = 0.0;
+        if (la < 14 && lb < 14) {
+          double sm = 0.0;
+#pragma unroll
+          for (int p = 0; p < kMtPv; ++p) sm += L.M[p][la] * L.T[p][lb];
+          v = (2.0 * t / 3.0) * sm;
+          if (la < 8 && lb < 8) v += hw[kMtHwH1 + mt_tri8(la, lb)];
+          const int a2 = map2(la), b2 = map2(lb);
+          if (a2 >= 0 && b2 >= 0) v += hw[kMtHwH2 + mt_tri8(a2, b2)];
+          if ((la == 8) != (lb == 8)) {
+            const int oth = la == 8 ? lb : la, o2 = map2(oth);
+            v += (2.0 / 3.0) * L.gpsi[oth];
+            if (oth < 8) v += L.gphi[0][oth] / 6.0 + (t / 12.0) * L.gF[0][oth];
+            if (o2 >= 0) v += L.gphi[1][o2] / 6.0 - (t / 12.0) * L.gF[1][o2];
+          } else if (la == 8 && lb == 8) {
+            v += (4.0 / 3.0) * L.gpsi[8];
+          }
+        }
+        const int lo = la < lb ? la : lb, hi = la < lb ? lb : la;
+        if (lo == 8 && hi == 8) v += 2.0 * (k1 * dF + k2 * dD) / (t * t * t);
+        else if (lo == 5 && hi == 8) v += k1 / (t * t);
+        else if (lo == 6 && hi == 8) v += k2 / (t * t);
+        else if (lo == 8 && hi == 14) v -= k1 / (t * t);
+        else if (lo == 8 && hi == 15) v -= k2 / (t * t);
+        (&L.H[0][0])[e] = v * P.sw[la % kMtNv] * P.sw[lb % kMtNv];
+      }
+    }
+    __syncthreads();
+    // ---- D: Do = Hess_oo + Go' W Go, Ct = Hess_no + Gn' W Go, Dn = Hess_nn + Gn' W Gn; the vectors of the right-hand side
+    for (int e = lane; e < 3 * 81; e += 64) {
+      const int which = e / 81, r = e - 81 * which, a = r / 9, c = r - 9 * a;
+      const int ra = which >= 1 ? 9 + a : a, rc = which == 2 ? 9 + c : c;
+      double v = L.H[ra][rc];
+#pragma unroll
+      for (int i = 0; i < kMtNi; ++i) v += L.J[kMtNe + i][ra] * L.W[i] * L.J[kMtNe + i][rc];
+      L.P3[which][r] = v;
+    }
+    if (lane < 2 * kMtNv) {
+      const int side = lane / kMtNv, a = lane - kMtNv * side, col = side * kMtNv + a;
+      double ay = 0.0, gz0 = 0.0, g1 = 0.0, gz = 0.0;
+#pragma unroll
+      for (int c = 0; c < kMtNe; ++c) ay += L.J[c][col] * L.y[c];
+#pragma unroll
+      for (int i = 0; i < kMtNi; ++i) {
+        const double g = L.J[kMtNe + i][col];
+        gz0 += g * L.zeta[i]; g1 += g * L.is[i]; gz += g * L.z[i];
+      }
+      double (*dst)[kMtNv] = side ? L.vn : L.vo;
+      dst[0][a] = ay + gz0; dst[1][a] = g1; dst[2][a] = ay + gz;
+    }
+    __syncthreads();
+    // ---- E: the node's blocks and right-hand side (its own pair + the carry of the previous one)
+    if (own) {
+      double* Dg = st.dblk + o * 256;
+      double* Eg = st.eblk + o * 256;
+      for (int e = lane; e < 256; e += 64) {
+        const int i = e >> 4, c = e & 15;
+        double d = 0.0, ev = 0.0;
+        if (i < 9 && c < 9) {
+          d = L.P3[0][i * 9 + c] + L.cDn[i * 9 + c];
+          ev = L.P3[1][i * 9 + c];
+          if (i == c && i >= 5 && i < 8) { d += kMtCostDiag; ev += kMtCostOff; }
+        } else if (i < 9) {
+          d = L.J[c - 9][i];
+          ev = L.J[c - 9][9 + i];
+        } else if (c < 9) {
+          d = L.J[i - 9][c];
+        } else if (i == c) {
+          d = -kMtEpsReg;
+        }
+        Dg[e] = d; Eg[e] = ev;
+      }
+      double r0 = 0.0, r1 = 0.0, rdv = 0.0;
+      if (lane < kMtNv) {
+        const int a = lane;
+        double gc = a == 8 ? 1.0 : 0.0;
+        if (a >= 5 && a < 8) gc = 2e-4 * L.wo[a] + 2e-1 * (2.0 * L.wo[a] - L.wn[a] - L.up[a - 5]);
+        r0 = gc + L.vo[0][a] + L.cvn[0][a];
+        r1 = L.vo[1][a] + L.cvn[1][a];
+        rdv = fabs(gc + L.vo[2][a] + L.cvn[2][a]);
+      } else if (lane < 16) {
+        r0 = L.fun[lane - kMtNv];
+      }
+      const double kk = wave_max(rdv);
+      if (lane < 16) {
+        st.rhs[o * 16 + lane] = -r0;
+        st.r1[o * 16 + lane] = lane == kMtNv ? kk : r1;
+      }
+    }
+    __syncthreads();
+    // the carry for the next pair
+    for (int e = lane; e < 81; e += 64) L.cDn[e] = L.P3[2][e];
+    if (lane < 3 * kMtNv) (&L.cvn[0][0])[lane] = (&L.vn[0][0])[lane];
+    if (lane < 3) L.up[lane] = L.wo[5 + lane];
+    __syncthreads();
+  }
+}
+
 // k_mt_kkt: two waves per instance: block elimination of the cyclic block-tridiagonal KKT system from the
 // assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.
 //
@@ -1189,7 +1462,57 @@ __device__ __forceinline__ double mt_block_reduce(double v, double* red, int op 
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_mt_step(MtProblem P, MtState st) {
+// k_mt_prepare2: one workgroup per instance, after k_mt_node: convergence test and barrier update as k_mt_prepare
+// (the stationarity residual comes per node from k_mt_node), then the right-hand side rhs = rhs0 - mu r1
+__global__ void __launch_bounds__(256) k_mt_prepare2(MtProblem P, MtState st) {
+  __shared__ double red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
+  double* scal = st.scal + (size_t)b * 16;
+  if (scal[5] != 0.0) return;
+  const double* w = st.w + (size_t)b * N * kMtNv;
+  const double* sv = st.s + (size_t)b * N * kMtNi;
+  const double* zv = st.z + (size_t)b * N * kMtNi;
+  const double* fun = st.fun + (size_t)b * N * kMtNf;
+  const double* r1 = st.r1 + (size_t)b * N * 16;
+  double* rhs = st.rhs + (size_t)b * N * 16;
+  double mu = scal[0];
+  double kkt = 0.0, viol = 0.0, compl_ = 0.0, errmu = 0.0, lap = 0.0;
+  for (int j = tid; j < N; j += 256) {
+    kkt = fmax(kkt, r1[(size_t)j * 16 + kMtNv]);
+    lap += w[(size_t)j * kMtNv + 8] * P.sw[8];
+  }
+  for (int idx = tid; idx < N * kMtNe; idx += 256) {
+    const int j = idx / kMtNe, c = idx - j * kMtNe;
+    viol = fmax(viol, fabs(fun[j * kMtNf + c]));
+  }
+  for (int idx = tid; idx < N * kMtNi; idx += 256) {
+    const int j = idx / kMtNi, c = idx - j * kMtNi;
+    const double s_ = sv[idx], z_ = zv[idx];
+    viol = fmax(viol, fabs(fun[j * kMtNf + kMtNe + c] + s_));
+    compl_ = fmax(compl_, s_ * z_);
+    errmu = fmax(errmu, fabs(s_ * z_ - mu));
+  }
+  kkt = -mt_block_reduce<256>(-kkt, red, 1); viol = -mt_block_reduce<256>(-viol, red, 1);
+  compl_ = -mt_block_reduce<256>(-compl_, red, 1); errmu = -mt_block_reduce<256>(-errmu, red, 1);
+  lap = mt_block_reduce<256>(lap, red, 0);
+  if (tid == 0) { scal[2] = kkt; scal[3] = viol; scal[4] = compl_; scal[11] = lap; }
+  if (fmax(kkt, fmax(viol, compl_)) <= st.tol) {
+    if (tid == 0) scal[5] = 1.0;
+    return;
+  }
+  if (fmax(fmax(kkt, viol), errmu) <= st.mu_kappa * mu) {
+    const double mu_new = fmax(fmin(st.mu_fac * mu, pow(mu, st.mu_pow)), st.tol / 10.0);
+    if (mu_new != mu && tid == 0) scal[14] = 0.0;
+    mu = mu_new;
+  }
+  if (tid == 0) scal[0] = mu;
+  for (int idx = tid; idx < N * kMtNv; idx += 256) {
+    const int j = idx / kMtNv, a = idx - j * kMtNv;
+    rhs[(size_t)j * 16 + a] = fma(-mu, r1[(size_t)j * 16 + a], rhs[(size_t)j * 16 + a]);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
   __shared__ double red[8];
   const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
   double* scal = st.scal + (size_t)b * 16;

@@ -138,6 +138,33 @@ def test_hessian_chain_rule_vs_forward_over_forward_sweep(tmp_path):
 
 
 @pytest.mark.gpu
+def test_fused_node_kernel_vs_separate_assembly_kernels(tmp_path):
+    """k_mt_node (Jacobian, Hessian, KKT blocks and right-hand side of the node pairs in one pass, the default) against
+    the four kernels it replaces (RL_MT_UNFUSED=1: k_mt_jac_assemble, k_mt_hes_assemble, k_mt_prepare, k_mt_assemble):
+    same formulas entry by entry; only the right-hand side is summed in another order (rhs0 - mu r1).  After 12
+    iterations from the QSS warm start the iterates agree to rounding, after 80 to 1e-7."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for iters, tol in (("12", 1e-9), ("80", 1e-7)):
+        out = {}
+        for mode in ("0", "1"):
+            f = str(tmp_path / f"fu_{mode}_{iters}.npz")
+            env = dict(os.environ, RL_MT_UNFUSED=mode)
+            subprocess.run([sys.executable, os.path.join(here, "mintime_run.py"), f, iters], check=True, env=env, timeout=300)
+            out[mode] = np.load(f)
+        a, b = out["0"], out["1"]
+        su = np.maximum(np.abs(b["U"]).max(axis=(0, 1)), 1.0)
+        dev = max(np.abs(a["X"] - b["X"]).max(), np.abs(a["T"] - b["T"]).max(), np.abs((a["U"] - b["U"]) / su).max())
+        print(f"fused vs separate kernels, max_iter {iters}: iterations {a['st'][0, 0]:.0f} / {b['st'][0, 0]:.0f}, "
+              f"max deviation {dev:.2e}, kkt {a['st'][0, 1]:.3e} / {b['st'][0, 1]:.3e}, status {a['st'][0, 5]:.0f} / {b['st'][0, 5]:.0f}")
+        assert a["st"][0, 5] == b["st"][0, 5]
+        assert abs(a["st"][0, 0] - b["st"][0, 0]) <= (0 if iters == "12" else 2)
+        assert dev <= tol, dev
+
+
+@pytest.mark.gpu
 def test_mintime_batch_with_per_instance_widths(coarse):
     """A batch of tracks that differ in their widths (BASELINE config 2's perturbation applied to config 5):
     instances are independent (a duplicate agrees bit for bit, instance 0 equals the single solve), wider tracks
