@@ -1234,8 +1234,8 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
         hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + rl::kMtJacNodes - 1) / rl::kMtJacNodes, G.nb, 3), bn64, 0, G.q, G.P, G.st);
         if (ctx->mt_unfused) hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3(rl::mt_hes_blocks(N), G.nb, rl::kMtHesZ), bn64, 0, G.q, G.P, G.st);
-        hipLaunchKernelGGL(rl::k_mt_hes_point<1>, dim3(rl::mt_hes_blocks(N), G.nb, 2 * rl::kMtHesZ), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3(rl::mt_hes_blocks(N), G.nb, 1), bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_hes_point<1>, dim3(rl::mt_hes_blocks(N), G.nb, 2), bn64, 0, G.q, G.P, G.st);
         if (ctx->mt_unfused) {
           hipLaunchKernelGGL(rl::k_mt_hes_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
         } else {   // Jacobian, Hessian, blocks and right-hand side in one pass over the pairs
@@ -1248,7 +1248,11 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
         hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
       }
       hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_step, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_dir, dim3(rl::kMtDirBlocks(N), G.nb), bn64, 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_step_red, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_trial, gn, bn64, 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_step_fin, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_step_back, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
     }
     if (ctx->mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
       std::vector<double> h((size_t)B * 16);
@@ -1366,3 +1370,8 @@ static int sweep_single(rl_ctx* ctx, rl_track* trk, const int* i_start, int max_
   return RL_OK;
 }
 
+#ifdef RL_MT_HIST
+extern "C" int rl_debug_mt_hist(unsigned long long* out) {   // diagnostic build only
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rl::g_mt_hist), 16 * sizeof(unsigned long long));
+}
+#endif

@@ -330,16 +330,11 @@ __global__ void __launch_bounds__(64) k_mt_derivs(MtProblem P, MtState st) {
 //            Hessians H1, H2 of  (t/6) yh.f +- (t^2/12) gm_Y.F (+ own at the first point)   k_mt_hes_point<1>
 //   assembly H = H1 (+) H2 + (2t/3) M' Hm M + the products with t + the rate rows, scaled   k_mt_hes_assemble
 // with M = d(Ym,U)/d(Y,U,t,Y').  3.1 times fewer instructions than the sweep, and fewer live values per thread.
-constexpr int kMtPv = 8, kMtPairs8 = 36;
+constexpr int kMtPv = 8;
 constexpr int kMtHwXm = 0, kMtHwDf = 5, kMtHwGm = 10, kMtHwHm = 18, kMtHwJ1 = 54, kMtHwJ2 = 102, kMtHwH1 = 150, kMtHwH2 = 186,
               kMtHwJm = 222, kMtHwOw = 270, kMtHwF = 318, kMtHw = 336;   // Jm [6][8], own-row gradients [6][8], f1 f2 fm [3][6]
 
-__device__ __forceinline__ void mt_pair8(int q, int& a, int& b) {   // q-th pair a <= b of 8
-  a = 0;
-  while (q >= kMtPv - a) { q -= kMtPv - a; ++a; }
-  b = a + q;
-}
-__device__ __forceinline__ int mt_tri8(int a, int b) {               // inverse, any order
+__device__ __forceinline__ int mt_tri8(int a, int b) {               // index of the pair (a, b) of 8, any order: row-wise upper triangle
   const int lo = a < b ? a : b, hi = a < b ? b : a;
   return lo * kMtPv - lo * (lo - 1) / 2 + (hi - lo);
 }
@@ -544,49 +539,80 @@ __global__ void __launch_bounds__(64) k_mt_jac_assemble(MtProblem P, MtState st)
   }
 }
 
-// grid (blocks of 7 nodes, B, 4 [MID] or 8 [ENDS]): one pair of directions of one dynamics evaluation per thread.
-// Lane = (node, pair): nine consecutive pairs of a node per wave (63 lanes), so that a node's results leave as 72 B
-// segments and its unknowns arrive as broadcasts.
-constexpr int kMtHesNodes = 7, kMtHesPairs = 9, kMtHesZ = kMtPairs8 / kMtHesPairs;
+// grid (blocks of 3 nodes, B, 1 [MID] or 2 [ENDS]): one pair of directions of one dynamics evaluation per thread.
+// Lane = (node, pair): the pairs of a node leave next to each other and its unknowns arrive as broadcasts.
+//   Only 21 of the 36 pairs go through the dual arithmetic: the lateral offset n and the heading xi enter the dynamics
+// through  s' = v cos(xi + beta) / (1 - n kappa),  n' = v sin(xi + beta),  xi' = omega - kappa s'  only
+// (double_track.py:122-129: the force and moment balance knows nothing of where the car is on the road), so the
+// weighted sum  phi = m . f  splits into  phi_kin(n, xi, beta, v) + m2 omega + phi_dyn(omega, beta, v, F, delta, gamma):
+// the pairs among the six variables of phi_dyn are differentiated as before (phi_kin's share of (beta, v) rides along),
+// the 7 non-zero entries with n or xi are closed forms of  A v cos(theta) D + m1 v sin(theta),
+// A = m0 - kappa m2, theta = xi + beta, D = 1 / (1 - n kappa),  and the other 8 are zero (written: the work array is not cleared).
+constexpr int kMtHesNodes = 3, kMtDynVars = 6, kMtDynPairs = 21;
 __host__ __device__ constexpr int mt_hes_blocks(int N) { return (N + kMtHesNodes - 1) / kMtHesNodes; }
 template <int ENDS>
 __global__ void __launch_bounds__(64, 2) k_mt_hes_point(MtProblem P, MtState st) {
-  const int nl = (int)threadIdx.x / kMtHesPairs, ql = (int)threadIdx.x - kMtHesPairs * nl;
+  const int nl = (int)threadIdx.x / kMtDynPairs, q = (int)threadIdx.x - kMtDynPairs * nl;
   const int j = blockIdx.x * kMtHesNodes + nl, b = blockIdx.y, N = P.N;
-  const int pt = ENDS ? (int)blockIdx.z / kMtHesZ : 0, q = ((int)blockIdx.z % kMtHesZ) * kMtHesPairs + ql;
+  const int pt = ENDS ? (int)blockIdx.z : 0;
   if (nl >= kMtHesNodes || j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
   const int jn = j + 1 == N ? 0 : j + 1;
   const size_t o = (size_t)b * N + j;
   double Y[5], Yn[5], U[3], t;
   mt_phys(P, st.w + o * kMtNv, st.w + ((size_t)b * N + jn) * kMtNv, Y, Yn, U, t);
   double* hw = st.hw + o * kMtHw;
-  int a, bb;
-  mt_pair8(q, a, bb);
+  int a = 0, bb = q;   // q-th pair a <= b of the six variables 2 .. 7
+  while (bb >= kMtDynVars - a) { bb -= kMtDynVars - a; ++a; }
+  bb += a;
+  a += 2; bb += 2;
   using D2 = Dual<1, Dual<1>>;
   D2 Yd[5], Ud[3], f[6];
   auto seed = [&](D2& r, double val, int var) {
     r.v.v = val; r.v.d[0] = var == a ? 1.0 : 0.0; r.d[0].v = var == bb ? 1.0 : 0.0; r.d[0].d[0] = 0.0;
   };
+  double Yp[5];   // the point of this evaluation
 #pragma unroll
-  for (int c = 0; c < 5; ++c) seed(Yd[c], ENDS ? (pt ? Yn[c] : Y[c]) : hw[kMtHwXm + c], c);
+  for (int c = 0; c < 5; ++c) { Yp[c] = ENDS ? (pt ? Yn[c] : Y[c]) : hw[kMtHwXm + c]; seed(Yd[c], Yp[c], c); }
 #pragma unroll
   for (int c = 0; c < 3; ++c) seed(Ud[c], U[c], 5 + c);
   const double* y = st.y + o * kMtNe;
   DtTyres<D2> ty;
   mt_dyn<D2>(P, j, Yd, Ud, f, ty);
-  D2 L = f[0] * (y[0] * P.se[0] * (ENDS ? t / 6.0 : 1.0));
+  double m[6];
+  m[0] = y[0] * P.se[0] * (ENDS ? t / 6.0 : 1.0);
 #pragma unroll
   for (int c = 1; c < 6; ++c) {
-    double m = y[c] * P.se[c];
-    if (ENDS) m = m * (t / 6.0) + (pt ? -1.0 : 1.0) * (t * t / 12.0) * hw[kMtHwGm + c - 1];
-    L = L + f[c] * m;
+    m[c] = y[c] * P.se[c];
+    if (ENDS) m[c] = m[c] * (t / 6.0) + (pt ? -1.0 : 1.0) * (t * t / 12.0) * hw[kMtHwGm + c - 1];
   }
-  if (ENDS) {
-    if (pt == 0) L = L + mt_own_rows<D2>(P, Yd, Ud, ty, y, st.z + o * kMtNi);
-    hw[(pt ? kMtHwH2 : kMtHwH1) + q] = L.d[0].d[0];
-  } else {
-    hw[kMtHwHm + q] = L.d[0].d[0];
-    if (a == bb) hw[kMtHwGm + a] = L.v.d[0];
+  D2 L = f[0] * m[0];
+#pragma unroll
+  for (int c = 1; c < 6; ++c) L = L + f[c] * m[c];
+  double* H = hw + (ENDS ? (pt ? kMtHwH2 : kMtHwH1) : kMtHwHm);
+  if (ENDS && pt == 0) L = L + mt_own_rows<D2>(P, Yd, Ud, ty, y, st.z + o * kMtNi);
+  H[mt_tri8(a, bb)] = L.d[0].d[0];
+  if (!ENDS && a == bb) hw[kMtHwGm + a] = L.v.d[0];
+  // the entries with n (row 0: lanes 0 .. 7, column = lane) or xi (row 1: lanes 8 .. 14, column = lane - 7)
+  if (q < 15) {
+    const int r = q < 8 ? 0 : 1, c = q < 8 ? q : q - 7;
+    const double kap = P.kappa[j], A = m[0] - kap * m[2];
+    const double v = Yp[4], D = 1.0 / (1.0 - Yp[0] * kap);
+    double sn, cs;
+    m_sincos(Yp[1] + Yp[3], sn, cs);
+    const double dth = -A * v * sn * D + m[1] * v * cs;          // d / d theta
+    const double dn = A * v * cs * kap * D * D;                  // d / d n
+    double e = 0.0;
+    if (r == 0) {
+      if (c == 0) e = 2.0 * dn * kap * D;
+      else if (c == 1 || c == 3) e = -A * v * sn * kap * D * D;
+      else if (c == 4) e = A * cs * kap * D * D;
+    } else {
+      if (c == 1 || c == 3) e = -A * v * cs * D - m[1] * v * sn;
+      else if (c == 4) e = -A * sn * D + m[1] * cs;
+    }
+    H[mt_tri8(r, c)] = e;
+    if (!ENDS && q == 0) hw[kMtHwGm + 0] = dn;
+    if (!ENDS && q == 8) hw[kMtHwGm + 1] = dth;
   }
 }
 
@@ -1448,7 +1474,7 @@ __global__ void __launch_bounds__(64) k_mt_residuals(MtProblem P, MtState st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_mt_step: one workgroup (256 threads) per instance.
+// the step: helpers
 template <int BLOCK>
 __device__ __forceinline__ double mt_block_reduce(double v, double* red, int op /*0 sum, 1 min*/) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1512,127 +1538,248 @@ __global__ void __launch_bounds__(256) k_mt_prepare2(MtProblem P, MtState st) {
   }
 }
 
-__global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
-  __shared__ double red[8];
-  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
-  double* scal = st.scal + (size_t)b * 16;
-  if (scal[5] != 0.0) return;
-  mt_instance(P, b);
-  double* w = st.w + (size_t)b * N * kMtNv;
-  double* sv = st.s + (size_t)b * N * kMtNi;
-  double* yv = st.y + (size_t)b * N * kMtNe;
-  double* zv = st.z + (size_t)b * N * kMtNi;
-  const double* fun = st.fun + (size_t)b * N * kMtNf;
-  const double* jac = st.jac + (size_t)b * N * kMtNf * kMtLoc;
-  const double* dw = st.dw + (size_t)b * N * kMtNv;
-  const double* dy = st.dy + (size_t)b * N * kMtNe;
-  double* dsv = st.vec + (size_t)b * N * 16;      // reuse: ds [N,17] does not fit 16 -> use blk scratch instead
-  double* ds = st.blk + (size_t)b * N * 3 * 256;  // [N,17] ds, then [N,17] dz (the factor blocks are dead now)
-  double* dz = ds + (size_t)N * kMtNi;
-  (void)dsv;
-  const double mu = scal[0];
-  // ds = -r_g - G dw ; dz = -(s z - mu + z ds) / s ; fraction to the boundary
-  double ap = 1.0, ad = 1.0, theta0 = 0.0, phi0 = 0.0;
+// The step in four kernels (it was one workgroup per instance that evaluated the trial points itself: 395 registers, one
+// workgroup per CU, 1.33 rounds for a sub-batch of 341 instances and nothing else resident beside it):
+//   k_mt_dir         per inequality ROW, all instances: ds, dz, the wave's share of the step lengths and of (theta0, phi0)
+//   k_mt_step_red    per instance: the fraction-to-the-boundary lengths ap, ad and (theta0, phi0) of the current point
+//   k_mt_trial       per NODE, all instances: the trial points w + a dw, a = ap, ap / 2, ap / 4 -> the node's shares of (theta, phi)
+//   k_mt_step_fin    per instance: the first acceptable of the three (72 / 18 / 7 % of the steps of the benchmark batch) -> the update
+//   k_mt_step_back   per instance, only where all three were rejected (3 %): further halvings, each evaluated in the kernel
+// scal: 12 ap, 15 ad, 8 theta0, 9 phi0; 7 = -1 marks "no trial accepted yet" between the last two kernels.
+struct MtStepPtrs {
+  double *w, *sv, *yv, *zv, *ds, *dz, *scal, *filt;
+  const double *dw, *dy;
+};
+__device__ __forceinline__ MtStepPtrs mt_step_ptrs(const MtState& st, int b, int N) {
+  MtStepPtrs q;
+  q.w = st.w + (size_t)b * N * kMtNv; q.sv = st.s + (size_t)b * N * kMtNi; q.yv = st.y + (size_t)b * N * kMtNe;
+  q.zv = st.z + (size_t)b * N * kMtNi; q.dw = st.dw + (size_t)b * N * kMtNv; q.dy = st.dy + (size_t)b * N * kMtNe;
+  q.ds = st.blk + (size_t)b * N * 3 * 256;   // [N,17] ds, then [N,17] dz (the factor blocks are dead now)
+  q.dz = q.ds + (size_t)N * kMtNi;
+  q.scal = st.scal + (size_t)b * 16; q.filt = st.filt + (size_t)b * 2 * kMtFilter;
+  return q;
+}
+
+#ifdef RL_MT_HIST
+__device__ unsigned long long g_mt_hist[16];   // diagnostic build: accepted steps by number of halvings (12 = none accepted)
+#define RL_MT_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_mt_hist[k], 1ull); } while (0)
+#else
+#define RL_MT_COUNT(k) do { } while (0)
+#endif
+// acceptance of a trial point (theta, phi) against the current point and the filter
+__device__ __forceinline__ bool mt_accept(const MtState& st, const double* filt, int nfilt, int N, double theta, double phi,
+                                          double theta0, double phi0) {
+  const bool fin = isfinite(theta) && isfinite(phi);
+  // a step may not more than double the l1 infeasibility, whatever it does to the objective -- above a floor of
+  // 1e-5 per row: next to a feasible point (theta0 ~ 0) the second-order infeasibility of any useful step is larger
+  // than twice nothing, and without the floor such instances crept along with two halvings per iteration
+  const double floor_ = kMtThetaFloor * (double)(N * kMtNf);
+  // eth, eph: what rounding alone moves the two sums by (next to the solution the improvement asked for is smaller)
+  const double eth = 1e-13 * (double)(N * kMtNf), eph = 1e-13 * fabs(phi0);
+  bool acc = fin && theta <= fmax(kMtThetaGrowth * theta0, floor_) + 1e-9 &&
+             (theta <= (1.0 - 1e-5) * theta0 + eth || phi <= phi0 - 1e-5 * theta0 + eph);
+  // ... and once the iterate is nearly feasible (l1 infeasibility below th_filter per row) the step must be acceptable
+  // to the earlier iterates of this barrier problem as well: otherwise two points, one of less infeasibility and
+  // one of less objective, can be visited in turn for ever (seen on a few of 1024 instances).  Far from feasibility
+  // the iteration legitimately trades one for the other, and a filter there would need a restoration phase.
+  for (int e = 0; e < nfilt && acc && theta0 < st.th_filter * (double)(N * kMtNf); ++e)
+    acc = theta <= (1.0 - 1e-5) * filt[2 * e] + eth || phi <= filt[2 * e + 1] - 1e-5 * filt[2 * e] + eph;
+  return acc;
+}
+
+// the accepted step of length a (after `halvings` halvings of ap): iterate, damping, filter, bookkeeping
+__device__ __forceinline__ void mt_take_step(const MtState& st, const MtStepPtrs& q, int N, int tid, double a, int halvings) {
+  const double mu = q.scal[0], ap = q.scal[12], ad = q.scal[15], theta0 = q.scal[8], phi0 = q.scal[9];
+  const int nfilt_total = (int)q.scal[14];
+  const double az = st.dual_cap > 0.0 ? fmin(fmin(ad, 1.0), fmax(st.dual_cap * a, 1e-3)) : fmin(ad, 1.0);
+  for (int idx = tid; idx < N * kMtNv; idx += 256) q.w[idx] += a * q.dw[idx];
+  for (int idx = tid; idx < N * kMtNe; idx += 256) q.yv[idx] += a * q.dy[idx];
   for (int idx = tid; idx < N * kMtNi; idx += 256) {
+    const double s_ = q.sv[idx] + a * q.ds[idx];
+    double z_ = q.zv[idx] + az * q.dz[idx];
+    z_ = fmin(fmax(z_, mu / (1e10 * s_)), 1e10 * mu / s_);
+    q.sv[idx] = s_; q.zv[idx] = z_;
+  }
+  double delta = q.scal[1];
+  delta = fmin(fmax(delta * (a > st.a_hi ? st.d_down : (a > st.a_lo ? 1.0 : st.d_up)), 1e-6), 1e3);
+  __syncthreads();   // everybody has read scal
+  if (tid == 0) {
+    q.scal[1] = delta; q.scal[7] = a; q.scal[6] += 1.0; q.scal[12] = ap; q.scal[13] = (double)halvings;
+    const int slot = nfilt_total % kMtFilter;   // the point just left joins the filter
+    q.filt[2 * slot] = theta0; q.filt[2 * slot + 1] = phi0;
+    q.scal[14] = (double)(nfilt_total + 1);
+  }
+}
+
+// grid (blocks of 64 rows, B): one inequality row per thread: ds = -r_g - G dw, dz = -(s z - mu + z ds) / s, and the wave's
+// share of (ap, ad, theta0, phi0) -> part[b][block][4]  (part = the elimination's vec scratch, dead by now: [B,N,16] >= 4 blocks)
+constexpr int kMtDirBlocks(int N) { return (N * kMtNi + 63) / 64; }
+__global__ void __launch_bounds__(64) k_mt_dir(MtProblem P, MtState st) {
+  const int b = blockIdx.y, N = P.N, idx = blockIdx.x * 64 + threadIdx.x;
+  const MtStepPtrs q = mt_step_ptrs(st, b, N);
+  if (q.scal[5] != 0.0) return;
+  double ap = 1.0, ad = 1.0, th = 0.0, ph = 0.0;
+  if (idx < N * kMtNi) {
+    const double* fun = st.fun + (size_t)b * N * kMtNf;
+    const double* jac = st.jac + (size_t)b * N * kMtNf * kMtLoc;
+    const double mu = q.scal[0];
     const int j = idx / kMtNi, c = idx - j * kMtNi, jn = j + 1 == N ? 0 : j + 1;
     const double* Jr = jac + ((size_t)j * kMtNf + kMtNe + c) * kMtLoc;
     double gd = 0.0;
-    for (int a = 0; a < kMtNv; ++a) gd += Jr[a] * dw[(size_t)j * kMtNv + a] + Jr[9 + a] * dw[(size_t)jn * kMtNv + a];
-    const double s_ = sv[idx], z_ = zv[idx], rg = fun[j * kMtNf + kMtNe + c] + s_;
+#pragma unroll
+    for (int a = 0; a < kMtNv; ++a) gd += Jr[a] * q.dw[(size_t)j * kMtNv + a] + Jr[9 + a] * q.dw[(size_t)jn * kMtNv + a];
+    const double s_ = q.sv[idx], z_ = q.zv[idx], rg = fun[j * kMtNf + kMtNe + c] + s_;
     const double d_s = -rg - gd;
     const double d_z = -(s_ * z_ - mu + z_ * d_s) / s_;
-    ds[idx] = d_s; dz[idx] = d_z;
-    if (d_s < 0.0) ap = fmin(ap, -0.995 * s_ / d_s);
-    if (d_z < 0.0) ad = fmin(ad, -0.995 * z_ / d_z);
-    theta0 += fabs(rg);
-    phi0 -= mu * log(s_);
+    q.ds[idx] = d_s; q.dz[idx] = d_z;
+    if (d_s < 0.0) ap = -0.995 * s_ / d_s;
+    if (d_z < 0.0) ad = -0.995 * z_ / d_z;
+    ap = fmin(ap, 1.0); ad = fmin(ad, 1.0);
+    th = fabs(rg);
+    ph = -mu * log(s_);
+  }
+  ap = wave_min(ap); ad = wave_min(ad); th = wave_sum(th); ph = wave_sum(ph);
+  if (threadIdx.x == 0) {
+    double* o = st.vec + (size_t)b * N * 16 + (size_t)blockIdx.x * 4;
+    o[0] = ap; o[1] = ad; o[2] = th; o[3] = ph;
+  }
+}
+
+// per instance: the step lengths and (theta0, phi0) of the current point from the shares of k_mt_dir
+__global__ void __launch_bounds__(256) k_mt_step_red(MtProblem P, MtState st) {
+  __shared__ double red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
+  const MtStepPtrs q = mt_step_ptrs(st, b, N);
+  if (q.scal[5] != 0.0) return;
+  const double* fun = st.fun + (size_t)b * N * kMtNf;
+  const double* part = st.vec + (size_t)b * N * 16;
+  double ap = 1.0, ad = 1.0, theta0 = 0.0, phi0 = 0.0;
+  for (int k = tid; k < kMtDirBlocks(N); k += 256) {
+    ap = fmin(ap, part[4 * k]); ad = fmin(ad, part[4 * k + 1]); theta0 += part[4 * k + 2]; phi0 += part[4 * k + 3];
   }
   for (int idx = tid; idx < N * kMtNe; idx += 256) {
     const int j = idx / kMtNe, c = idx - j * kMtNe;
     theta0 += fabs(fun[j * kMtNf + c]);
   }
   for (int idx = tid; idx < N; idx += 256) {
-    const double* wj = w + (size_t)idx * kMtNv;
-    const double* wn = w + (size_t)(idx + 1 == N ? 0 : idx + 1) * kMtNv;
+    const double* wj = q.w + (size_t)idx * kMtNv;
+    const double* wn = q.w + (size_t)(idx + 1 == N ? 0 : idx + 1) * kMtNv;
     double c = wj[8];
     for (int a = 5; a < 8; ++a) c += 1e-4 * wj[a] * wj[a] + 1e-1 * (wn[a] - wj[a]) * (wn[a] - wj[a]);
     phi0 += c;
   }
   ap = mt_block_reduce<256>(ap, red, 1); ad = mt_block_reduce<256>(ad, red, 1);
   theta0 = mt_block_reduce<256>(theta0, red, 0); phi0 = mt_block_reduce<256>(phi0, red, 0);
-  // backtracking against the filter {(theta0, phi0)}
-  double a = ap;
-  bool ok = false;
-  int halvings = 0;
-  double* filt = st.filt + (size_t)b * 2 * kMtFilter;
-  const int nfilt_total = (int)scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
-  for (int trial = 0; trial < 12; ++trial) {
+  if (tid == 0) { q.scal[12] = ap; q.scal[15] = ad; q.scal[8] = theta0; q.scal[9] = phi0; }
+}
+
+// (theta, phi) share of the pair j at the trial point w + a dw, s + a ds
+__device__ __forceinline__ void mt_trial_node(const MtProblem& P, const MtStepPtrs& q, int N, int j, double a, double mu,
+                                              double& theta, double& phi) {
+  const int jn = j + 1 == N ? 0 : j + 1;
+  double wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
+#pragma unroll
+  for (int k = 0; k < kMtNv; ++k) {
+    wo[k] = q.w[(size_t)j * kMtNv + k] + a * q.dw[(size_t)j * kMtNv + k];
+    wn[k] = q.w[(size_t)jn * kMtNv + k] + a * q.dw[(size_t)jn * kMtNv + k];
+  }
+  mt_pair<double>(P, j, wo, wn, eq, g);
+  double c = wo[8];
+#pragma unroll
+  for (int k = 5; k < 8; ++k) c += 1e-4 * wo[k] * wo[k] + 1e-1 * (wn[k] - wo[k]) * (wn[k] - wo[k]);
+  phi += c;
+#pragma unroll
+  for (int k = 0; k < kMtNe; ++k) theta += fabs(eq[k]);
+#pragma unroll
+  for (int k = 0; k < kMtNi; ++k) {
+    const double s_ = q.sv[(size_t)j * kMtNi + k] + a * q.ds[(size_t)j * kMtNi + k];
+    theta += fabs(g[k] + s_);
+    phi -= mu * log(s_);
+  }
+}
+
+// grid (node blocks, B): the first kMtTrials trial points (ap, ap / 2, ap / 4: 97 % of the accepted steps on the benchmark batch),
+// one node pair per thread -> vec[b][j][2 k .. 2 k + 1], k = trial (the shares of k_mt_dir there have been consumed)
+constexpr int kMtTrials = 3;
+__global__ void __launch_bounds__(64) k_mt_trial(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
+  const MtStepPtrs q = mt_step_ptrs(st, b, N);
+  if (j >= N || q.scal[5] != 0.0) return;
+  mt_instance(P, b);
+  double* o = st.vec + ((size_t)b * N + j) * 16;
+  double a = q.scal[12];
+  const double mu = q.scal[0];
+  for (int k = 0; k < kMtTrials; ++k) {
     double theta = 0.0, phi = 0.0;
-    bool fin = true;
-    for (int j = tid; j < N; j += 256) {
-      const int jn = j + 1 == N ? 0 : j + 1;
-      double wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
-#pragma unroll
-      for (int q = 0; q < kMtNv; ++q) {
-        wo[q] = w[(size_t)j * kMtNv + q] + a * dw[(size_t)j * kMtNv + q];
-        wn[q] = w[(size_t)jn * kMtNv + q] + a * dw[(size_t)jn * kMtNv + q];
-      }
-      mt_pair<double>(P, j, wo, wn, eq, g);
-      double c = wo[8];
-#pragma unroll
-      for (int q = 5; q < 8; ++q) c += 1e-4 * wo[q] * wo[q] + 1e-1 * (wn[q] - wo[q]) * (wn[q] - wo[q]);
-      phi += c;
-#pragma unroll
-      for (int q = 0; q < kMtNe; ++q) theta += fabs(eq[q]);
-#pragma unroll
-      for (int q = 0; q < kMtNi; ++q) {
-        const double s_ = sv[(size_t)j * kMtNi + q] + a * ds[(size_t)j * kMtNi + q];
-        theta += fabs(g[q] + s_);
-        phi -= mu * log(s_);
-      }
-    }
-    theta = mt_block_reduce<256>(theta, red, 0); phi = mt_block_reduce<256>(phi, red, 0);
-    fin = isfinite(theta) && isfinite(phi);
-    // a step may not more than double the l1 infeasibility, whatever it does to the objective -- above a floor of
-    // 1e-5 per row: next to a feasible point (theta0 ~ 0) the second-order infeasibility of any useful step is larger
-    // than twice nothing, and without the floor such instances crept along with two halvings per iteration
-    const double floor_ = kMtThetaFloor * (double)(N * kMtNf);
-    // eth, eph: what rounding alone moves the two sums by (next to the solution the improvement asked for is smaller)
-    const double eth = 1e-13 * (double)(N * kMtNf), eph = 1e-13 * fabs(phi0);
-    bool acc = fin && theta <= fmax(kMtThetaGrowth * theta0, floor_) + 1e-9 &&
-               (theta <= (1.0 - 1e-5) * theta0 + eth || phi <= phi0 - 1e-5 * theta0 + eph);
-    // ... and once the iterate is nearly feasible (l1 infeasibility below th_filter per row) the step must be acceptable
-    // to the earlier iterates of this barrier problem as well: otherwise two points, one of less infeasibility and
-    // one of less objective, can be visited in turn for ever (seen on a few of 1024 instances).  Far from feasibility
-    // the iteration legitimately trades one for the other, and a filter there would need a restoration phase.
-    for (int e = 0; e < nfilt && acc && theta0 < st.th_filter * (double)(N * kMtNf); ++e)
-      acc = theta <= (1.0 - 1e-5) * filt[2 * e] + eth || phi <= filt[2 * e + 1] - 1e-5 * filt[2 * e] + eph;
-    if (acc) { ok = true; halvings = trial; break; }
+    mt_trial_node(P, q, N, j, a, mu, theta, phi);
+    o[2 * k] = theta; o[2 * k + 1] = phi;
     a *= 0.5;
   }
-  double delta = scal[1];
+}
+
+__global__ void __launch_bounds__(256) k_mt_step_fin(MtProblem P, MtState st) {
+  __shared__ double red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
+  const MtStepPtrs q = mt_step_ptrs(st, b, N);
+  if (q.scal[5] != 0.0) return;
+  const double* tp = st.vec + (size_t)b * N * 16;
+  double th[kMtTrials], ph[kMtTrials];
+#pragma unroll
+  for (int k = 0; k < kMtTrials; ++k) { th[k] = 0.0; ph[k] = 0.0; }
+  for (int j = tid; j < N; j += 256) {
+#pragma unroll
+    for (int k = 0; k < kMtTrials; ++k) { th[k] += tp[(size_t)j * 16 + 2 * k]; ph[k] += tp[(size_t)j * 16 + 2 * k + 1]; }
+  }
+#pragma unroll
+  for (int k = 0; k < kMtTrials; ++k) { th[k] = mt_block_reduce<256>(th[k], red, 0); ph[k] = mt_block_reduce<256>(ph[k], red, 0); }
+  const int nfilt_total = (int)q.scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
+  double a = q.scal[12];
+  int taken = -1;
+#pragma unroll
+  for (int k = 0; k < kMtTrials; ++k) {
+    if (taken < 0) {
+      if (mt_accept(st, q.filt, nfilt, N, th[k], ph[k], q.scal[8], q.scal[9])) taken = k;
+      else a *= 0.5;
+    }
+  }
+  if (taken >= 0) {
+    RL_MT_COUNT(taken);
+    mt_take_step(st, q, N, tid, a, taken);
+  } else {
+    __syncthreads();
+    if (tid == 0) q.scal[7] = -1.0;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_mt_step_back(MtProblem P, MtState st) {
+  __shared__ double red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
+  const MtStepPtrs q = mt_step_ptrs(st, b, N);
+  if (q.scal[5] != 0.0 || q.scal[7] != -1.0) return;
+  mt_instance(P, b);
+  const double mu = q.scal[0], theta0 = q.scal[8], phi0 = q.scal[9];
+  const int nfilt_total = (int)q.scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
+  double a = q.scal[12];
+  for (int k = 1; k < kMtTrials; ++k) a *= 0.5;
+  bool ok = false;
+  int halvings = 0;
+  for (int trial = kMtTrials; trial < 12; ++trial) {
+    a *= 0.5;
+    double theta = 0.0, phi = 0.0;
+    for (int j = tid; j < N; j += 256) mt_trial_node(P, q, N, j, a, mu, theta, phi);
+    theta = mt_block_reduce<256>(theta, red, 0); phi = mt_block_reduce<256>(phi, red, 0);
+    if (mt_accept(st, q.filt, nfilt, N, theta, phi, theta0, phi0)) { ok = true; halvings = trial; break; }
+  }
   if (!ok) {
     // no acceptable step: more damping, same point (the next iteration re-solves with the larger delta)
-    delta = fmax(10.0 * delta, 1e-4);
-    if (tid == 0) { scal[1] = delta; scal[7] = 0.0; scal[6] += 1.0; if (delta > 1e6) scal[5] = 2.0; }
+    const double delta = fmax(10.0 * q.scal[1], 1e-4);
+    __syncthreads();
+    if (tid == 0) { q.scal[1] = delta; q.scal[7] = 0.0; q.scal[6] += 1.0; if (delta > 1e6) q.scal[5] = 2.0; }
+    RL_MT_COUNT(12);
     return;
   }
-  const double az = st.dual_cap > 0.0 ? fmin(fmin(ad, 1.0), fmax(st.dual_cap * a, 1e-3)) : fmin(ad, 1.0);
-  for (int idx = tid; idx < N * kMtNv; idx += 256) w[idx] += a * dw[idx];
-  for (int idx = tid; idx < N * kMtNe; idx += 256) yv[idx] += a * dy[idx];
-  for (int idx = tid; idx < N * kMtNi; idx += 256) {
-    const double s_ = sv[idx] + a * ds[idx];
-    double z_ = zv[idx] + az * dz[idx];
-    z_ = fmin(fmax(z_, mu / (1e10 * s_)), 1e10 * mu / s_);
-    sv[idx] = s_; zv[idx] = z_;
-  }
-  delta = fmin(fmax(delta * (a > st.a_hi ? st.d_down : (a > st.a_lo ? 1.0 : st.d_up)), 1e-6), 1e3);
-  if (tid == 0) {
-    scal[1] = delta; scal[7] = a; scal[6] += 1.0; scal[8] = theta0; scal[9] = phi0; scal[12] = ap; scal[13] = (double)halvings;
-    const int slot = nfilt_total % kMtFilter;   // the point just left joins the filter
-    filt[2 * slot] = theta0; filt[2 * slot + 1] = phi0;
-    scal[14] = (double)(nfilt_total + 1);
-  }
+  RL_MT_COUNT(halvings);
+  mt_take_step(st, q, N, tid, a, halvings);
 }
 
 // physical X [B,N,6], U [B,N,4], T [B,N]  <->  scaled unknowns w [B,N,9]
