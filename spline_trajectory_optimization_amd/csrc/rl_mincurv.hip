@@ -1170,6 +1170,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   }
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
   if (ctx->mt_hes_sweep) RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
+  RL_HIP(hipMemsetAsync(st.jac, 0, counts[5] * sizeof(double), ctx->stream));   // k_mt_node never writes columns 16, 17 (structurally zero)
   // A few sub-batches on as many streams: the KKT elimination is one wave per instance and latency bound (its time
   // does not depend on the batch), the derivative kernels are throughput bound -- with the sub-batches offset by the
   // in-order queues one's elimination runs beside another's derivatives.  Instances are independent, so the split
@@ -1239,7 +1240,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
         if (ctx->mt_unfused) {
           hipLaunchKernelGGL(rl::k_mt_hes_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
         } else {   // Jacobian, Hessian, blocks and right-hand side in one pass over the pairs
-          hipLaunchKernelGGL(rl::k_mt_node, dim3((N + rl::kMtRun - 1) / rl::kMtRun, G.nb), bn64, 0, G.q, G.P, G.st);
+          hipLaunchKernelGGL(rl::k_mt_node, dim3(((N + rl::kMtRun - 1) / rl::kMtRun + rl::kMtNodeGroups - 1) / rl::kMtNodeGroups, G.nb), bn64, 0, G.q, G.P, G.st);
           hipLaunchKernelGGL(rl::k_mt_prepare2, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
         }
       }

@@ -946,273 +946,305 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
 }
 
 // k_mt_node: Jacobian, Hessian and KKT blocks of the node pairs in ONE pass (the default; k_mt_jac_assemble,
-// k_mt_hes_assemble, k_mt_prepare and k_mt_assemble stay as the path of the forward-over-forward cross-check).
-// The three kernels it replaces were bound by memory: every pair's 24 x 18 Jacobian and 18 x 18 Hessian went to HBM
-// and came back twice (for the pair itself and for its successor, which needs the "next node" columns):
-// 25 KB per node and iteration, 4 TB/s in k_mt_assemble.  Here one wave walks kMtRun consecutive pairs; Jacobian and
-// Hessian of the pair live in LDS, and what the NEXT node's diagonal block and right-hand side need of them
-// (Dn = Hess_nn + Gn' W Gn, An' y + Gn' zeta, ...) is carried to the next pair in LDS -- the wave starts one pair
-// early to have the carry of its first node (1 / kMtRun more work).  The Jacobian is still written (k_mt_step and
-// the final residuals read it), the Hessian is not.  The work array of the next pair is fetched into registers
-// while the current pair is processed.
+// k_mt_hes_assemble, k_mt_prepare and k_mt_assemble stay as the cross-check path, RL_MT_UNFUSED=1).
+//   The kernels it replaces were bound by memory and by their own index arithmetic: every pair's 24 x 18 Jacobian and
+// 18 x 18 Hessian went to HBM and came back twice (for the pair itself and for its successor, which needs the "next
+// node" columns): 25 KB per node and iteration; and with one wave per pair and "entry e = lane + 64 k" loops nine of ten
+// instructions computed indices or branched.  Here
+//   * a group of 16 lanes owns a RUN of kMtRun consecutive pairs and walks it; lane = COLUMN (the pair function does not
+//     depend on the next node's gamma and t: columns 16, 17 of every matrix are zero), rows are compile-time loop indices,
+//     so every structural decision (which of J1 / J2 / Jm, which rows are closed forms, which entries of the inequality
+//     Jacobian can be non-zero) is taken by the compiler or is a lane constant;
+//   * the lane keeps its column of M, Hm M, the Jacobian and the Hessian in registers; LDS holds the work array of the
+//     pair (fetched one pair ahead into registers) and what other lanes read as broadcasts (M, the Jacobian);
+//   * what the NEXT node's diagonal block and right-hand side need of this pair (Dn = Hess_nn + Gn' W Gn, An' y + Gn' zeta)
+//     is carried to the next pair in LDS -- the group starts one pair early to have the carry of its first node
+//     (1 / kMtRun more work).  The Jacobian is still written (k_mt_dir and the final residuals read it), the Hessian is not.
 //   The barrier parameter is updated from the residuals of ALL nodes (k_mt_prepare2, afterwards), so the right-hand
 // side leaves in two pieces: rhs0 (everything but the mu / s term of zeta) and r1 = G' (1 / s); k_mt_prepare2 forms
 // rhs = rhs0 - mu r1 with the mu it has just chosen.  r1[9] carries the node's max |r_d| to the convergence test.
-constexpr int kMtRun = 8;
-struct MtNodeLds {
+constexpr int kMtRun = 9, kMtNodeGroups = 4;
+struct MtNodeGrp {
   double hw[kMtHw];
-  double M[kMtPv][14], JM[6][14], T[kMtPv][14], gpsi[14], gphi[2][kMtPv], gF[2][kMtPv];
-  double J[kMtNf][kMtLoc], H[kMtLoc][kMtLoc];
-  double P3[3][81];                       // Do, Ct, Dn of the pair
-  double cDn[81];                         // Dn of the previous pair
-  double wo[kMtNv], wn[kMtNv], y[kMtNe], z[kMtNi], s[kMtNi], fun[kMtNf];
-  double W[kMtNi], zeta[kMtNi], is[kMtNi];
-  double vo[3][kMtNv], vn[3][kMtNv], cvn[3][kMtNv];   // (A' y + G' W (g + s), G' (1 / s), A' y + G' z): own columns, next node's, carried
-  double up[3];                           // controls of the previous node (cost gradient)
+  double wo[16], wn[16], y[8], z[kMtNi + 1], s[kMtNi + 1], fun[kMtNf];
+  double M[kMtPv][16];
+  double J[kMtNf][16];
+  double W[kMtNi + 1], zeta[kMtNi + 1], is[kMtNi + 1];
+  double gphi[16], gF[16], gpsi[16], tx[16], rt[16];
+  double cDn[kMtNv][16], cvn[3][16], up[4];   // the carry: Dn, (A' y + G' W (g + s), G' (1 / s), A' y + G' z) of the next node's columns, controls
 };
 
+// can row i of the inequality Jacobian have an entry in column r?  (rows as in mt_pair_emit: 0..3 tyre ellipses and 4 power
+// depend on (Y, U) of the node; 5 speed; 6, 7 force; 8, 9 steering; 10..13 the rates; 14, 15 the road edges; 16 the duration)
+__host__ __device__ constexpr bool mt_g_has(int i, int r) {
+  return i < 5 ? r < 8 : i == 5 ? r == 4 : i < 8 ? r == 5 : i < 10 ? r == 6 : i < 12 ? (r == 5 || r == 8 || r == 14)
+       : i < 14 ? (r == 6 || r == 8 || r == 15) : i < 16 ? r == 0 : r == 8;
+}
+__host__ __device__ constexpr int mt_map2(int zi) { return zi >= 9 ? zi - 9 : (zi >= 5 && zi < 8 ? zi : -1); }
+
 __global__ void __launch_bounds__(64) k_mt_node(MtProblem P, MtState st) {
-  __shared__ MtNodeLds L;
+  __shared__ MtNodeGrp LG[kMtNodeGroups];
   const int b = blockIdx.y, lane = threadIdx.x, N = P.N;
   if (st.scal[(size_t)b * 16 + 5] != 0.0) return;
-  const int j0 = blockIdx.x * kMtRun;
-  const int cnt = N - j0 < kMtRun ? N - j0 : kMtRun;
-  auto pair_of = [&](int it) { return it < 0 ? (j0 == 0 ? N - 1 : j0 - 1) : j0 + it; };
-  // the inputs of a pair: 336 doubles of work array, and 83 of unknowns / multipliers / slacks / functions
-  double pre[8];
+  const int c = lane & 15;
+  MtNodeGrp& L = LG[lane >> 4];
+  const int run0 = ((int)blockIdx.x * kMtNodeGroups + (lane >> 4)) * kMtRun;
+  const int cnt = run0 < N ? (N - run0 < kMtRun ? N - run0 : kMtRun) : 0;   // a group without pairs walks along without writing
+  const int j0 = cnt > 0 ? run0 : 0;
+  auto pair_of = [&](int it) { return it < 0 ? (j0 == 0 ? N - 1 : j0 - 1) : (it < cnt ? j0 + it : j0); };
+  // lane constants
+  const int c1 = c < 8 ? c : 7;                               // the lane's column of a first-end quantity
+  const int c2 = c < 8 ? c : (c >= 9 && c < 14 ? c - 9 : 0);  // ... of a second-end quantity: map2(c) where there is one
+  const bool has2 = (c >= 5 && c < 8) || (c >= 9 && c < 14);
+  const int q1 = 7 * c1 - c1 * (c1 - 1) / 2, q2 = 7 * c2 - c2 * (c2 - 1) / 2;
+  auto tri_lane = [](int la, int cx, int qx) { return cx <= la ? qx + la : 7 * la - la * (la - 1) / 2 + cx; };   // mt_tri8(la, cx)
+  double swc = P.sw[0];
+#pragma unroll
+  for (int k = 1; k < kMtNv; ++k) swc = c % kMtNv == k ? P.sw[k] : swc;
+  const double su0 = P.sw[5], su2 = P.sw[6];
+  // the inputs of a pair: 336 doubles of work array, 9 + 9 + 7 + 17 + 17 + 24 of unknowns / multipliers / slacks / functions
+  double ph[21], ps[9];
   auto fetch = [&](int j) {
-    const size_t o = (size_t)b * N + j;
-    const int jn = j + 1 == N ? 0 : j + 1;
+    const size_t o = (size_t)b * N + j, on = (size_t)b * N + (j + 1 == N ? 0 : j + 1);
     const double* hw = st.hw + o * kMtHw;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pre[k] = lane + 64 * k < kMtHw ? hw[lane + 64 * k] : 0.0;
-    const double* src = lane < 9    ? st.w + o * kMtNv + lane
-                        : lane < 18 ? st.w + ((size_t)b * N + jn) * kMtNv + (lane - 9)
-                        : lane < 25 ? st.y + o * kMtNe + (lane - 18)
-                        : lane < 42 ? st.z + o * kMtNi + (lane - 25)
-                                    : st.s + o * kMtNi + (lane - 42);
-    pre[6] = lane < 59 ? *src : 0.0;
-    pre[7] = lane < kMtNf ? st.fun[o * kMtNf + lane] : 0.0;
+    for (int k = 0; k < 21; ++k) ph[k] = hw[c + 16 * k];
+    ps[0] = c < kMtNv ? st.w[o * kMtNv + c] : 0.0;
+    ps[1] = c < kMtNv ? st.w[on * kMtNv + c] : 0.0;
+    ps[2] = c < kMtNe ? st.y[o * kMtNe + c] : 0.0;
+    ps[3] = st.z[o * kMtNi + c]; ps[4] = st.z[o * kMtNi + 16];
+    ps[5] = st.s[o * kMtNi + c]; ps[6] = st.s[o * kMtNi + 16];
+    ps[7] = st.fun[o * kMtNf + c];
+    ps[8] = c < 8 ? st.fun[o * kMtNf + 16 + c] : 0.0;
   };
   auto deposit = [&]() {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) if (lane + 64 * k < kMtHw) L.hw[lane + 64 * k] = pre[k];
-    if (lane < 9) L.wo[lane] = pre[6];
-    else if (lane < 18) L.wn[lane - 9] = pre[6];
-    else if (lane < 25) L.y[lane - 18] = pre[6];
-    else if (lane < 42) L.z[lane - 25] = pre[6];
-    else if (lane < 59) L.s[lane - 42] = pre[6];
-    if (lane < kMtNf) L.fun[lane] = pre[7];
+    for (int k = 0; k < 21; ++k) L.hw[c + 16 * k] = ph[k];
+    L.wo[c] = ps[0]; L.wn[c] = ps[1];
+    if (c < 8) { L.y[c] = ps[2]; L.fun[16 + c] = ps[8]; }
+    L.z[c] = ps[3]; L.s[c] = ps[5]; L.fun[c] = ps[7];
+    if (c == 0) { L.z[16] = ps[4]; L.s[16] = ps[6]; }
   };
-  auto map2 = [](int zi) { return zi >= 9 ? zi - 9 : (zi >= 5 && zi < 8 ? zi : -1); };
+#pragma unroll
+  for (int k = 0; k < kMtNv; ++k) L.cDn[k][c] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) L.cvn[k][c] = 0.0;
   fetch(pair_of(-1));
-  for (int it = -1; it < cnt; ++it) {
-    const int j = pair_of(it);
-    const size_t o = (size_t)b * N + j;
-    const bool own = it >= 0;
+  for (int it = -1; it < kMtRun; ++it) {
+    const size_t o = (size_t)b * N + pair_of(it);
+    const bool own = it >= 0 && it < cnt;
     deposit();
     __syncthreads();
-    if (it + 1 < cnt) fetch(pair_of(it + 1));
+    if (it + 1 < kMtRun) fetch(pair_of(it + 1));
     const double* hw = L.hw;
     const double* J1 = hw + kMtHwJ1;
     const double* J2 = hw + kMtHwJ2;
     const double* Jm = hw + kMtHwJm;
-    const double t = L.wo[8] * P.sw[8];
-    // ---- A: M = d(Ym, U) / d(Y, U, t, Y'), gradients at the ends, weights of the inequality rows
-    if (lane < 2 * kMtPv) {
-      const int pt = lane >> 3, a = lane & 7;
-      const double* J = pt ? J2 : J1;
+    const double t = L.wo[8] * P.sw[8], t8 = t / 8.0;
+    // ---- A: the lane's column of M = d(Ym, U) / d(Y, U, t, Y'); gradients at the ends; weights of the inequality rows
+    double Mc[kMtPv];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const double j1 = J1[(1 + r) * kMtPv + c1], j2 = J2[(1 + r) * kMtPv + c2];
+      double v = 0.0;
+      if (c < 5) v = (c == r ? 0.5 : 0.0) + t8 * j1;
+      else if (c < 8) v = t8 * (j1 - j2);
+      else if (c == 8) v = hw[kMtHwDf + r] / 8.0;
+      else if (c < 14) v = (c - 9 == r ? 0.5 : 0.0) - t8 * j2;
+      Mc[r] = v;
+    }
+#pragma unroll
+    for (int k = 5; k < kMtPv; ++k) Mc[k] = c == k ? 1.0 : 0.0;
+#pragma unroll
+    for (int p = 0; p < kMtPv; ++p) L.M[p][c] = Mc[p];
+    {
+      const double* J = c < 8 ? J1 : J2;
+      const int a = c & 7;
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s1 += L.y[c] * P.se[c] * J[c * kMtPv + a];
+      for (int cc = 0; cc < 6; ++cc) s1 += L.y[cc] * P.se[cc] * J[cc * kMtPv + a];
 #pragma unroll
       for (int r = 0; r < 5; ++r) s2 += hw[kMtHwGm + r] * J[(1 + r) * kMtPv + a];
-      L.gphi[pt][a] = s1; L.gF[pt][a] = s2;
-    } else if (lane >= 32 && lane < 32 + kMtNi) {
-      const int i = lane - 32;
-      const double s_ = L.s[i], z_ = L.z[i], wgt = z_ / s_;
-      L.W[i] = wgt; L.zeta[i] = wgt * (L.fun[kMtNe + i] + s_); L.is[i] = 1.0 / s_;
+      L.gphi[c] = s1; L.gF[c] = s2;
     }
-    for (int e = lane; e < kMtPv * 14; e += 64) {
-      const int r = e / 14, zi = e - 14 * r;
-      double v = 0.0;
-      if (r < 5) {
-        if (zi < 5) v = (zi == r ? 0.5 : 0.0) + (t / 8.0) * J1[(1 + r) * kMtPv + zi];
-        else if (zi < 8) v = (t / 8.0) * (J1[(1 + r) * kMtPv + zi] - J2[(1 + r) * kMtPv + zi]);
-        else if (zi == 8) v = hw[kMtHwDf + r] / 8.0;
-        else v = (zi - 9 == r ? 0.5 : 0.0) - (t / 8.0) * J2[(1 + r) * kMtPv + (zi - 9)];
-      } else {
-        v = zi == r ? 1.0 : 0.0;
-      }
-      L.M[r][zi] = v;
-    }
-    __syncthreads();
-    // ---- B: Jm M, Hm M, M' gm
-    for (int e = lane; e < 6 * 14; e += 64) {
-      const int c = e / 14, zi = e - 14 * c;
-      double v = 0.0;
-#pragma unroll
-      for (int p = 0; p < kMtPv; ++p) v += Jm[c * kMtPv + p] * L.M[p][zi];
-      L.JM[c][zi] = v;
-    }
-    for (int e = lane; e < kMtPv * 14; e += 64) {
-      const int r = e / 14, zi = e - 14 * r;
-      double v = 0.0;
-#pragma unroll
-      for (int p = 0; p < kMtPv; ++p) v += hw[kMtHwHm + mt_tri8(r, p)] * L.M[p][zi];
-      L.T[r][zi] = v;
-    }
-    if (lane < 14) {
-      double v = 0.0;
-#pragma unroll
-      for (int p = 0; p < kMtPv; ++p) v += L.M[p][lane] * hw[kMtHwGm + p];
-      L.gpsi[lane] = v;
-    }
-    __syncthreads();
-    // ---- C: the 24 x 18 Jacobian (as k_mt_jac_assemble) and the 18 x 18 Hessian (as k_mt_hes_assemble)
     {
-      const double ru = (L.wn[5] - L.wo[5]) * P.sw[5] / t, rd = (L.wn[6] - L.wo[6]) * P.sw[6] / t;
-      double* Jout = st.jac + o * kMtNf * kMtLoc;
-      for (int e = lane; e < kMtNf * kMtLoc; e += 64) {
-        const int row = e / kMtLoc, col = e - kMtLoc * row;
-        double v = 0.0;
-        if (row < 6) {
-          const int c = row;
-          if (col < 14) {
-            const int zi = col;
-            double dv = 4.0 * L.JM[c][zi];
-            if (zi < 5) dv += J1[c * kMtPv + zi];
-            else if (zi < 8) dv += J1[c * kMtPv + zi] + J2[c * kMtPv + zi];
-            else if (zi >= 9) dv += J2[c * kMtPv + (zi - 9)];
-            v = (t / 6.0) * dv;
-            if (zi == 8) v += (hw[kMtHwF + c] + 4.0 * hw[kMtHwF + 12 + c] + hw[kMtHwF + 6 + c]) / 6.0;
-            if (zi < 5 && c == 1 + zi) v += 1.0;
-            if (zi >= 9 && c == 1 + (zi - 9)) v -= 1.0;
-            v *= P.se[c];
-          }
-        } else if (row <= 11) {
-          if (col < kMtPv) v = hw[kMtHwOw + (row - 6) * kMtPv + col];
-        } else {
-          const int gq = row - kMtNe;
-          const double su0 = P.sw[5], su2 = P.sw[6];
-          if (gq == 5) v = col == 4 ? -1.0 / P.sw[4] : 0.0;
-          else if (gq == 6) v = col == 5 ? -1.0 / su0 : 0.0;
-          else if (gq == 7) v = col == 5 ? 1.0 / su0 : 0.0;
-          else if (gq == 8) v = col == 6 ? -1.0 / su2 : 0.0;
-          else if (gq == 9) v = col == 6 ? 1.0 / su2 : 0.0;
-          else if (gq == 10 || gq == 11) {
-            double dr = col == 5 ? -1.0 / t : (col == 14 ? 1.0 / t : (col == 8 ? -ru / t : 0.0));
-            v = (gq == 10 ? -dr : dr) / su0;
-          } else if (gq == 12 || gq == 13) {
-            double dr = col == 6 ? -1.0 / t : (col == 15 ? 1.0 / t : (col == 8 ? -rd / t : 0.0));
-            v = (gq == 12 ? -dr : dr) / su2;
-          } else if (gq == 14) v = col == 0 ? -1.0 / P.sw[0] : 0.0;
-          else if (gq == 15) v = col == 0 ? 1.0 / P.sw[0] : 0.0;
-          else v = col == 8 ? -1.0 : 0.0;
-        }
-        v *= P.sw[col % kMtNv];
-        (&L.J[0][0])[e] = v;
-        if (own) Jout[e] = v;
+      const double s_ = L.s[c], z_ = L.z[c], wgt = z_ / s_;
+      L.W[c] = wgt; L.zeta[c] = wgt * (L.fun[kMtNe + c] + s_); L.is[c] = 1.0 / s_;
+      if (c == 0) {
+        const double s6 = L.s[16], z6 = L.z[16], w6 = z6 / s6;
+        L.W[16] = w6; L.zeta[16] = w6 * (L.fun[kMtNe + 16] + s6); L.is[16] = 1.0 / s6;
       }
-      const double su0 = P.sw[5], su2 = P.sw[6];
-      const double k1 = (L.z[11] - L.z[10]) / su0, k2 = (L.z[13] - L.z[12]) / su2;
+    }
+    __syncthreads();
+    // ---- B: the lane's columns of Jm M and Hm M, M' gm, the products with t
+    double JMc[6], Tc[kMtPv];
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      double v = 0.0;
+#pragma unroll
+      for (int p = 0; p < kMtPv; ++p) v += Jm[cc * kMtPv + p] * Mc[p];
+      JMc[cc] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < kMtPv; ++r) {
+      double v = 0.0;
+#pragma unroll
+      for (int p = 0; p < kMtPv; ++p) v += hw[kMtHwHm + mt_tri8(r, p)] * Mc[p];
+      Tc[r] = v;
+    }
+    double gpsi_c = 0.0;
+#pragma unroll
+    for (int p = 0; p < kMtPv; ++p) gpsi_c += Mc[p] * hw[kMtHwGm + p];
+    double tx_c = 0.0, rt_c = 0.0;
+    {
+      if (c != 8 && c < 14) {
+        tx_c = (2.0 / 3.0) * gpsi_c;
+        if (c < 8) tx_c += L.gphi[c] / 6.0 + (t / 12.0) * L.gF[c];
+        if (has2) tx_c += L.gphi[8 + c2] / 6.0 - (t / 12.0) * L.gF[8 + c2];
+      }
+      const double k1 = (L.z[11] - L.z[10]) / su0, k2 = (L.z[13] - L.z[12]) / su2;   // rate rows: k (u' - u) / t
       const double dF = (L.wn[5] - L.wo[5]) * P.sw[5], dD = (L.wn[6] - L.wo[6]) * P.sw[6];
-      for (int e = lane; e < kMtLoc * kMtLoc; e += 64) {
-        const int la = e / kMtLoc, lb = e - kMtLoc * la;
+      rt_c = c == 5 ? k1 / (t * t) : c == 6 ? k2 / (t * t) : c == 8 ? 2.0 * (k1 * dF + k2 * dD) / (t * t * t)
+           : c == 14 ? -k1 / (t * t) : c == 15 ? -k2 / (t * t) : 0.0;
+      L.gpsi[c] = gpsi_c; L.tx[c] = tx_c; L.rt[c] = rt_c;
+    }
+    // ---- C1: the lane's column of the 24 x 18 Jacobian (formulas of k_mt_jac_assemble)
+    double Jc[kMtNf];
+    {
+      const double t6 = t / 6.0;
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        const double j1 = J1[cc * kMtPv + c1], j2 = J2[cc * kMtPv + c2];
+        double dv = 4.0 * JMc[cc];
+        if (c < 5) dv += j1;
+        else if (c < 8) dv += j1 + j2;
+        else if (c >= 9) dv += j2;
+        double v = t6 * dv;
+        if (c == 8) v += (hw[kMtHwF + cc] + 4.0 * hw[kMtHwF + 12 + cc] + hw[kMtHwF + 6 + cc]) / 6.0;
+        if (cc >= 1 && c == cc - 1) v += 1.0;
+        if (cc >= 1 && c == cc + 8) v -= 1.0;
+        v *= P.se[cc];
+        Jc[cc] = c < 14 ? v * swc : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jc[6 + k] = c < kMtPv ? hw[kMtHwOw + k * kMtPv + c1] * swc : 0.0;
+      const double ru = (L.wn[5] - L.wo[5]) * P.sw[5] / t, rd = (L.wn[6] - L.wo[6]) * P.sw[6] / t;
+      const double dr1 = c == 5 ? -1.0 / t : (c == 14 ? 1.0 / t : (c == 8 ? -ru / t : 0.0));
+      const double dr2 = c == 6 ? -1.0 / t : (c == 15 ? 1.0 / t : (c == 8 ? -rd / t : 0.0));
+      Jc[12] = (c == 4 ? -1.0 / P.sw[4] : 0.0) * swc;
+      Jc[13] = (c == 5 ? -1.0 / su0 : 0.0) * swc;
+      Jc[14] = (c == 5 ? 1.0 / su0 : 0.0) * swc;
+      Jc[15] = (c == 6 ? -1.0 / su2 : 0.0) * swc;
+      Jc[16] = (c == 6 ? 1.0 / su2 : 0.0) * swc;
+      Jc[17] = (-dr1 / su0) * swc;
+      Jc[18] = (dr1 / su0) * swc;
+      Jc[19] = (-dr2 / su2) * swc;
+      Jc[20] = (dr2 / su2) * swc;
+      Jc[21] = (c == 0 ? -1.0 / P.sw[0] : 0.0) * swc;
+      Jc[22] = (c == 0 ? 1.0 / P.sw[0] : 0.0) * swc;
+      Jc[23] = (c == 8 ? -1.0 : 0.0) * swc;
+      double* Jout = st.jac + o * kMtNf * kMtLoc;
+#pragma unroll
+      for (int row = 0; row < kMtNf; ++row) {
+        L.J[row][c] = Jc[row];
+        if (own) Jout[row * kMtLoc + c] = Jc[row];     // columns 16, 17 stay at the zero the array is cleared to
+      }
+    }
+    __syncthreads();
+    // ---- C2: the lane's column of the 18 x 18 Hessian (formulas of k_mt_hes_assemble); rows 16, 17 are zero
+    double Hc[16];
+    {
+      const double gpsi8 = L.gpsi[8];
+#pragma unroll
+      for (int la = 0; la < 16; ++la) {
         double v = 0.0;
-        if (la < 14 && lb < 14) {
+        if (la < 14) {
           double sm = 0.0;
 #pragma unroll
-          for (int p = 0; p < kMtPv; ++p) sm += L.M[p][la] * L.T[p][lb];
+          for (int p = 0; p < 5; ++p) sm += L.M[p][la] * Tc[p];
+          if (la >= 5 && la < 8) sm += Tc[la];            // rows 5..7 of M are unit vectors
           v = (2.0 * t / 3.0) * sm;
-          if (la < 8 && lb < 8) v += hw[kMtHwH1 + mt_tri8(la, lb)];
-          const int a2 = map2(la), b2 = map2(lb);
-          if (a2 >= 0 && b2 >= 0) v += hw[kMtHwH2 + mt_tri8(a2, b2)];
-          if ((la == 8) != (lb == 8)) {
-            const int oth = la == 8 ? lb : la, o2 = map2(oth);
-            v += (2.0 / 3.0) * L.gpsi[oth];
-            if (oth < 8) v += L.gphi[0][oth] / 6.0 + (t / 12.0) * L.gF[0][oth];
-            if (o2 >= 0) v += L.gphi[1][o2] / 6.0 - (t / 12.0) * L.gF[1][o2];
-          } else if (la == 8 && lb == 8) {
-            v += (4.0 / 3.0) * L.gpsi[8];
-          }
+          if (la < 8) { const double h = hw[kMtHwH1 + tri_lane(la, c1, q1)]; v += c < 8 ? h : 0.0; }
+          if (mt_map2(la) >= 0) { const double h = hw[kMtHwH2 + tri_lane(mt_map2(la), c2, q2)]; v += has2 ? h : 0.0; }
+          if (la == 8) v += c == 8 ? (4.0 / 3.0) * gpsi8 : tx_c;
+          else { const double x = L.tx[la]; v += c == 8 ? x : 0.0; }
+          v = c < 14 ? v : 0.0;
         }
-        const int lo = la < lb ? la : lb, hi = la < lb ? lb : la;
-        if (lo == 8 && hi == 8) v += 2.0 * (k1 * dF + k2 * dD) / (t * t * t);
-        else if (lo == 5 && hi == 8) v += k1 / (t * t);
-        else if (lo == 6 && hi == 8) v += k2 / (t * t);
-        else if (lo == 8 && hi == 14) v -= k1 / (t * t);
-        else if (lo == 8 && hi == 15) v -= k2 / (t * t);
-        (&L.H[0][0])[e] = v * P.sw[la % kMtNv] * P.sw[lb % kMtNv];
+        if (la == 8) v += rt_c;
+        else if (la == 5 || la == 6 || la == 14 || la == 15) { const double x = L.rt[la]; v += c == 8 ? x : 0.0; }
+        Hc[la] = v * P.sw[la % kMtNv] * swc;
       }
     }
-    __syncthreads();
-    // ---- D: Do = Hess_oo + Go' W Go, Ct = Hess_no + Gn' W Go, Dn = Hess_nn + Gn' W Gn; the vectors of the right-hand side
-    for (int e = lane; e < 3 * 81; e += 64) {
-      const int which = e / 81, r = e - 81 * which, a = r / 9, c = r - 9 * a;
-      const int ra = which >= 1 ? 9 + a : a, rc = which == 2 ? 9 + c : c;
-      double v = L.H[ra][rc];
+    // ---- D: Hess + G' W G (Do: rows, columns < 9; Ct: rows >= 9, columns < 9; Dn: both >= 9) and the vectors of the right-hand side
+    double v0, v1, v2;
+    {
+      double WG[kMtNi];
 #pragma unroll
-      for (int i = 0; i < kMtNi; ++i) v += L.J[kMtNe + i][ra] * L.W[i] * L.J[kMtNe + i][rc];
-      L.P3[which][r] = v;
-    }
-    if (lane < 2 * kMtNv) {
-      const int side = lane / kMtNv, a = lane - kMtNv * side, col = side * kMtNv + a;
+      for (int i = 0; i < kMtNi; ++i) WG[i] = L.W[i] * Jc[kMtNe + i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double v = Hc[r];
+#pragma unroll
+        for (int i = 0; i < kMtNi; ++i)
+          if (mt_g_has(i, r)) v += L.J[kMtNe + i][r] * WG[i];
+        Hc[r] = v;
+      }
       double ay = 0.0, gz0 = 0.0, g1 = 0.0, gz = 0.0;
 #pragma unroll
-      for (int c = 0; c < kMtNe; ++c) ay += L.J[c][col] * L.y[c];
+      for (int row = 0; row < kMtNe; ++row) ay += Jc[row] * L.y[row];
 #pragma unroll
       for (int i = 0; i < kMtNi; ++i) {
-        const double g = L.J[kMtNe + i][col];
+        const double g = Jc[kMtNe + i];
         gz0 += g * L.zeta[i]; g1 += g * L.is[i]; gz += g * L.z[i];
       }
-      double (*dst)[kMtNv] = side ? L.vn : L.vo;
-      dst[0][a] = ay + gz0; dst[1][a] = g1; dst[2][a] = ay + gz;
+      v0 = ay + gz0; v1 = g1; v2 = ay + gz;
     }
-    __syncthreads();
     // ---- E: the node's blocks and right-hand side (its own pair + the carry of the previous one)
-    if (own) {
+    {
+      const int ct = c >= 9 ? c - 9 : 0, cl = c < 9 ? c : 0;
       double* Dg = st.dblk + o * 256;
       double* Eg = st.eblk + o * 256;
-      for (int e = lane; e < 256; e += 64) {
-        const int i = e >> 4, c = e & 15;
-        double d = 0.0, ev = 0.0;
-        if (i < 9 && c < 9) {
-          d = L.P3[0][i * 9 + c] + L.cDn[i * 9 + c];
-          ev = L.P3[1][i * 9 + c];
-          if (i == c && i >= 5 && i < 8) { d += kMtCostDiag; ev += kMtCostOff; }
-        } else if (i < 9) {
-          d = L.J[c - 9][i];
-          ev = L.J[c - 9][9 + i];
-        } else if (c < 9) {
-          d = L.J[i - 9][c];
-        } else if (i == c) {
-          d = -kMtEpsReg;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double d, ev = 0.0;
+        if (i < kMtNv) {
+          double dd = Hc[i] + L.cDn[i][cl];
+          double ee = 9 + i < 16 ? Hc[9 + i] : 0.0;
+          if (i >= 5 && i < 8) { dd += c == i ? kMtCostDiag : 0.0; ee += c == i ? kMtCostOff : 0.0; }
+          const double jt = L.J[ct][i];                                 // Ao(j)'
+          const double jt2 = 9 + i < 16 ? L.J[ct][9 + i] : 0.0;         // An(j)'
+          d = c < 9 ? dd : jt; ev = c < 9 ? ee : jt2;
+        } else {
+          d = c < 9 ? Jc[i - 9] : (c == i ? -kMtEpsReg : 0.0);          // Ao(j)
         }
-        Dg[e] = d; Eg[e] = ev;
+        if (own) { Dg[i * 16 + c] = d; Eg[i * 16 + c] = ev; }
       }
-      double r0 = 0.0, r1 = 0.0, rdv = 0.0;
-      if (lane < kMtNv) {
-        const int a = lane;
-        double gc = a == 8 ? 1.0 : 0.0;
-        if (a >= 5 && a < 8) gc = 2e-4 * L.wo[a] + 2e-1 * (2.0 * L.wo[a] - L.wn[a] - L.up[a - 5]);
-        r0 = gc + L.vo[0][a] + L.cvn[0][a];
-        r1 = L.vo[1][a] + L.cvn[1][a];
-        rdv = fabs(gc + L.vo[2][a] + L.cvn[2][a]);
-      } else if (lane < 16) {
-        r0 = L.fun[lane - kMtNv];
+      double r0, r1 = 0.0, rdv = 0.0;
+      if (c < kMtNv) {
+        double gc = c == 8 ? 1.0 : 0.0;
+        if (c >= 5 && c < 8) gc = 2e-4 * L.wo[c] + 2e-1 * (2.0 * L.wo[c] - L.wn[c] - L.up[c - 5]);
+        r0 = gc + v0 + L.cvn[0][c];
+        r1 = v1 + L.cvn[1][c];
+        rdv = fabs(gc + v2 + L.cvn[2][c]);
+      } else {
+        r0 = L.fun[c - kMtNv];
       }
-      const double kk = wave_max(rdv);
-      if (lane < 16) {
-        st.rhs[o * 16 + lane] = -r0;
-        st.r1[o * 16 + lane] = lane == kMtNv ? kk : r1;
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) rdv = fmax(rdv, __shfl_xor(rdv, m, 16));
+      if (own) {
+        st.rhs[o * 16 + c] = -r0;
+        st.r1[o * 16 + c] = c == kMtNv ? rdv : r1;
       }
     }
     __syncthreads();
-    // the carry for the next pair
-    for (int e = lane; e < 81; e += 64) L.cDn[e] = L.P3[2][e];
-    if (lane < 3 * kMtNv) (&L.cvn[0][0])[lane] = (&L.vn[0][0])[lane];
-    if (lane < 3) L.up[lane] = L.wo[5 + lane];
+    // the carry for the next pair: lanes 9 .. 15 hold the next node's columns (its gamma and t do not occur)
+    if (c >= 9) {
+#pragma unroll
+      for (int a = 0; a < 7; ++a) L.cDn[a][c - 9] = Hc[9 + a];
+      L.cvn[0][c - 9] = v0; L.cvn[1][c - 9] = v1; L.cvn[2][c - 9] = v2;
+    } else if (c < 3) {
+      L.up[c] = L.wo[5 + c];
+    }
     __syncthreads();
   }
 }
