@@ -82,9 +82,9 @@ struct rl_ctx {
   hipStream_t arena_stream = nullptr;
   bool arena_busy = false;       // arena_ev has been recorded at least once
   // second in-order queue of the min-time solve (half batches side by side), forked from / joined into `stream`
-  static constexpr int kMaxGroups = 4;
-  hipStream_t aux_stream[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+  static constexpr int kMaxGroups = 8;
+  hipStream_t aux_stream[kMaxGroups - 1] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
   bool mt_poll = false;          // set by the HOST entry point of the min-time solve around its call of the _dev one: poll for early exit
   bool mt_hes_sweep = false;     // RL_MT_HES_SWEEP=1: the Hessian by k_mt_derivs<2> instead of the chain-rule kernels
   bool mt_unfused = false;       // RL_MT_UNFUSED=1: Jacobian / Hessian / block assembly by the four separate kernels instead of k_mt_node

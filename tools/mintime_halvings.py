@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Histogram of the accepted step lengths of the min-time solve (number of halvings of the fraction-to-the-boundary length)
+over all iterations of 1024 instances.  Needs a diagnostic build:  RL_MT_HIST=1 python -c "import __graft_entry__ as g; g.build()"."""
 import sys, os, ctypes
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

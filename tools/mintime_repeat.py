@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Three consecutive timed calls of the batched min-time solve (1024 width-perturbed MGKT tracks): the first call of a fresh
+process on a fresh box is ~20 % slower than the following ones.   python tools/mintime_repeat.py"""
 import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from spline_trajectory_optimization_amd.min_time_optm.example import mgkt_problem, perturbed_widths
