@@ -88,7 +88,7 @@ struct rl_ctx {
   bool mt_poll = false;          // set by the HOST entry point of the min-time solve around its call of the _dev one: poll for early exit
   bool mt_hes_sweep = false;     // RL_MT_HES_SWEEP=1: the Hessian by k_mt_derivs<2> instead of the chain-rule kernels
   bool mt_unfused = false;       // RL_MT_UNFUSED=1: Jacobian / Hessian / block assembly by the four separate kernels instead of k_mt_node
-  int mt_groups = 3;             // RL_MT_GROUPS=1..4 (measured at 256 / 1024 instances: 3.66 / 11.55 s, 3.31 / 11.05, 3.14 / 10.53, 3.11 / 10.59)
+  int mt_groups = 3;             // RL_MT_GROUPS=1..8 (round 3, 1024 instances: 1 / 2 / 3 / 4 / 8 streams 1.23 / 1.29 / 1.21 / 1.19 / 1.19 s)
   // Device staging blocks of the HOST-pointer entry points (PoolBuf): handed out best-fit, returned at the end of
   // the call, freed with the context -- a second call of the same shape allocates nothing.
   struct PoolBlock { void* p; size_t cap; bool used; };
