@@ -1,5 +1,5 @@
 """Helper of test_mintime.py: solve the coarse MGKT problem for a few iterations in THIS process (whose environment
-selects the Hessian implementation of the library) and save the iterate.   python mintime_run.py out.npz iterations"""
+selects the Hessian implementation of the library) and save the iterate.   python mintime_run.py out.npz iterations [node spacing, m]"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ from oracle import sqp_twin as tw  # noqa: E402
 from spline_trajectory_optimization_amd import ops  # noqa: E402
 from spline_trajectory_optimization_amd.min_time_optm import defaults  # noqa: E402
 
-d = mgkt_problem(8.0, defaults.ESTIMATES)
+d = mgkt_problem(float(sys.argv[3]) if len(sys.argv) > 3 else 8.0, defaults.ESTIMATES)
 P = tw.Problem(defaults.MODEL, d["s"], d["kappa"], d["left"], d["right"], d["L"], defaults.SOLVER["average_track_width"],
                defaults.SOLVER["speed_cap"])
 X0, U0, T0 = P.unpack(tw.initial_point(P, d["speed"], d["seg_time"]))

@@ -165,6 +165,33 @@ def test_fused_node_kernel_vs_separate_assembly_kernels(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spacing", [31.0, 22.0, 13.0, 5.0])
+def test_fused_node_kernel_tails(tmp_path, spacing):
+    """Node counts that leave partial runs / blocks in every kernel of the default path (runs of 9 pairs in k_mt_node, blocks of
+    3 / 8 nodes in the derivative kernels, 64 rows in k_mt_dir): two iterations against the separate assembly kernels
+    (one thread block per node there: no tails).  The two paths sum the right-hand side in different orders; one KKT solve
+    turns that into 1e-11 on every size, and these coarse grids (31 m between nodes on a kart track) amplify it by a decade per
+    iteration -- a misplaced tail entry would show as O(1)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = {}
+    for mode in ("0", "1"):
+        f = str(tmp_path / f"tail_{mode}.npz")
+        env = dict(os.environ, RL_MT_UNFUSED=mode)
+        subprocess.run([sys.executable, os.path.join(here, "mintime_run.py"), f, "2", str(spacing)], check=True, env=env, timeout=300)
+        out[mode] = np.load(f)
+    a, b = out["0"], out["1"]
+    N = a["X"].shape[1]
+    su = np.maximum(np.abs(b["U"]).max(axis=(0, 1)), 1.0)
+    dev = max(np.abs(a["X"] - b["X"]).max(), np.abs(a["T"] - b["T"]).max(), np.abs((a["U"] - b["U"]) / su).max())
+    print(f"N = {N} (mod 9: {N % 9}, mod 3: {N % 3}, mod 8: {N % 8}): max deviation after 2 iterations {dev:.2e}, kkt {a['st'][0, 1]:.3e} / {b['st'][0, 1]:.3e}")
+    assert np.isfinite(a["X"]).all() and a["st"][0, 0] == b["st"][0, 0] == 2.0
+    assert dev <= 1e-8, dev
+
+
+@pytest.mark.gpu
 def test_mintime_batch_with_per_instance_widths(coarse):
     """A batch of tracks that differ in their widths (BASELINE config 2's perturbation applied to config 5):
     instances are independent (a duplicate agrees bit for bit, instance 0 equals the single solve), wider tracks
