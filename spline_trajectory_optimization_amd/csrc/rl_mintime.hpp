@@ -14,21 +14,27 @@
 //   17 inequalities tyre ellipses (4), power, v >= 1, force / steer limits, force / steer RATE limits
 //       (two rows each), lateral limits, t >= 0                                   g_j(w_j, w_j+1) + s_j = 0, s_j > 0
 //
-//   every iteration:  k_mt_derivs   functions and Jacobians (forward duals) through the templated model code
-//                     k_mt_hes_*    the EXACT Hessian of the pair Lagrangians: forward over forward duals on each
-//                                   dynamics evaluation, chain rule through the Hermite-Simpson midpoint
+//   every iteration:  k_mt_derivs<0>, k_mt_hes_values   functions; values of the dynamics at the two ends -> midpoint
+//                     k_mt_jac_dirs   Jacobians of the three dynamics evaluations of a pair (forward duals)
+//                     k_mt_hes_point  the EXACT Hessians of the weighted dynamics at the midpoint and the ends (forward over
+//                                   forward duals; the pairs with the lateral offset / heading in closed form)
+//                     k_mt_node     chain rule through the Hermite-Simpson midpoint: Jacobian and Hessian of the pair, the
+//                                   16 x 16 diagonal / coupling blocks and the right-hand side, in one pass over runs of pairs
+//                     k_mt_prepare2 convergence test, barrier update, rhs = rhs0 - mu r1
 //                     k_mt_kkt      the barrier QP  [K  A'; A  -eps I] [dw; dy] = rhs  with
 //                                   K = H_cost + Hess + G' S^-1 Z G + delta I: block tridiagonal and CYCLIC
 //                                   (closed lap), 16 x 16 blocks (9 unknowns + 7 multipliers per node),
-//                                   factorised node by node (block LDL' without pivoting; the lap closure is
-//                                   a border block row carried along); the count of negative pivots
+//                                   factorised node by node from both ends (block LDL' without pivoting; the lap closure
+//                                   is a border block row carried along); the count of negative pivots
 //                                   (7 N of 16 N) is the inertia test that drives delta
-//                     k_mt_step     fraction-to-the-boundary rule, backtracking on (infeasibility, barrier
+//                     k_mt_dir, k_mt_step_red, k_mt_trial, k_mt_step_fin, k_mt_step_back
+//                                   fraction-to-the-boundary rule, backtracking on (infeasibility, barrier
 //                                   objective) with a small filter, update of w, s, y, z, delta
-//   One wave per instance in k_mt_kkt (every 16 x 16 block lives in registers, 4 entries per lane, in the
+//   Two waves per instance in k_mt_kkt (every 16 x 16 block lives in registers, 4 entries per lane, in the
 //   operand layout of v_mfma_f64_16x16x4_f64: the block products run on the matrix cores, the block
-//   inverse on cross-lane moves), one thread per (instance, node, slice) in
-//   k_mt_derivs, one workgroup per instance in k_mt_step.
+//   inverse on cross-lane moves); everything else is node- or row-parallel over the whole batch, and one workgroup per
+//   instance only takes decisions.  (k_mt_derivs<1/2>, k_mt_jac_assemble, k_mt_hes_assemble, k_mt_prepare, k_mt_assemble:
+//   the cross-check paths RL_MT_HES_SWEEP=1 / RL_MT_UNFUSED=1.)
 #pragma once
 #include "rl_dtrack.hpp"
 #include "rl_device.hpp"
