@@ -1663,9 +1663,20 @@ __global__ void __launch_bounds__(64) k_mt_dir(MtProblem P, MtState st) {
     const double mu = q.scal[0];
     const int j = idx / kMtNi, c = idx - j * kMtNi, jn = j + 1 == N ? 0 : j + 1;
     const double* Jr = jac + ((size_t)j * kMtNf + kMtNe + c) * kMtLoc;
+    // G dw over the entries the row can have (mt_g_has): rows 0..4 the node's (Y, U), the others one to three entries
+    const double* dwo = q.dw + (size_t)j * kMtNv;
+    const double* dwn = q.dw + (size_t)jn * kMtNv;
     double gd = 0.0;
+    if (c < 5) {
 #pragma unroll
-    for (int a = 0; a < kMtNv; ++a) gd += Jr[a] * q.dw[(size_t)j * kMtNv + a] + Jr[9 + a] * q.dw[(size_t)jn * kMtNv + a];
+      for (int a = 0; a < 8; ++a) gd += Jr[a] * dwo[a];
+    } else if (c == 5) gd = Jr[4] * dwo[4];
+    else if (c < 8) gd = Jr[5] * dwo[5];
+    else if (c < 10) gd = Jr[6] * dwo[6];
+    else if (c < 12) gd = Jr[5] * dwo[5] + Jr[8] * dwo[8] + Jr[14] * dwn[5];
+    else if (c < 14) gd = Jr[6] * dwo[6] + Jr[8] * dwo[8] + Jr[15] * dwn[6];
+    else if (c < 16) gd = Jr[0] * dwo[0];
+    else gd = Jr[8] * dwo[8];
     const double s_ = q.sv[idx], z_ = q.zv[idx], rg = fun[j * kMtNf + kMtNe + c] + s_;
     const double d_s = -rg - gd;
     const double d_z = -(s_ * z_ - mu + z_ * d_s) / s_;
