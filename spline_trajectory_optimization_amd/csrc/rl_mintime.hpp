@@ -429,23 +429,28 @@ __device__ __forceinline__ void mt_own_rows_each(const MtProblem& P, const S (&Y
   r[5] = (Y[4] * fd - p[DT_PMAX]) / p[DT_PMAX];
 }
 
-// grid (blocks of 8 nodes, B, 3): Jacobians of f at the two ends and at the midpoint, one direction per thread; the
+// grid (blocks of 10 nodes, B, 3): Jacobians of f at the two ends and at the midpoint, one direction per thread; the
 // first end also differentiates its own curved rows, the midpoint leaves the value of f there.  Lane = (node, direction):
-// the eight directions of a node write eight consecutive doubles of its row (64 B segments instead of lone 8 B words
-// 2.7 KB apart), and read the node's unknowns as broadcasts.
-constexpr int kMtJacNodes = 8;
+// the directions of a node write consecutive doubles of its rows (instead of lone 8 B words 2.7 KB apart) and read the
+// node's unknowns as broadcasts.  Only the six variables of the force and moment balance (omega, beta, v, F, delta, gamma)
+// go through the dual arithmetic; the lateral offset and the heading enter through s' = v cos(xi + beta) / (1 - n kappa),
+// n' = v sin(xi + beta), xi' = omega - kappa s' only (see k_mt_hes_point): their two columns are closed forms, written by
+// the first two lanes of the node.
+constexpr int kMtJacNodes = 10, kMtJacDirs = 6;
 __global__ void __launch_bounds__(64) k_mt_jac_dirs(MtProblem P, MtState st) {
-  const int j = blockIdx.x * kMtJacNodes + ((int)threadIdx.x >> 3), b = blockIdx.y, N = P.N;
-  const int pt = blockIdx.z, d = threadIdx.x & 7;
-  if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  const int nl = (int)threadIdx.x / kMtJacDirs, dl = (int)threadIdx.x - kMtJacDirs * nl;
+  const int j = blockIdx.x * kMtJacNodes + nl, b = blockIdx.y, N = P.N;
+  const int pt = blockIdx.z, d = 2 + dl;
+  if (nl >= kMtJacNodes || j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
   const int jn = j + 1 == N ? 0 : j + 1;
   double Y[5], Yn[5], U[3], t;
   mt_phys(P, st.w + ((size_t)b * N + j) * kMtNv, st.w + ((size_t)b * N + jn) * kMtNv, Y, Yn, U, t);
   double* hw = st.hw + ((size_t)b * N + j) * kMtHw;
   using D = Dual<1>;
   D Yd[5], Ud[3], f[6];
+  double Yp[5];
 #pragma unroll
-  for (int c = 0; c < 5; ++c) { Yd[c].v = pt == 0 ? Y[c] : (pt == 1 ? Yn[c] : hw[kMtHwXm + c]); Yd[c].d[0] = d == c ? 1.0 : 0.0; }
+  for (int c = 0; c < 5; ++c) { Yp[c] = pt == 0 ? Y[c] : (pt == 1 ? Yn[c] : hw[kMtHwXm + c]); Yd[c].v = Yp[c]; Yd[c].d[0] = d == c ? 1.0 : 0.0; }
 #pragma unroll
   for (int c = 0; c < 3; ++c) { Ud[c].v = U[c]; Ud[c].d[0] = d == 5 + c ? 1.0 : 0.0; }
   DtTyres<D> ty;
@@ -459,7 +464,21 @@ __global__ void __launch_bounds__(64) k_mt_jac_dirs(MtProblem P, MtState st) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) hw[kMtHwOw + c * kMtPv + d] = r[c].d[0];
   }
-  if (pt == 2 && d == 0) {
+  if (dl < 2) {   // column 0 (n) or 1 (xi) of the six rows, in closed form; the own rows do not depend on either
+    const double kap = P.kappa[j], v = Yp[4], D_ = 1.0 / (1.0 - Yp[0] * kap);
+    double sn, cs;
+    m_sincos(Yp[1] + Yp[3], sn, cs);
+    const double d0 = dl == 0 ? v * cs * kap * D_ * D_ : -v * sn * D_;   // d s' / d n, d s' / d xi
+    const double d1 = dl == 0 ? 0.0 : v * cs;                            // d n'
+    J[0 * kMtPv + dl] = d0; J[1 * kMtPv + dl] = d1; J[2 * kMtPv + dl] = -kap * d0;
+#pragma unroll
+    for (int c = 3; c < 6; ++c) J[c * kMtPv + dl] = 0.0;
+    if (pt == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) hw[kMtHwOw + c * kMtPv + dl] = 0.0;
+    }
+  }
+  if (pt == 2 && dl == 0) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) hw[kMtHwF + 12 + c] = f[c].v;
   }
