@@ -1133,7 +1133,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   const size_t bn = (size_t)B * N;
   const size_t counts[] = {bn * rl::kMtNv, bn * rl::kMtNi, bn * rl::kMtNe, bn * rl::kMtNi, bn * rl::kMtNf,
                            bn * rl::kMtNf * rl::kMtLoc, bn * rl::kMtLoc * rl::kMtLoc, bn * rl::kMtNv, bn * rl::kMtNe,
-                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16, (size_t)B * 2 * rl::kMtFilter, bn * rl::kMtHw, bn * 16};
+                           bn * 3 * 256, bn * 16, (size_t)B * 16, bn * 256, bn * 256, bn * 16, (size_t)B * 2 * rl::kMtFilter, bn * rl::kMtHw, bn * 16, bn * rl::kMtGc};
   size_t total = 0;
   for (size_t c : counts) total += Arena::pad(c * sizeof(double));
   Arena ar(ctx);
@@ -1145,7 +1145,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.hes = ar.take<double>(counts[6]); st.dw = ar.take<double>(counts[7]); st.dy = ar.take<double>(counts[8]);
   st.blk = ar.take<double>(counts[9]); st.vec = ar.take<double>(counts[10]); st.scal = ar.take<double>(counts[11]);
   st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
-  st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]); st.r1 = ar.take<double>(counts[17]);
+  st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]); st.r1 = ar.take<double>(counts[17]); st.gc = ar.take<double>(counts[18]);
   st.tol = tol;
   double mt_mu0, mt_delta0;
   {
@@ -1170,7 +1170,6 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   }
   RL_HIP(hipMemsetAsync(st.scal, 0, counts[11] * sizeof(double), ctx->stream));
   if (ctx->mt_hes_sweep) RL_HIP(hipMemsetAsync(st.hes, 0, counts[6] * sizeof(double), ctx->stream));
-  RL_HIP(hipMemsetAsync(st.jac, 0, counts[5] * sizeof(double), ctx->stream));   // k_mt_node never writes columns 16, 17 (structurally zero)
   // A few sub-batches on as many streams: the KKT elimination is one wave per instance and latency bound (its time
   // does not depend on the batch), the derivative kernels are throughput bound -- with the sub-batches offset by the
   // in-order queues one's elimination runs beside another's derivatives.  Instances are independent, so the split
@@ -1198,7 +1197,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     G.st.w = st.w + o * rl::kMtNv; G.st.s = st.s + o * rl::kMtNi; G.st.y = st.y + o * rl::kMtNe; G.st.z = st.z + o * rl::kMtNi;
     G.st.fun = st.fun + o * rl::kMtNf; G.st.jac = st.jac + o * rl::kMtNf * rl::kMtLoc; G.st.hes = st.hes + o * rl::kMtLoc * rl::kMtLoc;
     G.st.dw = st.dw + o * rl::kMtNv; G.st.dy = st.dy + o * rl::kMtNe; G.st.blk = st.blk + o * 3 * 256; G.st.vec = st.vec + o * 16;
-    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.filt = st.filt + (size_t)G.b0 * 2 * rl::kMtFilter; G.st.hw = st.hw + o * rl::kMtHw; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16; G.st.r1 = st.r1 + o * 16;
+    G.st.scal = st.scal + (size_t)G.b0 * 16; G.st.filt = st.filt + (size_t)G.b0 * 2 * rl::kMtFilter; G.st.hw = st.hw + o * rl::kMtHw; G.st.dblk = st.dblk + o * 256; G.st.eblk = st.eblk + o * 256; G.st.rhs = st.rhs + o * 16; G.st.r1 = st.r1 + o * 16; G.st.gc = st.gc + o * rl::kMtGc;
     G.X = X + o * 6; G.U = U + o * 4; G.T = T + o; G.stats = stats + (size_t)G.b0 * 12;
   }
   if (ngrp > 1) {   // fork: the other streams start after everything already enqueued on the first
@@ -1247,6 +1246,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       if (ctx->mt_hes_sweep || ctx->mt_unfused) {
         hipLaunchKernelGGL(rl::k_mt_prepare, dim3(G.nb), dim3(64), 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_gc_pack, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
       }
       hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_dir, dim3(rl::kMtDirBlocks(N), G.nb), bn64, 0, G.q, G.P, G.st);

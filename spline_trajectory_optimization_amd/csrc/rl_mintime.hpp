@@ -197,6 +197,7 @@ struct MtState {       // per-batch device arrays, instance-major
   double* eblk;   // [B,N,256] assembled coupling blocks E_j = M[j+1][j]
   double* rhs;    // [B,N,16]  assembled right-hand sides
   double* r1;     // [B,N,16]  k_mt_node: 0..8 the coefficient of mu in the right-hand side, 9 the node's max |r_d|
+  double* gc;     // [B,N,64]  the 60 entries of the inequality Jacobian that can be non-zero (kMtGc*), what k_mt_dir reads
   double* hw;     // [B,N,kMtHw] work array of the chain-rule Hessian (k_mt_hes_*)
   double* filt;   // [B,16] filter: (infeasibility, barrier objective) of up to 8 earlier iterates of the current barrier problem
   double* scal;   // [B,16] per-instance scalars: 0 mu, 1 delta, 2 kkt, 3 viol, 4 compl, 5 status (0 run, 1 converged,
@@ -984,7 +985,8 @@ __global__ void __launch_bounds__(64) k_mt_assemble(MtProblem P, MtState st) {
 //     pair (fetched one pair ahead into registers) and what other lanes read as broadcasts (M, the Jacobian);
 //   * what the NEXT node's diagonal block and right-hand side need of this pair (Dn = Hess_nn + Gn' W Gn, An' y + Gn' zeta)
 //     is carried to the next pair in LDS -- the group starts one pair early to have the carry of its first node
-//     (1 / kMtRun more work).  The Jacobian is still written (k_mt_dir and the final residuals read it), the Hessian is not.
+//     (1 / kMtRun more work).  Of the Jacobian only the 60 entries of the inequality rows that can be non-zero are written
+//     (k_mt_dir reads them; the final residuals re-assemble the full Jacobian), the Hessian never leaves the chip.
 //   The barrier parameter is updated from the residuals of ALL nodes (k_mt_prepare2, afterwards), so the right-hand
 // side leaves in two pieces: rhs0 (everything but the mu / s term of zeta) and r1 = G' (1 / s); k_mt_prepare2 forms
 // rhs = rhs0 - mu r1 with the mu it has just chosen.  r1[9] carries the node's max |r_d| to the convergence test.
@@ -1006,6 +1008,22 @@ __host__ __device__ constexpr bool mt_g_has(int i, int r) {
        : i < 14 ? (r == 6 || r == 8 || r == 15) : i < 16 ? r == 0 : r == 8;
 }
 __host__ __device__ constexpr int mt_map2(int zi) { return zi >= 9 ? zi - 9 : (zi >= 5 && zi < 8 ? zi : -1); }
+
+// Compact inequality Jacobian of a pair: slots 0..39 = rows 0..4 x columns 0..7 (tyre ellipses, power: the node's (Y, U)),
+// slots 40..59 = the one to three entries of the other rows (mt_g_has), in row order.
+constexpr int kMtGc = 64, kMtGcSparse = 20;
+__device__ constexpr unsigned char kMtGcRow[kMtGcSparse] = {5, 6, 7, 8, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13, 13, 13, 14, 15, 16};
+__device__ constexpr unsigned char kMtGcCol[kMtGcSparse] = {4, 5, 5, 6, 6, 5, 8, 14, 5, 8, 14, 6, 8, 15, 6, 8, 15, 0, 0, 8};
+
+// cross-check paths (full Jacobian from k_mt_derivs<1> / k_mt_jac_assemble): gather the compact form; grid (N, B)
+__global__ void __launch_bounds__(64) k_mt_gc_pack(MtProblem P, MtState st) {
+  const int j = blockIdx.x, b = blockIdx.y, l = threadIdx.x, N = P.N;
+  if (st.scal[(size_t)b * 16 + 5] != 0.0 || l >= 40 + kMtGcSparse) return;
+  const size_t o = (size_t)b * N + j;
+  const double* Jg = st.jac + (o * kMtNf + kMtNe) * kMtLoc;
+  const int row = l < 40 ? l >> 3 : kMtGcRow[l - 40], col = l < 40 ? l & 7 : kMtGcCol[l - 40];
+  st.gc[o * kMtGc + l] = Jg[row * kMtLoc + col];
+}
 
 __global__ void __launch_bounds__(64) k_mt_node(MtProblem P, MtState st) {
   __shared__ MtNodeGrp LG[kMtNodeGroups];
@@ -1168,14 +1186,19 @@ __global__ void __launch_bounds__(64) k_mt_node(MtProblem P, MtState st) {
       Jc[21] = (c == 0 ? -1.0 / P.sw[0] : 0.0) * swc;
       Jc[22] = (c == 0 ? 1.0 / P.sw[0] : 0.0) * swc;
       Jc[23] = (c == 8 ? -1.0 : 0.0) * swc;
-      double* Jout = st.jac + o * kMtNf * kMtLoc;
+      double* Gc = st.gc + o * kMtGc;
 #pragma unroll
-      for (int row = 0; row < kMtNf; ++row) {
-        L.J[row][c] = Jc[row];
-        if (own) Jout[row * kMtLoc + c] = Jc[row];     // columns 16, 17 stay at the zero the array is cleared to
-      }
+      for (int row = 0; row < kMtNf; ++row) L.J[row][c] = Jc[row];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        if (own && c < 8) Gc[i * 8 + c] = Jc[kMtNe + i];
     }
     __syncthreads();
+    if (own) {   // the sparse rows of the inequality Jacobian, 16 + 4 entries
+      double* Gc = st.gc + o * kMtGc;
+      Gc[40 + c] = L.J[kMtNe + kMtGcRow[c]][kMtGcCol[c]];
+      if (c < kMtGcSparse - 16) Gc[56 + c] = L.J[kMtNe + kMtGcRow[16 + c]][kMtGcCol[16 + c]];
+    }
     // ---- C2: the lane's column of the 18 x 18 Hessian (formulas of k_mt_hes_assemble); rows 16, 17 are zero
     double Hc[16];
     {
@@ -1678,24 +1701,23 @@ __global__ void __launch_bounds__(64) k_mt_dir(MtProblem P, MtState st) {
   double ap = 1.0, ad = 1.0, th = 0.0, ph = 0.0;
   if (idx < N * kMtNi) {
     const double* fun = st.fun + (size_t)b * N * kMtNf;
-    const double* jac = st.jac + (size_t)b * N * kMtNf * kMtLoc;
     const double mu = q.scal[0];
     const int j = idx / kMtNi, c = idx - j * kMtNi, jn = j + 1 == N ? 0 : j + 1;
-    const double* Jr = jac + ((size_t)j * kMtNf + kMtNe + c) * kMtLoc;
-    // G dw over the entries the row can have (mt_g_has): rows 0..4 the node's (Y, U), the others one to three entries
+    // G dw over the entries the row can have (the compact form of k_mt_node / k_mt_gc_pack)
+    const double* G = st.gc + ((size_t)b * N + j) * kMtGc;
     const double* dwo = q.dw + (size_t)j * kMtNv;
     const double* dwn = q.dw + (size_t)jn * kMtNv;
     double gd = 0.0;
     if (c < 5) {
 #pragma unroll
-      for (int a = 0; a < 8; ++a) gd += Jr[a] * dwo[a];
-    } else if (c == 5) gd = Jr[4] * dwo[4];
-    else if (c < 8) gd = Jr[5] * dwo[5];
-    else if (c < 10) gd = Jr[6] * dwo[6];
-    else if (c < 12) gd = Jr[5] * dwo[5] + Jr[8] * dwo[8] + Jr[14] * dwn[5];
-    else if (c < 14) gd = Jr[6] * dwo[6] + Jr[8] * dwo[8] + Jr[15] * dwn[6];
-    else if (c < 16) gd = Jr[0] * dwo[0];
-    else gd = Jr[8] * dwo[8];
+      for (int a = 0; a < 8; ++a) gd += G[c * 8 + a] * dwo[a];
+    } else if (c == 5) gd = G[40] * dwo[4];
+    else if (c < 8) gd = G[35 + c] * dwo[5];
+    else if (c < 10) gd = G[35 + c] * dwo[6];
+    else if (c < 12) { const double* g3 = G + 45 + 3 * (c - 10); gd = g3[0] * dwo[5] + g3[1] * dwo[8] + g3[2] * dwn[5]; }
+    else if (c < 14) { const double* g3 = G + 51 + 3 * (c - 12); gd = g3[0] * dwo[6] + g3[1] * dwo[8] + g3[2] * dwn[6]; }
+    else if (c < 16) gd = G[43 + c] * dwo[0];
+    else gd = G[59] * dwo[8];
     const double s_ = q.sv[idx], z_ = q.zv[idx], rg = fun[j * kMtNf + kMtNe + c] + s_;
     const double d_s = -rg - gd;
     const double d_z = -(s_ * z_ - mu + z_ * d_s) / s_;
