@@ -86,6 +86,12 @@ struct rl_ctx {
   hipStream_t aux_stream[kMaxGroups - 1] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
   bool mt_poll = false;          // set by the HOST entry point of the min-time solve around its call of the _dev one: poll for early exit
+  // the poll never drains the queues: the status words of a chunk of 8 iterations are copied by a side stream into pinned
+  // memory while the next chunk is already enqueued, and looked at one chunk later
+  hipStream_t poll_stream = nullptr;
+  hipEvent_t ev_chunk[kMaxGroups] = {}, ev_poll[2] = {nullptr, nullptr};
+  double* poll_host = nullptr;   // pinned, 2 x poll_cap doubles
+  size_t poll_cap = 0;
   bool mt_hes_sweep = false;     // RL_MT_HES_SWEEP=1: the Hessian by k_mt_derivs<2> instead of the chain-rule kernels
   bool mt_unfused = false;       // RL_MT_UNFUSED=1: Jacobian / Hessian / block assembly by the four separate kernels instead of k_mt_node
   int mt_groups = 3;             // RL_MT_GROUPS=1..8 (round 3, 1024 instances: 1 / 2 / 3 / 4 / 8 streams 1.23 / 1.29 / 1.21 / 1.19 / 1.19 s)
@@ -377,6 +383,10 @@ void rl_ctx_destroy(rl_ctx* ctx) {
     if (ctx->ev_join[g]) (void)hipEventDestroy(ctx->ev_join[g]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->poll_stream) (void)hipStreamDestroy(ctx->poll_stream);
+  for (auto& e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_poll) if (e) (void)hipEventDestroy(e);
+  if (ctx->poll_host) (void)hipHostFree(ctx->poll_host);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
@@ -1222,6 +1232,19 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     hipLaunchKernelGGL(rl::k_mt_init, dim3((N * rl::kMtNi + 255) / 256, G.nb), dim3(256), 0, G.q, G.P, G.st, mt_mu0, mt_delta0);
   }
   RL_HIP(hipGetLastError());
+  if (ctx->mt_poll) {
+    if (!ctx->poll_stream) RL_HIP(hipStreamCreateWithFlags(&ctx->poll_stream, hipStreamNonBlocking));
+    for (int g = 0; g < ngrp; ++g)
+      if (!ctx->ev_chunk[g]) RL_HIP(hipEventCreateWithFlags(&ctx->ev_chunk[g], hipEventDisableTiming));
+    for (auto& e : ctx->ev_poll)
+      if (!e) RL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (ctx->poll_cap < (size_t)B * 16) {
+      if (ctx->poll_host) RL_HIP(hipHostFree(ctx->poll_host));
+      ctx->poll_host = nullptr; ctx->poll_cap = 0;
+      RL_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->poll_host), 2 * (size_t)B * 16 * sizeof(double), hipHostMallocDefault));
+      ctx->poll_cap = (size_t)B * 16;
+    }
+  }
   for (int it = 0; it < max_iter; ++it) {   // finished instances return at once from every kernel
     for (int g = 0; g < ngrp; ++g) {
       const Grp& G = grp[g];
@@ -1256,15 +1279,24 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       hipLaunchKernelGGL(rl::k_mt_step_back, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
     }
     if (ctx->mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
-      std::vector<double> h((size_t)B * 16);
-      RL_HIP(join());
-      RL_HIP(hipMemcpyAsync(h.data(), st.scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      RL_HIP(hipStreamSynchronize(ctx->stream));
-      bool all = true;
-      for (int b = 0; b < B; ++b) all = all && h[(size_t)b * 16 + 5] != 0.0;
-      if (all) break;
+      const int chunk = it >> 3, slot = chunk & 1;
+      for (int g = 0; g < ngrp; ++g) {
+        RL_HIP(hipEventRecord(ctx->ev_chunk[g], grp[g].q));
+        RL_HIP(hipStreamWaitEvent(ctx->poll_stream, ctx->ev_chunk[g], 0));
+      }
+      RL_HIP(hipMemcpyAsync(ctx->poll_host + (size_t)slot * ctx->poll_cap, st.scal, (size_t)B * 16 * sizeof(double),
+                            hipMemcpyDeviceToHost, ctx->poll_stream));
+      RL_HIP(hipEventRecord(ctx->ev_poll[slot], ctx->poll_stream));
+      if (chunk >= 1) {   // the chunk before this one: its copy is done, or nearly, while this chunk keeps the GPU busy
+        RL_HIP(hipEventSynchronize(ctx->ev_poll[slot ^ 1]));
+        const double* h = ctx->poll_host + (size_t)(slot ^ 1) * ctx->poll_cap;
+        bool all = true;
+        for (int b = 0; b < B && all; ++b) all = h[(size_t)b * 16 + 5] != 0.0;
+        if (all) break;
+      }
     }
   }
+  if (ctx->mt_poll) RL_HIP(hipStreamSynchronize(ctx->poll_stream));   // no copy in flight into the pinned buffer when the call returns
   // final residuals of the instances still running (status 0 = iteration limit)
   for (int g = 0; g < ngrp; ++g) {
     const Grp& G = grp[g];
