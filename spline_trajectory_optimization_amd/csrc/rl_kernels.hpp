@@ -367,7 +367,7 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
 constexpr int kSweepDumpHead = 16;
 
 template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false, bool SIGMA_LDS = RINGS_LDS>
-__global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 4 : 1) void k_sweep(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
   const TrackDev& tr = a.tr;
@@ -511,6 +511,32 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(SweepArgs a) {
       // windowed, wave-cooperative search: a wave takes 64 consecutive samples and intersects
       // their normals with the left ring, then with the right ring (one curve evaluation for both)
       const int nwt = (m + kWave - 1) / kWave;
+#ifndef RL_SWEEP_TASKS
+#define RL_SWEEP_TASKS 1
+#endif
+      if constexpr (BLOCK >= 512 && !JOINT && RL_SWEEP_TASKS) {
+        // EXPERIMENT (-DRL_ABLATION, RL_SWEEP_BLOCK=512): eight waves per instance, the two rings of a tile searched by a wave
+        // PAIR (task = (tile, ring)); the curve point is evaluated by both waves of the pair
+        for (int tk = wave; tk < 2 * nwt; tk += NW) {
+          const int wt = tk >> 1;
+          const bool right = tk & 1;
+          const int r = wt * kWave + lane;
+          const bool active = r < m;
+          const int i = active ? (r < m0 ? i0 + r : j0 + (r - m0)) : (m0 > 0 ? i0 : j0);
+          CurvePoint<K, 1> c;
+          eval_sample<K, 1>(tr, cx, cy, i, tr.ell[i], c);
+          double dx, dy, inv_s2;
+          scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);
+          if (!right) {
+            const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y, dx, dy, a.max_dist, false);
+            if (active) { sL[i] = hl.best_s; hints[i] = (unsigned short)(hl.edge == kNoEdge ? 0xFFFF : hl.edge); }
+          } else {
+            const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x, c.y, -dx, -dy, a.max_dist, false);
+            if (active) { sR[i] = hr.best_s; hints[Npad + i] = (unsigned short)(hr.edge == kNoEdge ? 0xFFFF : hr.edge); }
+          }
+        }
+        return;
+      }
       for (int wt = wave; wt < nwt; wt += NW) {
         const int r = wt * kWave + lane;
         const bool active = r < m;

@@ -298,6 +298,11 @@ int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepAr
     return p.rings_in_lds ? launch_sweep_t<5, 256, true, true>(ctx, a, p.lds_bytes)
                           : launch_sweep_t<5, 256, false, true>(ctx, a, p.lds_bytes);
   }
+#ifdef RL_ABLATION
+  if (k == 5 && !joint && !p.rings_in_lds && !a.dbg && getenv("RL_SWEEP_BLOCK") && atoi(getenv("RL_SWEEP_BLOCK")) == 512)
+    return p.sigma_in_lds ? launch_sweep_t<5, 512, false, false, false, true>(ctx, a, p.lds_bytes)
+                          : launch_sweep_t<5, 512, false>(ctx, a, p.lds_bytes);
+#endif
   if (k == 5 && !joint && !p.rings_in_lds && p.sigma_in_lds)
     return launch_sweep_t<5, 256, false, false, false, true>(ctx, a, p.lds_bytes);
 #ifdef RL_STAMPS
