@@ -1025,6 +1025,9 @@ __global__ void __launch_bounds__(64) k_mt_gc_pack(MtProblem P, MtState st) {
   st.gc[o * kMtGc + l] = Jg[row * kMtLoc + col];
 }
 
+static_assert(kMtHw == 21 * 16, "k_mt_node fetches the work array as 21 rows of 16 lanes");
+static_assert(kMtNv == 9 && kMtNe == 7 && kMtNi == 17 && kMtLoc == 18, "k_mt_node's lane = column layout is written for 9 + 7 unknowns per node");
+static_assert(kMtHesNodes * kMtDynPairs <= 64 && kMtJacNodes * kMtJacDirs <= 64, "(node, direction) lanes of the derivative kernels fit one wave");
 __global__ void __launch_bounds__(64) k_mt_node(MtProblem P, MtState st) {
   __shared__ MtNodeGrp LG[kMtNodeGroups];
   const int b = blockIdx.y, lane = threadIdx.x, N = P.N;
