@@ -23,7 +23,7 @@
  *     changed between calls (rl_ctx_set_stream): the *_dev calls that use the arena order themselves behind the
  *     previous user of the arena with an event when the stream has changed, so two such calls enqueued on different
  *     streams without a host synchronisation in between run one after the other, never on the same scratch at once;
- *   - the only environment variables the product library reads are RL_GLOBAL_V1, RL_MT_HES_SWEEP, RL_MT_UNFUSED, RL_MT_GROUPS (test
+ *   - the only environment variables the product library reads are RL_GLOBAL_V1, RL_MT_HES_SWEEP, RL_MT_UNFUSED, RL_MT_KKT4, RL_MT_GROUPS (test
  *     hooks selecting a second implementation, read once in rl_ctx_create) and RL_FORCE_RESIDENCY / RL_FORCE_GLOBAL_RINGS
  *     (residency of the sweep's per-instance state; all variants are bit-identical): INTEGRATION.md lists them.  Solver
  *     strategy constants are compile-time; RL_MT_* / RL_DEBUG_FLAGS overrides exist only in a -DRL_ABLATION diagnostic build;

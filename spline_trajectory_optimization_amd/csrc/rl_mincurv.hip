@@ -93,6 +93,7 @@ struct rl_ctx {
   double* poll_host = nullptr;   // pinned, 2 x poll_cap doubles
   size_t poll_cap = 0;
   bool mt_hes_sweep = false;     // RL_MT_HES_SWEEP=1: the Hessian by k_mt_derivs<2> instead of the chain-rule kernels
+  bool mt_kkt4 = true;           // RL_MT_KKT4=0: the elimination with two fronts per instance (k_mt_kkt) instead of four (k_mt_kkt4, N >= 64)
   bool mt_unfused = false;       // RL_MT_UNFUSED=1: Jacobian / Hessian / block assembly by the four separate kernels instead of k_mt_node
   int mt_groups = 3;             // RL_MT_GROUPS=1..8 (round 3, 1024 instances: 1 / 2 / 3 / 4 / 8 streams 1.23 / 1.29 / 1.21 / 1.19 / 1.19 s)
   // Device staging blocks of the HOST-pointer entry points (PoolBuf): handed out best-fit, returned at the end of
@@ -368,6 +369,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
   if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
   if (const char* v = getenv("RL_MT_HES_SWEEP")) c->mt_hes_sweep = v[0] == '1';
   if (const char* v = getenv("RL_MT_UNFUSED")) c->mt_unfused = v[0] == '1';
+  if (const char* v = getenv("RL_MT_KKT4")) c->mt_kkt4 = v[0] == '1';
   if (const char* v = getenv("RL_MT_GROUPS")) { const int g = atoi(v); if (g >= 1 && g <= rl_ctx::kMaxGroups) c->mt_groups = g; }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
@@ -1276,7 +1278,8 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
         hipLaunchKernelGGL(rl::k_mt_assemble, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_gc_pack, dim3(N, G.nb), dim3(64), 0, G.q, G.P, G.st);
       }
-      hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
+      if (ctx->mt_kkt4 && N >= 64) hipLaunchKernelGGL(rl::k_mt_kkt4, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
+      else hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_dir, dim3(rl::kMtDirBlocks(N), G.nb), bn64, 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_step_red, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_trial, gn, bn64, 0, G.q, G.P, G.st);

@@ -1543,6 +1543,291 @@ __global__ void __launch_bounds__(128) k_mt_kkt(MtProblem P, MtState st) {
   }
 }
 
+// k_mt_kkt4: the same elimination with FOUR fronts (four waves per instance).  The chain 0 .. N-2 is cut at the middle node m
+// (as in k_mt_kkt) and at q1 = m / 2, q3 = m + (N - 1 - m) / 2:
+//     front 0: 0 .. q1-1 ascending,   fill towards the border node L = N-1      front 2: m-1 .. q1+1 descending, fill towards m
+//     front 3: m+1 .. q3-1 ascending, fill towards m                            front 1: N-2 .. q3+1 descending, fill towards L
+// Interior nodes are coupled to L only through the two ends of the chain, so a front that starts next to m carries its fill
+// towards m INSTEAD of towards L: every front does exactly the work of a front of k_mt_kkt, on half as many nodes.  The fronts
+// meet pairwise at q1 and q3; what is left is a 4-node system (q1, q3 | m | L): wave 0 eliminates q1 and wave 1 q3 at the same
+// time, wave 0 then m and L.  Back substitution: x_L, x_m, x_q1, x_q3, then the four chains away from q1 / q3.  The dependent
+// chain is (N-1)/4 + 3 block steps instead of (N-1)/2 + 2.  Same factorisation up to the elimination order (inertia test as before).
+struct MtKkt4Share {
+  double T[4][256], Fn[4][256], Sl[4][256];       // per front: Schur complement onto its meeting node, fill meeting node -> target, sum for its target's diagonal
+  double rn[4][16], rl[4][16];
+  double dSm[2][256], dSL[2][256], dC[2][256];    // from the elimination of q1 (0) and q3 (1): to S_m, S_L and the block M[L][m]
+  double drm[2][16], drL[2][16];
+  double xL[16], xm[16], xq[2][16];
+  double xs[4][2][16];
+  int bad[4], nneg[4], bad2[2], nneg2[2], ok;
+};
+
+__global__ void __launch_bounds__(256, 2) k_mt_kkt4(MtProblem P, MtState st) {
+  __shared__ MtKkt4Share X;
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, N = P.N;
+  const int i = lane & 15, q = lane >> 4;
+  double* scal = st.scal + (size_t)b * 16;
+  if (scal[5] != 0.0) return;
+  const double* Dg = st.dblk + (size_t)b * N * 256;
+  const double* Eg = st.eblk + (size_t)b * N * 256;
+  const double* Rg = st.rhs + (size_t)b * N * 16;
+  double* blk = st.blk + (size_t)b * N * 3 * 256;   // per node: P [256], Q [256], a' [16]
+  double* vec = st.vec + (size_t)b * N * 16;
+  double delta = scal[1];
+  auto ld = [&](const double* G) { MtBlk Z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Z.v[r] = G[i * 16 + 4 * r + q];
+    return Z; };
+  auto ld_t = [&](const double* G) { MtBlk Z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Z.v[r] = G[(4 * r + q) * 16 + i];
+    return Z; };
+  auto st_rm = [&](double* G, const MtBlk& Z) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[i * 16 + 4 * r + q] = Z.v[r]; };
+  auto shift = [&](MtBlk& Z) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Z.v[r] += (i == 4 * r + q && i < kMtNv) ? delta : 0.0; };
+  auto lds_get = [&](const double* A) { MtBlk Z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Z.v[r] = A[lane * 4 + r];
+    return Z; };
+  auto lds_put = [&](double* A, const MtBlk& Z) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A[lane * 4 + r] = Z.v[r]; };
+  const MtBlk zero = {{0.0, 0.0, 0.0, 0.0}};
+  const int L_ = N - 1, m = (N - 1) / 2, q1 = m / 2, q3 = m + (N - 1 - m) / 2;
+  const bool asc = wave == 0 || wave == 3;
+  const int first = wave == 0 ? 0 : (wave == 1 ? N - 2 : (wave == 2 ? m - 1 : m + 1));
+  const int cnt = wave == 0 ? q1 : (wave == 1 ? N - 2 - q3 : (wave == 2 ? m - 1 - q1 : q3 - m - 1));   // all >= 1 for N >= 16
+  const int meet = (wave == 0 || wave == 2) ? q1 : q3;
+  auto node = [&](int s_) { return asc ? first + s_ : first - s_; };
+  auto ld_e = [&](int j) { return asc ? ld(Eg + (size_t)j * 256) : ld_t(Eg + (size_t)(j - 1) * 256); };   // coupling to the next node of the front
+
+  int attempt = 0;
+  bool ok = false;
+  for (; attempt < 12 && !ok; ++attempt) {
+    bool bad = false;
+    int n_neg = 0;
+    MtBlk S = ld_t(Dg + (size_t)first * 256); shift(S);
+    // the block M[target][first node]: E_{N-1}' , E_{N-2} (border), E_{m-1}, E_m' (middle)
+    MtBlk F = wave == 0 ? ld_t(Eg + (size_t)(N - 1) * 256) : (wave == 1 ? ld(Eg + (size_t)(N - 2) * 256)
+            : (wave == 2 ? ld(Eg + (size_t)(m - 1) * 256) : ld_t(Eg + (size_t)m * 256)));
+    MtBlk SlC = zero, Tx = zero, Fx = zero;
+    double rlC = 0.0, rx = 0.0;
+    double rk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rk[r] = Rg[(size_t)first * 16 + 4 * r + q];
+    MtBlk eN = ld_e(first), dN = cnt > 1 ? ld_t(Dg + (size_t)node(1) * 256) : zero;
+    double rN = cnt > 1 ? Rg[(size_t)node(1) * 16 + i] : 0.0;
+    for (int s_ = 0; s_ < cnt && !bad; ++s_) {
+      const int j = node(s_);
+      const MtBlk E = eN, dC = dN;
+      const double rC = rN;
+      if (s_ + 1 < cnt) {
+        eN = ld_e(node(s_ + 1));
+        dN = s_ + 2 < cnt ? ld_t(Dg + (size_t)node(s_ + 2) * 256) : zero;
+        rN = s_ + 2 < cnt ? Rg[(size_t)node(s_ + 2) * 16 + i] : 0.0;
+      }
+      const int neg = mt_invert(S, lane);
+      if (neg < 0) { bad = true; break; }
+      n_neg += neg;
+      const double aj = mt_gemv(S, rk);
+      if (q == 0) vec[(size_t)j * 16 + i] = aj;
+      const MtBlk Pm = mt_mul_t(S, E);
+      const MtBlk Qm = mt_mul_t(S, F);
+      double* Bj = blk + (size_t)j * 3 * 256;
+      st_rm(Bj, Pm); st_rm(Bj + 256, Qm);
+      rlC -= mt_gemv(Qm, rk);
+      {
+        const MtBlk U = mt_mul_t(F, Qm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) SlC.v[r] -= U.v[r];
+      }
+      const MtBlk M = mt_mul_t(E, Pm), Fn = mt_mul_t(E, Qm);
+      const double rn = -mt_gemv(Pm, rk);
+      if (s_ + 1 < cnt) {
+        S = dC; shift(S);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { S.v[r] -= M.v[r]; F.v[r] = -Fn.v[r]; }
+        mt_to_k(rC + rn, q, rk);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Tx.v[r] = -M.v[r]; Fx.v[r] = -Fn.v[r]; }
+        rx = rn;
+      }
+    }
+    lds_put(X.T[wave], Tx); lds_put(X.Fn[wave], Fx); lds_put(X.Sl[wave], SlC);
+    if (q == 0) { X.rn[wave][i] = rx; X.rl[wave][i] = rlC; }
+    if (lane == 0) { X.bad[wave] = bad ? 1 : 0; X.nneg[wave] = n_neg; }
+    __syncthreads();
+    const bool fronts_ok = X.bad[0] == 0 && X.bad[1] == 0 && X.bad[2] == 0 && X.bad[3] == 0;
+    // ---- the meeting nodes: wave 0 eliminates q1 (fronts 0 and 2), wave 1 q3 (fronts 1 and 3); two targets each: L and m
+    if (fronts_ok && wave < 2) {
+      const int other = wave + 2;
+      const MtBlk To = lds_get(X.T[other]), CL = Fx, Cm = lds_get(X.Fn[other]);   // M[L][meet] from the own front, M[m][meet] from the other
+      MtBlk Sq = ld_t(Dg + (size_t)meet * 256); shift(Sq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Sq.v[r] += Tx.v[r] + To.v[r];
+      double rqk[4];
+      mt_to_k(Rg[(size_t)meet * 16 + i] + rx + X.rn[other][i], q, rqk);
+      const int negq = mt_invert(Sq, lane);
+      const double aq = mt_gemv(Sq, rqk);
+      if (q == 0) vec[(size_t)meet * 16 + i] = aq;
+      const MtBlk Qm = mt_mul_t(Sq, Cm), QL = mt_mul_t(Sq, CL);
+      double* Bq = blk + (size_t)meet * 3 * 256;
+      st_rm(Bq, Qm); st_rm(Bq + 256, QL);
+      MtBlk dSm = mt_mul_t(Cm, Qm), dSL = mt_mul_t(CL, QL), dCc = mt_mul_t(Cm, QL);   // Qm Cm', QL CL', QL Cm'
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dSm.v[r] = -dSm.v[r]; dSL.v[r] = -dSL.v[r]; dCc.v[r] = -dCc.v[r]; }
+      lds_put(X.dSm[wave], dSm); lds_put(X.dSL[wave], dSL); lds_put(X.dC[wave], dCc);
+      const double drm = -mt_gemv(Qm, rqk), drL = -mt_gemv(QL, rqk);
+      if (q == 0) { X.drm[wave][i] = drm; X.drL[wave][i] = drL; }
+      if (lane == 0) { X.bad2[wave] = negq < 0 ? 1 : 0; X.nneg2[wave] = negq < 0 ? 0 : negq; }
+    }
+    __syncthreads();
+    if (fronts_ok && wave == 0) {
+      // ---- m, then the border
+      bool okm = X.bad2[0] == 0 && X.bad2[1] == 0;
+      MtBlk Sm = ld_t(Dg + (size_t)m * 256); shift(Sm);
+      MtBlk Sl = ld_t(Dg + (size_t)L_ * 256); shift(Sl);
+      MtBlk C;
+      {
+        const MtBlk a2 = lds_get(X.Sl[2]), a3 = lds_get(X.Sl[3]), d0 = lds_get(X.dSm[0]), d1 = lds_get(X.dSm[1]);
+        const MtBlk l1 = lds_get(X.Sl[1]), e0 = lds_get(X.dSL[0]), e1 = lds_get(X.dSL[1]);
+        const MtBlk c0 = lds_get(X.dC[0]), c1 = lds_get(X.dC[1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Sm.v[r] += a2.v[r] + a3.v[r] + d0.v[r] + d1.v[r];
+          Sl.v[r] += SlC.v[r] + l1.v[r] + e0.v[r] + e1.v[r];
+          C.v[r] = c0.v[r] + c1.v[r];
+        }
+      }
+      double rmk[4];
+      mt_to_k(Rg[(size_t)m * 16 + i] + X.rl[2][i] + X.rl[3][i] + X.drm[0][i] + X.drm[1][i], q, rmk);
+      double rl = Rg[(size_t)L_ * 16 + i] + rlC + X.rl[1][i] + X.drL[0][i] + X.drL[1][i];
+      int total = X.nneg[0] + X.nneg[1] + X.nneg[2] + X.nneg[3] + X.nneg2[0] + X.nneg2[1];
+      const int negm = mt_invert(Sm, lane);
+      if (negm < 0) okm = false;
+      total += negm;
+      const double am = mt_gemv(Sm, rmk);
+      if (q == 0) vec[(size_t)m * 16 + i] = am;
+      const MtBlk QLm = mt_mul_t(Sm, C);                // M[L][m] S_m^-1
+      double* Bm = blk + (size_t)m * 3 * 256;
+      st_rm(Bm, zero); st_rm(Bm + 256, QLm);
+      rl -= mt_gemv(QLm, rmk);
+      {
+        const MtBlk U = mt_mul_t(C, QLm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sl.v[r] -= U.v[r];
+      }
+      const int negl = mt_invert(Sl, lane);
+      if (negl < 0 || total + negl != N * kMtNe) okm = false;
+      if (okm) {
+        double rlk[4];
+        mt_to_k(rl, q, rlk);
+        const double xl = mt_gemv(Sl, rlk);
+        if (q == 0) X.xL[i] = xl;
+      }
+      if (lane == 0) X.ok = okm ? 1 : 0;
+    }
+    __syncthreads();
+    if (!fronts_ok || X.ok == 0) {
+      delta = fmax(10.0 * delta, 1e-4);
+      __syncthreads();
+      if (delta > 1e8) break;
+      continue;
+    }
+    ok = true;
+  }
+  if (threadIdx.x == 0) { scal[1] = delta; scal[10] += (double)(attempt - 1); }
+  if (!ok) {
+    if (threadIdx.x == 0) scal[5] = 2.0;
+    return;
+  }
+  // ---- back substitution.  Wave 0: x_L, x_m = a_m - Q_m' x_L, x_q = a_q - Qm_q' x_m - QL_q' x_L for q1 and q3
+  double* dw = st.dw + (size_t)b * N * kMtNv;
+  double* dy = st.dy + (size_t)b * N * kMtNe;
+  auto put_x = [&](int j, double x) {   // lanes 0..15
+    if (lane < kMtNv) dw[(size_t)j * kMtNv + lane] = x;
+    else dy[(size_t)j * kMtNe + lane - kMtNv] = x;
+  };
+  if (wave == 0 && lane < 16) {
+    put_x(L_, X.xL[lane]);
+    const double* Qg = blk + (size_t)m * 3 * 256 + 256;
+    double xm = vec[(size_t)m * 16 + lane];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xm = fma(-Qg[k * 16 + lane], X.xL[k], xm);
+    X.xm[lane] = xm;
+    put_x(m, xm);
+  }
+  mt_wave_sync();
+  if (wave == 0 && lane < 32) {   // lanes 0..15: q1, lanes 16..31: q3
+    const int which = lane >> 4, c = lane & 15, jq = which ? q3 : q1;
+    const double* Pg = blk + (size_t)jq * 3 * 256;   // Qm (towards m), then QL
+    double x = vec[(size_t)jq * 16 + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x = fma(-Pg[k * 16 + c], X.xm[k], fma(-Pg[256 + k * 16 + c], X.xL[k], x));
+    X.xq[which][c] = x;
+    if (c < kMtNv) dw[(size_t)jq * kMtNv + c] = x;
+    else dy[(size_t)jq * kMtNe + c - kMtNv] = x;
+  }
+  __syncthreads();
+  // a'_j = a_j - Q_j' x_target for the nodes of this wave's front, four nodes at a time
+  {
+    double xt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xt[k] = wave < 2 ? X.xL[k] : X.xm[k];
+    const int j_lo = asc ? first : first - (cnt - 1), j_hi = j_lo + cnt;
+    for (int j0 = j_lo; j0 < j_hi; j0 += 4) {
+      const int j = j0 + q;
+      if (j < j_hi) {
+        const double* Qg = blk + (size_t)j * 3 * 256 + 256;
+        double acc = vec[(size_t)j * 16 + i];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(-Qg[k * 16 + i], xt[k], acc);
+        blk[(size_t)j * 3 * 256 + 512 + i] = acc;
+      }
+    }
+  }
+  mt_wave_sync();
+  // the chains run from the meeting node back to the front's first node: x_j = a'_j - P_j' x_(next node of the front)
+  double (*xs)[16] = X.xs[wave];
+  const int steps = cnt;
+  auto chain_node = [&](int s_) { return node(cnt - 1 - s_); };
+  double pb[4][17];
+  auto fetch = [&](double (&dst)[17], int s_) {
+    if (s_ < steps && lane < 16) {
+      const double* Bn = blk + (size_t)chain_node(s_) * 3 * 256;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dst[k] = Bn[k * 16 + lane];
+      dst[16] = Bn[512 + lane];
+    }
+  };
+  fetch(pb[0], 0); fetch(pb[1], 1); fetch(pb[2], 2);
+  if (lane < 16) xs[0][lane] = X.xq[(wave == 0 || wave == 2) ? 0 : 1][lane];
+  mt_wave_sync();
+  int cur = 0;
+  for (int s0 = 0; s0 < steps; s0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s_ = s0 + u;
+      if (s_ >= steps) break;
+      fetch(pb[(u + 3) & 3], s_ + 3);
+      if (lane < 16) {
+        double x0 = pb[u][16], x1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) { x0 = fma(-pb[u][k], xs[cur][k], x0); x1 = fma(-pb[u][k + 1], xs[cur][k + 1], x1); }
+        const double x = x0 + x1;
+        put_x(chain_node(s_), x);
+        xs[cur ^ 1][lane] = x;
+      }
+      mt_wave_sync();
+      cur ^= 1;
+    }
+  }
+}
+
 // residuals only (final report of the instances that ran into the iteration limit)
 __global__ void __launch_bounds__(64) k_mt_residuals(MtProblem P, MtState st) {
   const int b = blockIdx.x, lane = threadIdx.x, N = P.N;

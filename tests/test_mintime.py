@@ -165,6 +165,33 @@ def test_fused_node_kernel_vs_separate_assembly_kernels(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spacing", [8.0, 5.0, 3.0])
+def test_four_front_vs_two_front_elimination(tmp_path, spacing):
+    """k_mt_kkt4 (four fronts per instance, the default for N >= 64) against k_mt_kkt (two fronts, RL_MT_KKT4=0): the same
+    block factorisation in another elimination order -- equal refactorisation decisions (inertia), iterates equal to rounding
+    after 12 iterations, for node counts that put the cuts q1, m, q3 at different parities."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = {}
+    for mode in ("0", "1"):
+        f = str(tmp_path / f"k4_{mode}.npz")
+        env = dict(os.environ, RL_MT_KKT4=mode)
+        subprocess.run([sys.executable, os.path.join(here, "mintime_run.py"), f, "12", str(spacing)], check=True, env=env, timeout=300)
+        out[mode] = np.load(f)
+    a, b = out["1"], out["0"]
+    N = a["X"].shape[1]
+    su = np.maximum(np.abs(b["U"]).max(axis=(0, 1)), 1.0)
+    dev = max(np.abs(a["X"] - b["X"]).max(), np.abs(a["T"] - b["T"]).max(), np.abs((a["U"] - b["U"]) / su).max())
+    print(f"four vs two fronts, N = {N}: max deviation after 12 iterations {dev:.2e}, kkt {a['st'][0, 1]:.6e} / {b['st'][0, 1]:.6e}, "
+          f"refactorisations {a['st'][0, 9]:.0f} / {b['st'][0, 9]:.0f}")
+    assert N >= 64 and a["st"][0, 0] == b["st"][0, 0] == 12.0
+    assert a["st"][0, 9] == b["st"][0, 9]
+    assert dev <= 1e-8, dev
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("spacing", [31.0, 22.0, 13.0, 5.0])
 def test_fused_node_kernel_tails(tmp_path, spacing):
     """Node counts that leave partial runs / blocks in every kernel of the default path (runs of 9 pairs in k_mt_node, blocks of
