@@ -226,9 +226,10 @@ def mintime_leg(B, with_cpu):
                 "flops_per_instance": flops_inst, "flops_per_instance_iteration_node": flops_inst / leg["iterations_mean"] / nodes,
                 "flops_source": c["source"], "measured_in_run": False,
                 "mfma_f64_share_of_flops": c.get("fp64_flops_mfma_share"), "mfma_f64_peak_tflops": MFMA_F64_PEAK_GFLOPS / 1e3,
-                "dependent_chain": "k_mt_kkt eliminates the lap's block-tridiagonal KKT system node by node from both ends: "
-                                   f"(N-1)/2 = {(nodes - 1) // 2} sequential 16x16 block steps per call whatever the batch"
-                                   + (f"; measured {chain_us:.0f} us per call = {chain_us / ((nodes - 1) // 2):.1f} us per block step"
+                "dependent_chain": "k_mt_kkt4 eliminates the lap's block-tridiagonal KKT system node by node with four fronts (from both ends "
+                                   f"and from the middle node outwards): (N-1)/4 + 3 = {(nodes - 1) // 4 + 3} sequential 16x16 block steps per call "
+                                   "whatever the batch"
+                                   + (f"; measured {chain_us:.0f} us per call = {chain_us / ((nodes - 1) // 4 + 3):.1f} us per block step"
                                       if chain_us else "")
                                    + f" -> >= {leg['iterations_mean']:.0f} x that per solve: the floor under wall_s for small batches",
                 "actual_limiter": "FP64 VALU issue of the derivative kernels (transcendental / division sequences of the tyre model) "
