@@ -1164,6 +1164,7 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
   st.dblk = ar.take<double>(counts[12]); st.eblk = ar.take<double>(counts[13]); st.rhs = ar.take<double>(counts[14]);
   st.filt = ar.take<double>(counts[15]); st.hw = ar.take<double>(counts[16]); st.r1 = ar.take<double>(counts[17]); st.gc = ar.take<double>(counts[18]);
   st.tol = tol;
+
   double mt_mu0, mt_delta0;
   {
     // Strategy constants of the line search / barrier update.  Measured on 1024 width-perturbed MGKT tracks
@@ -1256,12 +1257,12 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
     for (int g = 0; g < ngrp; ++g) {
       const Grp& G = grp[g];
       const dim3 gn((N + 63) / 64, G.nb);
-      hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, G.q, G.P, G.st);
       if (ctx->mt_hes_sweep) {   // cross-check: forward (over forward) duals through the whole pair function
+        hipLaunchKernelGGL(rl::k_mt_derivs<0>, gn, bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_derivs<1>, dim3((N + 63) / 64, G.nb, rl::kMtJacSlices), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_derivs<2>, dim3((N + 63) / 64, G.nb, rl::kMtHesSlices), bn64, 0, G.q, G.P, G.st);
       } else {
-        hipLaunchKernelGGL(rl::k_mt_hes_values, gn, bn64, 0, G.q, G.P, G.st);
+        hipLaunchKernelGGL(rl::k_mt_values, gn, bn64, 0, G.q, G.P, G.st);   // functions; values of the dynamics at the two ends -> midpoint
         hipLaunchKernelGGL(rl::k_mt_jac_dirs, dim3((N + rl::kMtJacNodes - 1) / rl::kMtJacNodes, G.nb, 3), bn64, 0, G.q, G.P, G.st);
         if (ctx->mt_unfused) hipLaunchKernelGGL(rl::k_mt_jac_assemble, dim3(N, G.nb), bn64, 0, G.q, G.P, G.st);
         hipLaunchKernelGGL(rl::k_mt_hes_point<0>, dim3(rl::mt_hes_blocks(N), G.nb, 1), bn64, 0, G.q, G.P, G.st);
@@ -1281,10 +1282,8 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       if (ctx->mt_kkt4 && N >= 64) hipLaunchKernelGGL(rl::k_mt_kkt4, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
       else hipLaunchKernelGGL(rl::k_mt_kkt, dim3(G.nb), dim3(128), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_dir, dim3(rl::kMtDirBlocks(N), G.nb), bn64, 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_step_red, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_trial, gn, bn64, 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_step_fin, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
-      hipLaunchKernelGGL(rl::k_mt_step_back, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_step, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
     }
     if (ctx->mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
       const int chunk = it >> 3, slot = chunk & 1;

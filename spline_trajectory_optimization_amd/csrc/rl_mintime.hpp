@@ -14,23 +14,23 @@
 //   17 inequalities tyre ellipses (4), power, v >= 1, force / steer limits, force / steer RATE limits
 //       (two rows each), lateral limits, t >= 0                                   g_j(w_j, w_j+1) + s_j = 0, s_j > 0
 //
-//   every iteration:  k_mt_derivs<0>, k_mt_hes_values   functions; values of the dynamics at the two ends -> midpoint
+//   every iteration:  k_mt_values   functions; values of the dynamics at the two ends -> midpoint
 //                     k_mt_jac_dirs   Jacobians of the three dynamics evaluations of a pair (forward duals)
 //                     k_mt_hes_point  the EXACT Hessians of the weighted dynamics at the midpoint and the ends (forward over
 //                                   forward duals; the pairs with the lateral offset / heading in closed form)
 //                     k_mt_node     chain rule through the Hermite-Simpson midpoint: Jacobian and Hessian of the pair, the
 //                                   16 x 16 diagonal / coupling blocks and the right-hand side, in one pass over runs of pairs
 //                     k_mt_prepare2 convergence test, barrier update, rhs = rhs0 - mu r1
-//                     k_mt_kkt      the barrier QP  [K  A'; A  -eps I] [dw; dy] = rhs  with
+//                     k_mt_kkt4     the barrier QP  [K  A'; A  -eps I] [dw; dy] = rhs  with
 //                                   K = H_cost + Hess + G' S^-1 Z G + delta I: block tridiagonal and CYCLIC
 //                                   (closed lap), 16 x 16 blocks (9 unknowns + 7 multipliers per node),
-//                                   factorised node by node from both ends (block LDL' without pivoting; the lap closure
+//                                   factorised node by node by four fronts (block LDL' without pivoting; the lap closure
 //                                   is a border block row carried along); the count of negative pivots
 //                                   (7 N of 16 N) is the inertia test that drives delta
-//                     k_mt_dir, k_mt_step_red, k_mt_trial, k_mt_step_fin, k_mt_step_back
+//                     k_mt_dir, k_mt_trial, k_mt_step
 //                                   fraction-to-the-boundary rule, backtracking on (infeasibility, barrier
 //                                   objective) with a small filter, update of w, s, y, z, delta
-//   Two waves per instance in k_mt_kkt (every 16 x 16 block lives in registers, 4 entries per lane, in the
+//   Four waves per instance in k_mt_kkt4 (two in k_mt_kkt, its cross-check and the kernel of short laps; every 16 x 16 block lives in registers, 4 entries per lane, in the
 //   operand layout of v_mfma_f64_16x16x4_f64: the block products run on the matrix cores, the block
 //   inverse on cross-lane moves); everything else is node- or row-parallel over the whole batch, and one workgroup per
 //   instance only takes decisions.  (k_mt_derivs<1/2>, k_mt_jac_assemble, k_mt_hes_assemble, k_mt_prepare, k_mt_assemble:
@@ -388,10 +388,9 @@ __device__ __forceinline__ S mt_own_rows(const MtProblem& P, const S (&Y)[5], co
   return L;
 }
 
-// grid (node blocks, B): values of the two end evaluations -> midpoint and F1 - F2
-__global__ void __launch_bounds__(64) k_mt_hes_values(MtProblem P, MtState st) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
-  if (j >= N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+// values of the two end evaluations -> midpoint and F1 - F2
+__device__ __forceinline__ void mt_hes_values_body(const MtProblem& P, const MtState& st, int b, int j) {
+  const int N = P.N;
   const int jn = j + 1 == N ? 0 : j + 1;
   double Y[5], Yn[5], U[3], t;
   mt_phys(P, st.w + ((size_t)b * N + j) * kMtNv, st.w + ((size_t)b * N + jn) * kMtNv, Y, Yn, U, t);
@@ -410,6 +409,35 @@ __global__ void __launch_bounds__(64) k_mt_hes_values(MtProblem P, MtState st) {
   }
 #pragma unroll
   for (int c = 0; c < 6; ++c) { hw[kMtHwF + c] = f1[c]; hw[kMtHwF + 6 + c] = f2[c]; }
+}
+// functions eq, g of the pair at the current point -> st.fun
+__device__ __forceinline__ void mt_fun_body(MtProblem P, const MtState& st, int b, int j) {
+  mt_instance(P, b);
+  const int N = P.N, jn = j + 1 == N ? 0 : j + 1;
+  const double* wo_ = st.w + ((size_t)b * N + j) * kMtNv;
+  const double* wn_ = st.w + ((size_t)b * N + jn) * kMtNv;
+  const size_t o = (size_t)b * N + j;
+  double wo[kMtNv], wn[kMtNv], eq[kMtNe], g[kMtNi];
+#pragma unroll
+  for (int a = 0; a < kMtNv; ++a) { wo[a] = wo_[a]; wn[a] = wn_[a]; }
+  mt_pair<double>(P, j, wo, wn, eq, g);
+#pragma unroll
+  for (int c = 0; c < kMtNe; ++c) st.fun[o * kMtNf + c] = eq[c];
+#pragma unroll
+  for (int c = 0; c < kMtNi; ++c) st.fun[o * kMtNf + kMtNe + c] = g[c];
+}
+// grid (node blocks, B): values of the two end evaluations -> midpoint and F1 - F2
+__global__ void __launch_bounds__(64) k_mt_hes_values(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j >= P.N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  mt_hes_values_body(P, st, b, j);
+}
+// grid (node blocks, B): both of the above in one launch (the first kernel of an iteration of the default path)
+__global__ void __launch_bounds__(64) k_mt_values(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j >= P.N || st.scal[(size_t)b * 16 + 5] != 0.0) return;
+  mt_fun_body(P, st, b, j);
+  mt_hes_values_body(P, st, b, j);
 }
 
 // the curved rows of this node that depend on (Y, U) only, one by one (row order: eq 6, g 0..3, g 4)
@@ -1300,6 +1328,78 @@ __global__ void __launch_bounds__(64) k_mt_node(MtProblem P, MtState st) {
   }
 }
 
+template <int BLOCK>
+__device__ __forceinline__ double mt_block_reduce(double v, double* red, int op /*0 sum, 1 min*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = op == 0 ? wave_sum(v) : wave_min(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int q = 1; q < BLOCK / 64; ++q) r = op == 0 ? r + red[q] : fmin(r, red[q]);
+  __syncthreads();
+  return r;
+}
+
+// k_mt_prepare2 (one workgroup per instance, after k_mt_node): convergence test and barrier update as k_mt_prepare (the stationarity
+// residual comes per node from k_mt_node), then the right-hand side rhs = rhs0 - mu r1.  (Measured: as a prologue of the elimination
+// kernel instead of a kernel of its own it is 1.5 % faster for 1024 instances and 13 % slower for 256: a kernel of its own.)
+template <int BLOCK>
+__device__ __forceinline__ bool mt_prepare2(const MtProblem& P, const MtState& st, int b, int tid, double* red) {
+  const int N = P.N;
+  double* scal = st.scal + (size_t)b * 16;
+  const double* w = st.w + (size_t)b * N * kMtNv;
+  const double* sv = st.s + (size_t)b * N * kMtNi;
+  const double* zv = st.z + (size_t)b * N * kMtNi;
+  const double* fun = st.fun + (size_t)b * N * kMtNf;
+  const double* r1 = st.r1 + (size_t)b * N * 16;
+  double* rhs = st.rhs + (size_t)b * N * 16;
+  double mu = scal[0];
+  double kkt = 0.0, viol = 0.0, compl_ = 0.0, errmu = 0.0, lap = 0.0;
+  for (int j = tid; j < N; j += BLOCK) {
+    kkt = fmax(kkt, r1[(size_t)j * 16 + kMtNv]);
+    lap += w[(size_t)j * kMtNv + 8] * P.sw[8];
+  }
+  for (int idx = tid; idx < N * kMtNe; idx += BLOCK) {
+    const int j = idx / kMtNe, c = idx - j * kMtNe;
+    viol = fmax(viol, fabs(fun[j * kMtNf + c]));
+  }
+  for (int idx = tid; idx < N * kMtNi; idx += BLOCK) {
+    const int j = idx / kMtNi, c = idx - j * kMtNi;
+    const double s_ = sv[idx], z_ = zv[idx];
+    viol = fmax(viol, fabs(fun[j * kMtNf + kMtNe + c] + s_));
+    compl_ = fmax(compl_, s_ * z_);
+    errmu = fmax(errmu, fabs(s_ * z_ - mu));
+  }
+  kkt = -mt_block_reduce<BLOCK>(-kkt, red, 1); viol = -mt_block_reduce<BLOCK>(-viol, red, 1);
+  compl_ = -mt_block_reduce<BLOCK>(-compl_, red, 1); errmu = -mt_block_reduce<BLOCK>(-errmu, red, 1);
+  lap = mt_block_reduce<BLOCK>(lap, red, 0);
+  if (tid == 0) { scal[2] = kkt; scal[3] = viol; scal[4] = compl_; scal[11] = lap; }
+  if (fmax(kkt, fmax(viol, compl_)) <= st.tol) {
+    if (tid == 0) scal[5] = 1.0;
+    return true;
+  }
+  if (fmax(fmax(kkt, viol), errmu) <= st.mu_kappa * mu) {
+    const double mu_new = fmax(fmin(st.mu_fac * mu, pow(mu, st.mu_pow)), st.tol / 10.0);
+    if (mu_new != mu && tid == 0) scal[14] = 0.0;
+    mu = mu_new;
+  }
+  if (tid == 0) scal[0] = mu;
+  for (int idx = tid; idx < N * kMtNv; idx += BLOCK) {
+    const int j = idx / kMtNv, a = idx - j * kMtNv;
+    rhs[(size_t)j * 16 + a] = fma(-mu, r1[(size_t)j * 16 + a], rhs[(size_t)j * 16 + a]);
+  }
+  __syncthreads();
+  return false;
+}
+
+
+__global__ void __launch_bounds__(256) k_mt_prepare2(MtProblem P, MtState st) {
+  __shared__ double red[8];
+  if (st.scal[(size_t)blockIdx.x * 16 + 5] != 0.0) return;
+  (void)mt_prepare2<256>(P, st, blockIdx.x, threadIdx.x, red);
+}
+
 // k_mt_kkt: two waves per instance: block elimination of the cyclic block-tridiagonal KKT system from the
 // assembled blocks (retry with a larger delta until the inertia is right), solution dw, dy.
 //
@@ -1843,77 +1943,15 @@ __global__ void __launch_bounds__(64) k_mt_residuals(MtProblem P, MtState st) {
 
 // ------------------------------------------------------------------------------------------------
 // the step: helpers
-template <int BLOCK>
-__device__ __forceinline__ double mt_block_reduce(double v, double* red, int op /*0 sum, 1 min*/) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v = op == 0 ? wave_sum(v) : wave_min(v);
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  double r = red[0];
-  for (int q = 1; q < BLOCK / 64; ++q) r = op == 0 ? r + red[q] : fmin(r, red[q]);
-  __syncthreads();
-  return r;
-}
 
-// k_mt_prepare2: one workgroup per instance, after k_mt_node: convergence test and barrier update as k_mt_prepare
-// (the stationarity residual comes per node from k_mt_node), then the right-hand side rhs = rhs0 - mu r1
-__global__ void __launch_bounds__(256) k_mt_prepare2(MtProblem P, MtState st) {
-  __shared__ double red[8];
-  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
-  double* scal = st.scal + (size_t)b * 16;
-  if (scal[5] != 0.0) return;
-  const double* w = st.w + (size_t)b * N * kMtNv;
-  const double* sv = st.s + (size_t)b * N * kMtNi;
-  const double* zv = st.z + (size_t)b * N * kMtNi;
-  const double* fun = st.fun + (size_t)b * N * kMtNf;
-  const double* r1 = st.r1 + (size_t)b * N * 16;
-  double* rhs = st.rhs + (size_t)b * N * 16;
-  double mu = scal[0];
-  double kkt = 0.0, viol = 0.0, compl_ = 0.0, errmu = 0.0, lap = 0.0;
-  for (int j = tid; j < N; j += 256) {
-    kkt = fmax(kkt, r1[(size_t)j * 16 + kMtNv]);
-    lap += w[(size_t)j * kMtNv + 8] * P.sw[8];
-  }
-  for (int idx = tid; idx < N * kMtNe; idx += 256) {
-    const int j = idx / kMtNe, c = idx - j * kMtNe;
-    viol = fmax(viol, fabs(fun[j * kMtNf + c]));
-  }
-  for (int idx = tid; idx < N * kMtNi; idx += 256) {
-    const int j = idx / kMtNi, c = idx - j * kMtNi;
-    const double s_ = sv[idx], z_ = zv[idx];
-    viol = fmax(viol, fabs(fun[j * kMtNf + kMtNe + c] + s_));
-    compl_ = fmax(compl_, s_ * z_);
-    errmu = fmax(errmu, fabs(s_ * z_ - mu));
-  }
-  kkt = -mt_block_reduce<256>(-kkt, red, 1); viol = -mt_block_reduce<256>(-viol, red, 1);
-  compl_ = -mt_block_reduce<256>(-compl_, red, 1); errmu = -mt_block_reduce<256>(-errmu, red, 1);
-  lap = mt_block_reduce<256>(lap, red, 0);
-  if (tid == 0) { scal[2] = kkt; scal[3] = viol; scal[4] = compl_; scal[11] = lap; }
-  if (fmax(kkt, fmax(viol, compl_)) <= st.tol) {
-    if (tid == 0) scal[5] = 1.0;
-    return;
-  }
-  if (fmax(fmax(kkt, viol), errmu) <= st.mu_kappa * mu) {
-    const double mu_new = fmax(fmin(st.mu_fac * mu, pow(mu, st.mu_pow)), st.tol / 10.0);
-    if (mu_new != mu && tid == 0) scal[14] = 0.0;
-    mu = mu_new;
-  }
-  if (tid == 0) scal[0] = mu;
-  for (int idx = tid; idx < N * kMtNv; idx += 256) {
-    const int j = idx / kMtNv, a = idx - j * kMtNv;
-    rhs[(size_t)j * 16 + a] = fma(-mu, r1[(size_t)j * 16 + a], rhs[(size_t)j * 16 + a]);
-  }
-}
-
-// The step in four kernels (it was one workgroup per instance that evaluated the trial points itself: 395 registers, one
-// workgroup per CU, 1.33 rounds for a sub-batch of 341 instances and nothing else resident beside it):
-//   k_mt_dir         per inequality ROW, all instances: ds, dz, the wave's share of the step lengths and of (theta0, phi0)
-//   k_mt_step_red    per instance: the fraction-to-the-boundary lengths ap, ad and (theta0, phi0) of the current point
-//   k_mt_trial       per NODE, all instances: the trial points w + a dw, a = ap, ap / 2, ap / 4 -> the node's shares of (theta, phi)
-//   k_mt_step_fin    per instance: the first acceptable of the three (72 / 18 / 7 % of the steps of the benchmark batch) -> the update
-//   k_mt_step_back   per instance, only where all three were rejected (3 %): further halvings, each evaluated in the kernel
-// scal: 12 ap, 15 ad, 8 theta0, 9 phi0; 7 = -1 marks "no trial accepted yet" between the last two kernels.
+// The step in three kernels (it was one workgroup per instance that evaluated the trial points itself: 395 registers, one
+// workgroup per CU and nothing else resident beside it):
+//   k_mt_dir    per inequality ROW, all instances: ds, dz, the wave's share of the step lengths and of (theta0, phi0)
+//   k_mt_trial  per NODE, all instances: the trial points w + a dw, a = ap, ap / 2, ap / 4 -> the node's shares of (theta, phi)
+//   k_mt_step   per instance: ap, ad, (theta0, phi0); the first acceptable of the three trial points (72 / 18 / 7 % of the steps of
+//               the benchmark batch), further halvings evaluated in the kernel where all three were rejected (3 %); the update
+// (Per-instance kernels wait for a slot behind the other sub-batches' node-parallel grids: the fewer of them in the chain of an
+//  iteration the better -- k_mt_step_red, k_mt_step_fin and k_mt_step_back were separate until they showed as 14 % of the streams' time.)
 struct MtStepPtrs {
   double *w, *sv, *yv, *zv, *ds, *dz, *scal, *filt;
   const double *dw, *dy;
@@ -1956,8 +1994,9 @@ __device__ __forceinline__ bool mt_accept(const MtState& st, const double* filt,
 }
 
 // the accepted step of length a (after `halvings` halvings of ap): iterate, damping, filter, bookkeeping
-__device__ __forceinline__ void mt_take_step(const MtState& st, const MtStepPtrs& q, int N, int tid, double a, int halvings) {
-  const double mu = q.scal[0], ap = q.scal[12], ad = q.scal[15], theta0 = q.scal[8], phi0 = q.scal[9];
+__device__ __forceinline__ void mt_take_step(const MtState& st, const MtStepPtrs& q, int N, int tid, double a, int halvings,
+                                             double ap, double ad, double theta0, double phi0) {
+  const double mu = q.scal[0];
   const int nfilt_total = (int)q.scal[14];
   const double az = st.dual_cap > 0.0 ? fmin(fmin(ad, 1.0), fmax(st.dual_cap * a, 1e-3)) : fmin(ad, 1.0);
   for (int idx = tid; idx < N * kMtNv; idx += 256) q.w[idx] += a * q.dw[idx];
@@ -1972,7 +2011,7 @@ __device__ __forceinline__ void mt_take_step(const MtState& st, const MtStepPtrs
   delta = fmin(fmax(delta * (a > st.a_hi ? st.d_down : (a > st.a_lo ? 1.0 : st.d_up)), 1e-6), 1e3);
   __syncthreads();   // everybody has read scal
   if (tid == 0) {
-    q.scal[1] = delta; q.scal[7] = a; q.scal[6] += 1.0; q.scal[12] = ap; q.scal[13] = (double)halvings;
+    q.scal[1] = delta; q.scal[7] = a; q.scal[6] += 1.0; q.scal[8] = theta0; q.scal[9] = phi0; q.scal[12] = ap; q.scal[13] = (double)halvings;
     const int slot = nfilt_total % kMtFilter;   // the point just left joins the filter
     q.filt[2 * slot] = theta0; q.filt[2 * slot + 1] = phi0;
     q.scal[14] = (double)(nfilt_total + 1);
@@ -1980,7 +2019,7 @@ __device__ __forceinline__ void mt_take_step(const MtState& st, const MtStepPtrs
 }
 
 // grid (blocks of 64 rows, B): one inequality row per thread: ds = -r_g - G dw, dz = -(s z - mu + z ds) / s, and the wave's
-// share of (ap, ad, theta0, phi0) -> part[b][block][4]  (part = the elimination's vec scratch, dead by now: [B,N,16] >= 4 blocks)
+// share of (ap, ad, theta0, phi0) -> part[b][block][4]  (part = the start of the instance's derivative work array hw, dead after k_mt_node)
 constexpr int kMtDirBlocks(int N) { return (N * kMtNi + 63) / 64; }
 __global__ void __launch_bounds__(64) k_mt_dir(MtProblem P, MtState st) {
   const int b = blockIdx.y, N = P.N, idx = blockIdx.x * 64 + threadIdx.x;
@@ -2018,37 +2057,9 @@ __global__ void __launch_bounds__(64) k_mt_dir(MtProblem P, MtState st) {
   }
   ap = wave_min(ap); ad = wave_min(ad); th = wave_sum(th); ph = wave_sum(ph);
   if (threadIdx.x == 0) {
-    double* o = st.vec + (size_t)b * N * 16 + (size_t)blockIdx.x * 4;
+    double* o = st.hw + (size_t)b * N * kMtHw + (size_t)blockIdx.x * 4;
     o[0] = ap; o[1] = ad; o[2] = th; o[3] = ph;
   }
-}
-
-// per instance: the step lengths and (theta0, phi0) of the current point from the shares of k_mt_dir
-__global__ void __launch_bounds__(256) k_mt_step_red(MtProblem P, MtState st) {
-  __shared__ double red[8];
-  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
-  const MtStepPtrs q = mt_step_ptrs(st, b, N);
-  if (q.scal[5] != 0.0) return;
-  const double* fun = st.fun + (size_t)b * N * kMtNf;
-  const double* part = st.vec + (size_t)b * N * 16;
-  double ap = 1.0, ad = 1.0, theta0 = 0.0, phi0 = 0.0;
-  for (int k = tid; k < kMtDirBlocks(N); k += 256) {
-    ap = fmin(ap, part[4 * k]); ad = fmin(ad, part[4 * k + 1]); theta0 += part[4 * k + 2]; phi0 += part[4 * k + 3];
-  }
-  for (int idx = tid; idx < N * kMtNe; idx += 256) {
-    const int j = idx / kMtNe, c = idx - j * kMtNe;
-    theta0 += fabs(fun[j * kMtNf + c]);
-  }
-  for (int idx = tid; idx < N; idx += 256) {
-    const double* wj = q.w + (size_t)idx * kMtNv;
-    const double* wn = q.w + (size_t)(idx + 1 == N ? 0 : idx + 1) * kMtNv;
-    double c = wj[8];
-    for (int a = 5; a < 8; ++a) c += 1e-4 * wj[a] * wj[a] + 1e-1 * (wn[a] - wj[a]) * (wn[a] - wj[a]);
-    phi0 += c;
-  }
-  ap = mt_block_reduce<256>(ap, red, 1); ad = mt_block_reduce<256>(ad, red, 1);
-  theta0 = mt_block_reduce<256>(theta0, red, 0); phi0 = mt_block_reduce<256>(phi0, red, 0);
-  if (tid == 0) { q.scal[12] = ap; q.scal[15] = ad; q.scal[8] = theta0; q.scal[9] = phi0; }
 }
 
 // (theta, phi) share of the pair j at the trial point w + a dw, s + a ds
@@ -2082,10 +2093,18 @@ constexpr int kMtTrials = 3;
 __global__ void __launch_bounds__(64) k_mt_trial(MtProblem P, MtState st) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
   const MtStepPtrs q = mt_step_ptrs(st, b, N);
-  if (j >= N || q.scal[5] != 0.0) return;
+  if (q.scal[5] != 0.0) return;
+  // the primal step length: every workgroup takes the minimum over the shares of k_mt_dir itself (220 values; a minimum does not depend on the order)
+  double ap = 1.0;
+  {
+    const double* part = st.hw + (size_t)b * N * kMtHw;
+    for (int k = threadIdx.x; k < kMtDirBlocks(N); k += 64) ap = fmin(ap, part[4 * k]);
+    ap = wave_min(ap);
+  }
+  if (j >= N) return;
   mt_instance(P, b);
   double* o = st.vec + ((size_t)b * N + j) * 16;
-  double a = q.scal[12];
+  double a = ap;
   const double mu = q.scal[0];
   for (int k = 0; k < kMtTrials; ++k) {
     double theta = 0.0, phi = 0.0;
@@ -2095,11 +2114,36 @@ __global__ void __launch_bounds__(64) k_mt_trial(MtProblem P, MtState st) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_mt_step_fin(MtProblem P, MtState st) {
+__global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
   __shared__ double red[8];
   const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
   const MtStepPtrs q = mt_step_ptrs(st, b, N);
   if (q.scal[5] != 0.0) return;
+  mt_instance(P, b);
+  const double mu = q.scal[0];
+  // ---- the step lengths and (theta0, phi0) of the current point from the shares of k_mt_dir
+  double ap = 1.0, ad = 1.0, theta0 = 0.0, phi0 = 0.0;
+  {
+    const double* fun = st.fun + (size_t)b * N * kMtNf;
+    const double* part = st.hw + (size_t)b * N * kMtHw;
+    for (int k = tid; k < kMtDirBlocks(N); k += 256) {
+      ap = fmin(ap, part[4 * k]); ad = fmin(ad, part[4 * k + 1]); theta0 += part[4 * k + 2]; phi0 += part[4 * k + 3];
+    }
+    for (int idx = tid; idx < N * kMtNe; idx += 256) {
+      const int j = idx / kMtNe, c = idx - j * kMtNe;
+      theta0 += fabs(fun[j * kMtNf + c]);
+    }
+    for (int idx = tid; idx < N; idx += 256) {
+      const double* wj = q.w + (size_t)idx * kMtNv;
+      const double* wn = q.w + (size_t)(idx + 1 == N ? 0 : idx + 1) * kMtNv;
+      double c = wj[8];
+      for (int a = 5; a < 8; ++a) c += 1e-4 * wj[a] * wj[a] + 1e-1 * (wn[a] - wj[a]) * (wn[a] - wj[a]);
+      phi0 += c;
+    }
+    ap = mt_block_reduce<256>(ap, red, 1); ad = mt_block_reduce<256>(ad, red, 1);
+    theta0 = mt_block_reduce<256>(theta0, red, 0); phi0 = mt_block_reduce<256>(phi0, red, 0);
+  }
+  // ---- the trial points of k_mt_trial: the first acceptable one
   const double* tp = st.vec + (size_t)b * N * 16;
   double th[kMtTrials], ph[kMtTrials];
 #pragma unroll
@@ -2111,44 +2155,24 @@ __global__ void __launch_bounds__(256) k_mt_step_fin(MtProblem P, MtState st) {
 #pragma unroll
   for (int k = 0; k < kMtTrials; ++k) { th[k] = mt_block_reduce<256>(th[k], red, 0); ph[k] = mt_block_reduce<256>(ph[k], red, 0); }
   const int nfilt_total = (int)q.scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
-  double a = q.scal[12];
+  double a = ap;
   int taken = -1;
 #pragma unroll
   for (int k = 0; k < kMtTrials; ++k) {
     if (taken < 0) {
-      if (mt_accept(st, q.filt, nfilt, N, th[k], ph[k], q.scal[8], q.scal[9])) taken = k;
+      if (mt_accept(st, q.filt, nfilt, N, th[k], ph[k], theta0, phi0)) taken = k;
       else a *= 0.5;
     }
   }
-  if (taken >= 0) {
-    RL_MT_COUNT(taken);
-    mt_take_step(st, q, N, tid, a, taken);
-  } else {
-    __syncthreads();
-    if (tid == 0) q.scal[7] = -1.0;
-  }
-}
-
-__global__ void __launch_bounds__(256, 2) k_mt_step_back(MtProblem P, MtState st) {
-  __shared__ double red[8];
-  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
-  const MtStepPtrs q = mt_step_ptrs(st, b, N);
-  if (q.scal[5] != 0.0 || q.scal[7] != -1.0) return;
-  mt_instance(P, b);
-  const double mu = q.scal[0], theta0 = q.scal[8], phi0 = q.scal[9];
-  const int nfilt_total = (int)q.scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
-  double a = q.scal[12];
-  for (int k = 1; k < kMtTrials; ++k) a *= 0.5;
-  bool ok = false;
-  int halvings = 0;
-  for (int trial = kMtTrials; trial < 12; ++trial) {
-    a *= 0.5;
+  // ---- all three rejected (3 % of the steps of the benchmark batch): further halvings, evaluated here
+  for (int trial = kMtTrials; trial < 12 && taken < 0; ++trial) {
     double theta = 0.0, phi = 0.0;
     for (int j = tid; j < N; j += 256) mt_trial_node(P, q, N, j, a, mu, theta, phi);
     theta = mt_block_reduce<256>(theta, red, 0); phi = mt_block_reduce<256>(phi, red, 0);
-    if (mt_accept(st, q.filt, nfilt, N, theta, phi, theta0, phi0)) { ok = true; halvings = trial; break; }
+    if (mt_accept(st, q.filt, nfilt, N, theta, phi, theta0, phi0)) taken = trial;
+    else a *= 0.5;
   }
-  if (!ok) {
+  if (taken < 0) {
     // no acceptable step: more damping, same point (the next iteration re-solves with the larger delta)
     const double delta = fmax(10.0 * q.scal[1], 1e-4);
     __syncthreads();
@@ -2156,8 +2180,8 @@ __global__ void __launch_bounds__(256, 2) k_mt_step_back(MtProblem P, MtState st
     RL_MT_COUNT(12);
     return;
   }
-  RL_MT_COUNT(halvings);
-  mt_take_step(st, q, N, tid, a, halvings);
+  RL_MT_COUNT(taken);
+  mt_take_step(st, q, N, tid, a, taken, ap, ad, theta0, phi0);
 }
 
 // physical X [B,N,6], U [B,N,4], T [B,N]  <->  scaled unknowns w [B,N,9]
