@@ -128,18 +128,40 @@ def cpu_legs(groups, i_starts, xy_gpu, ninst_total):
         except Exception:
             probe[mod] = False
     gv = parity_rule.summary(c)
-    gv["rule"] = ("per instance: dev = max|GPU - strict oracle| <= 1e-4 m, or the oracle's own re-roundings (FMA "
-                  "contraction; +-1 ulp on sampled positions / bound points) spread by > 1e-4 m on that instance and "
-                  "dev <= 10x that spread (tests/parity_rule.py)")
+    gv["rule"] = ("NEAREST BRANCH, per instance: max|GPU - strict oracle| <= 1e-4 m, or max|GPU - oracle_r| <= 1e-4 m for one "
+                  "of the oracle's re-roundings r (FMA build; up to 24 seeded +-1 ulp re-roundings of sampled positions / bound "
+                  "points) -- no multiple of a spread is accepted (tests/parity_rule.py)")
+    gv["per_instance"] = [{"instance": int(b), "dev_m": float(c["dev"][b]), "nearest_branch_dev_m": float(c["nearest"][b]),
+                           "branch": c["branch"][b], "oracle_rerounding_spread_m": float(c["noise"][b])} for b in range(len(c["dev"]))]
     cb = {"value": done / t_wall, "unit": "solves/s", "cores": cores, "kind": "port",
           "sample": f"{done} of the batch's instances (N={N_WAYPOINTS}, max_iter={MAX_ITER}), one per thread, "
                     f"{t_wall:.1f} s wall",
           "reference_path_probe": dict(probe, note="the reference's own CasADi/qpOASES + shapely path needs both "
                                        "modules and the reference tree; neither is on this box, so kind stays 'port'"),
           "gpu_vs_oracle": gv}
-    assert gv["failing"] == 0 and gv["within_1e-4"] + gv["certified_ill_conditioned"] == done, \
-        f"GPU results deviate from the oracle: {gv}"
+    ref_loop = reference_loop_time()
+    if ref_loop:
+        cb["reference_loop"] = ref_loop
     return cb
+
+
+def reference_loop_time():
+    """Wall time of the REFERENCE's own run_min_curvature_qp loop (optimizer.py:256-341) at exactly this configuration,
+    measured when fixture G7b was generated (tests/golden/make_golden.py: the reference's Python imported in the build
+    container, one core per run) and stored in the fixture -- not measured on this box (the reference cannot travel)."""
+    path = os.path.join(ROOT, "tests", "golden", "G7b_benchmarked_config.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    el = {str(k_): float(g[f"{k_}_elapsed_s"]) for k_ in g["cases"] if f"{k_}_elapsed_s" in g.files and "N2000" in str(k_)}
+    if not el:
+        return None
+    mean = float(np.mean(list(el.values())))
+    return {"value": 1.0 / mean, "unit": "solves/s", "cores": 1, "seconds_per_solve": el,
+            "where": "build container (8 vCPU, no GPU), one core per run, measured at fixture generation -- not on this box",
+            "caveat": "qpOASES and GEOS replaced by exact stand-ins (closed-form clamp, C ray-ring intersection): a LOWER "
+                      "bound on the reference's own time per solve",
+            "fixture": "tests/golden/G7b_benchmarked_config.npz"}
 
 
 def global_qp_leg(trk, d_widths, g, args, torch, with_cpu):
@@ -446,13 +468,17 @@ def run_rank(args):
             ctrl0 = last["ctrl"].cpu().numpy()
             dev_ref = {bi: float(np.hypot(ctrl0[bi, :, 0] - rc[0], ctrl0[bi, :, 1] - rc[1]).max()) for bi, rc in ref_run.items()}
 
-    # N > 1: every rank's shard of EVERY group arrived on rank 0 unchanged -- each rank publishes two checksums of what it
-    # sent (sum, sum of squares: same reduction kernel on the same shape, so equal bytes give equal sums), rank 0 recomputes
-    # them on what it received.  Outside the timed region.
+    # N > 1: every rank's shard of EVERY group arrived on rank 0 unchanged -- each rank publishes two INTEGER checksums of the
+    # bit patterns of what it sent (wrapping int64 sums: independent of the reduction order, the device and the storage
+    # offset), rank 0 recomputes them on what it received.  Outside the timed region.
+    def bit_checksums(x):
+        v = x.contiguous().view(torch.int64)
+        return torch.stack([v.sum(), torch.bitwise_xor(v, v >> 29).sum()])
+
     gather_check = None
     if world > 1:
-        chk = torch.stack([torch.stack([g["out"][last_slot]["xy"].sum(), (g["out"][last_slot]["xy"] ** 2).sum(),
-                                        g["out"][last_slot]["status"].to(torch.float64).sum()]) for g in groups])
+        chk = torch.stack([torch.cat([bit_checksums(g["out"][last_slot]["xy"]),
+                                      g["out"][last_slot]["status"].to(torch.int64).sum().reshape(1)]) for g in groups])
         all_chk = [torch.empty_like(chk) for _ in range(world)]
         dist.all_gather(all_chk, chk)
         if rank == 0:
@@ -460,12 +486,11 @@ def run_rank(args):
             for gi, g in enumerate(groups):
                 bg = g["widths"].shape[0]
                 for r in range(world):
-                    shard = gathered[last_slot][gi][r * bg:(r + 1) * bg]
-                    got = torch.stack([shard.sum(), (shard ** 2).sum()])
+                    got = bit_checksums(gathered[last_slot][gi][r * bg:(r + 1) * bg])
                     assert torch.equal(got, all_chk[r][gi, :2]), f"group {gi}: the shard of rank {r} changed in the gather"
                     n_ok += 1
-            gather_check = {"groups": len(groups), "ranks": world, "shards_equal": n_ok,
-                            "skipped_qps_per_rank": [[float(all_chk[r][gi, 2]) for gi in range(len(groups))] for r in range(world)]}
+            gather_check = {"groups": len(groups), "ranks": world, "shards_equal": n_ok, "checksum": "wrapping int64 sums of the bit patterns",
+                            "skipped_qps_per_rank": [[int(all_chk[r][gi, 2]) for gi in range(len(groups))] for r in range(world)]}
 
     if rank == 0:
         total_solves = world * B * args.steps
@@ -520,14 +545,27 @@ def run_rank(args):
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
         if ref_run:
+            per = {d_["instance"]: d_ for d_ in res.get("cpu_baseline", {}).get("gpu_vs_oracle", {}).get("per_instance", [])}
             res["gpu_vs_reference_run"] = {
                 "what": "instances of THIS batch that also exist as a run of the reference's own run_min_curvature_qp loop "
                         "(fixture tests/golden/G7b_benchmarked_config.npz: same widths bit for bit, same sweep order); "
                         "max control-point deviation [m]",
                 "instances": sorted(dev_ref), "dev_m": [dev_ref[b_] for b_ in sorted(dev_ref)],
                 "within_1e-4": int(sum(v <= 1e-4 for v in dev_ref.values())),
-                "note": "an instance outside 1e-4 m must be one the oracle's re-roundings certify as ill-conditioned "
-                        "(cpu_baseline.gpu_vs_oracle; tests/test_hip_parity.py::test_benchmarked_configuration_vs_reference_run)"}
+                "nearest_branch_dev_m": [per.get(b_, {}).get("nearest_branch_dev_m") for b_ in sorted(dev_ref)],
+                "nearest_branch": [per.get(b_, {}).get("branch") for b_ in sorted(dev_ref)],
+                "note": "an instance outside 1e-4 m of the reference's run must be within 1e-4 m of one of the oracle's re-rounding "
+                        "branches (sampled line; cpu_baseline.gpu_vs_oracle.per_instance; "
+                        "tests/test_hip_parity.py::test_benchmarked_configuration_vs_reference_run)"}
+        # headline parity block: what was compared, how many are where
+        gv_ = res.get("cpu_baseline", {}).get("gpu_vs_oracle")
+        if gv_:
+            res["parity"] = {"rule": "nearest branch <= 1e-4 m (tests/parity_rule.py)", "sample": gv_["sample"],
+                             "within_1e-4_of_strict_oracle": gv_["within_1e-4_of_strict_oracle"],
+                             "within_1e-4_of_a_rerounding_branch": gv_["within_1e-4_of_a_rerounding_branch"],
+                             "failing": gv_["failing"], "nearest_branch_dev_m_max": gv_["nearest_branch_dev_m_max"],
+                             "dev_vs_reference_run_m": res.get("gpu_vs_reference_run", {}).get("dev_m"),
+                             "ok": gv_["failing"] == 0}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -168,6 +168,21 @@ class BSplineTrajectory:
         length, _ = integrate.quad(self._speed, ts[0], ts[1], limit=1000)
         return length
 
+    def _second_over_speed(self, spl, lo, hi):
+        def f(u):
+            return interpolate.splev(u, spl, der=2) / self._speed(u)
+        value, _ = integrate.quad(f, lo, hi, limit=200)
+        return value
+
+    def eval_dx_sectional_length(self, ts):
+        """Integral of x''(u) / |r'(u)| over [ts[0], ts[1]] (reference :235-239; host quadrature like the reference's,
+        only reached from its commented-out min-time cost)."""
+        return self._second_over_speed(self._spl_x, ts[0], ts[1])
+
+    def eval_dy_sectional_length(self, ts):
+        """Integral of y''(u) / |r'(u)| over [ts[0], ts[1]] (reference :241-245)."""
+        return self._second_over_speed(self._spl_y, ts[0], ts[1])
+
     def get_length(self):
         return self._length
 

@@ -188,17 +188,65 @@ def test_sweep_golden_reference_run(rl, fits, rings):
         np.testing.assert_allclose(pts[:, 9:13], chk[:, 9:13], rtol=0, atol=1e-8)
 
 
+def test_sweep_wellconditioned_reference_runs(rl, fits, rings):
+    """Fixture G7c (round 4): run_min_curvature_qp executed by the reference's own loop on cases where the oracle's 24
+    re-roundings + FMA build agree to < 1e-6 m (max_iter = 1 and 2, N = 250 ... 500, two centre-line splines): the
+    reference's arithmetic defines the answer, so HIP must reproduce the run to 1e-4 m with equal per-pass success counts."""
+    g = golden("G7c_wellconditioned.npz")
+    for key in [str(k_) for k_ in g["cases"]]:
+        tag, Ns, _ = key.split("_")
+        N = int(Ns[1:])
+        t, cx, cy, k, length = spline(fits, tag)
+        trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+        trk.set_rings(rings[0], rings[1])
+        hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep(trk, cx, cy, g[f"{key}_i_start"])
+        dev = float(np.hypot(hcx - g[f"{key}_cx"], hcy - g[f"{key}_cy"]).max())
+        print(f"G7c {key}: HIP vs the reference's run {dev:.2e} m (oracle spread {float(g[f'{key}_oracle_spread_m']):.1e} m)")
+        assert dev <= TOL_M, (key, dev)
+        np.testing.assert_array_equal(ns, g[f"{key}_n_success"])
+
+
+# Fixture G7b, enumerated (measured on MI355X, round 4): which branch of the reference's arithmetic each case's HIP line
+# is on.  "reference" = within 1e-4 m of the REFERENCE's own run; otherwise the label of the oracle re-rounding
+# (tests/parity_rule.py: "fma" or "seed<r>", r <= 24) whose line the HIP result reproduces to 1e-4 m.  A case moving from
+# "reference" to a re-rounding branch, or off every branch, fails the test.
+G7B_EXPECTED = {
+    # measured (gpurun_out/gputest_r04a.log): HIP 7.6e-8 m from the oracle's FMA build; 18 of the 26 oracle runs are on that
+    # branch, 8 (the strict run among them) on the reference run's, 5.8e-3 m away
+    "c100_N2000_it5_seed11": "rerounding",
+    "c100_N2000_it5_seed12": "reference",          # 8.9e-7 m
+    "c100_N1929_it5_seed13": "reference",          # 8.0e-6 m
+    "c100_N2000_it5_seed0_bench0": "reference",    # 2.4e-6 m
+    # HIP 2.2e-5 m from re-rounding seed 19; 3 of the 26 oracle runs on that branch, 3 on the reference run's (0.84 m away)
+    "c100_N2000_it5_seed0_bench3": "rerounding",
+}
+
+
+def g7b_branches(t, cx, cy, k, length, N, rl_, rr_, ist, n_seeds=24):
+    """The strict oracle, its FMA build and n_seeds seeded re-roundings on one G7b case: [(label, cx, cy)]."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(seed):
+        return orc.run_min_curvature_qp(t, cx, cy, k, length, N, rl_, rr_, ist, rerounding=seed)[:2]
+    with ThreadPoolExecutor(8) as ex:
+        runs = list(ex.map(run, range(0, n_seeds + 1)))
+    out = [("strict" if s_ == 0 else f"seed{s_}", a, b) for s_, (a, b) in enumerate(runs)]
+    with orc.fma_variant():
+        a, b = run(0)
+    out.append(("fma", a, b))
+    return out
+
+
 def test_benchmarked_configuration_vs_reference_run(rl, fits, rings):
     """Fixture G7b: the reference's OWN loop at the benchmarked configuration (N = 2000 / 1929, max_iter = 5; three runs on
     the real Monza rings, instances 0 and 3 of bench.py's width-perturbed batch in bench.py's sweep order) against one
-    launch of the HIP sweep kernel.  Judged per case against the REFERENCE's run: within 1e-4 m (north_star), or the
-    oracle's own re-roundings spread by more than 1e-4 m on the case and HIP is within 10x that spread of the oracle
-    (tests/parity_rule.py's rule; the oracle itself reproduces all five runs to <= 4e-6 m,
-    tests/test_oracle_golden.py::test_g7b_benchmarked_configuration)."""
-    from concurrent.futures import ThreadPoolExecutor
+    launch of the HIP sweep kernel.  NEAREST-BRANCH rule, enumerated per case (G7B_EXPECTED): three cases must be within
+    1e-4 m (north_star) of the REFERENCE's run; the two on which the reference's arithmetic branches under +-1 ulp
+    re-roundings must be within 1e-4 m of the strict oracle or of one of its <= 24 + 1 re-roundings --
+    no multiple of a spread is accepted."""
     g = golden("G7b_benchmarked_config.npz")
     t, cx, cy, k, length = spline(fits, "c100")
-    within = 0
+    assert sorted(G7B_EXPECTED) == sorted(str(k_) for k_ in g["cases"])
     for key in [str(k_) for k_ in g["cases"]]:
         N = int(key.split("_")[1][1:])
         ist = g[f"{key}_i_start"]
@@ -216,22 +264,18 @@ def test_benchmarked_configuration_vs_reference_run(rl, fits, rings):
         same_counts = np.array_equal(ns, g[f"{key}_n_success"])
         print(f"G7b {key}: HIP vs the reference's run {dev_ref:.2e} m, per-pass successes "
               f"{'equal' if same_counts else str(ns.ravel().tolist()) + ' vs ' + str(g[f'{key}_n_success'].ravel().tolist())}")
-        if dev_ref <= TOL_M:
-            within += 1
+        if G7B_EXPECTED[key] == "reference":
+            assert dev_ref <= TOL_M and same_counts, (key, dev_ref)
             continue
-        # outside 1e-4 m: only acceptable on a case the reference's own arithmetic does not define to 1e-4 m
-
-        def run(seed):
-            return orc.run_min_curvature_qp(t, cx, cy, k, length, N, rl_, rr_, ist, rerounding=seed)[:2]
-        with ThreadPoolExecutor(8) as ex:
-            runs = list(ex.map(run, range(0, 8)))
-        ocx, ocy = runs[0]
-        spread = max(float(np.hypot(a - ocx, b - ocy).max()) for a, b in runs[1:])
-        dev = float(np.hypot(hcx - ocx, hcy - ocy).max())
-        print(f"    oracle re-rounding spread {spread:.2e} m, HIP vs strict oracle {dev:.2e} m")
-        assert spread > TOL_M and dev <= 10.0 * spread, (key, dev_ref, dev, spread)
-    print(f"G7b: HIP within 1e-4 m of the REFERENCE's own run on {within} of {len(g['cases'])} cases at the benchmarked configuration")
-    assert within >= 1
+        # a case on which the reference's own arithmetic branches: the HIP line must BE one of the branches
+        branches = g7b_branches(t, cx, cy, k, length, N, rl_, rr_, ist)
+        d = [(float(np.hypot(hcx - a, hcy - b).max()), lab) for lab, a, b in branches]
+        d_ref = [(float(np.hypot(g[f"{key}_cx"] - a, g[f"{key}_cy"] - b).max()), lab) for lab, a, b in branches]
+        near, lab = min(d)
+        n_same = sum(1 for x, _ in d if x <= TOL_M)
+        print(f"    nearest oracle branch: {lab} at {near:.2e} m ({n_same} of {len(d)} oracle runs are on the HIP line's branch; "
+              f"{sum(1 for x, _ in d_ref if x <= TOL_M)} on the reference run's)")
+        assert min(near, dev_ref) <= TOL_M, (key, "HIP line is on no branch of the oracle", dev_ref, sorted(d)[:3])
 
 
 def monza_like_widths(rl, fits, rings, tag, N, B, seed):
@@ -364,17 +408,25 @@ def test_full_size_properties(rl, fits, rings):
 
 
 def test_n4000_global_scratch_variant(rl, fits):
-    """BASELINE config 4 size (N=4000): rings no longer fit LDS, the kernel variant with rings and
-    crossings in global scratch must give the same answers."""
+    """BASELINE config 4 size (N=4000) through the sweep at the driver's default depth: B = 64 instances, max_iter = 5.
+    Rings no longer fit LDS, so the kernel variant with rings and crossings in global scratch runs; bookkeeping and
+    determinism on the whole batch, the per-instance nearest-branch rule on a sample of it (the oracle needs ~25 s per
+    N = 4000 instance and re-rounding)."""
     t, cx, cy, k, length = spline(fits, "c100")
-    N, B = 4000, 2
+    N, B, max_iter = 4000, 64, 5
+    n = len(cx)
     widths = rl.batch.width_batch(np.full(N, 5.0), np.full(N, 5.0), B, seed=11)
-    i_start = rl.batch.default_i_start(len(cx), k, 1, seed=2)
+    i_start = rl.batch.default_i_start(n, k, max_iter, seed=2)
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
     ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
     assert st.rings_in_lds == 0
-    po = ParityOracle(t, cx, cy, k, length, N, widths, i_start)
-    batch_parity(xy, po, "N=4000")
+    print(f"N={N} B={B} it={max_iter} kernel ms:", st.kernel_ms)
+    np.testing.assert_array_equal(status, 2 * max_iter * (n - 5) - ns.reshape(B, -1).sum(axis=1))
+    ctrl2, xy2, ns2, _, _ = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
+    np.testing.assert_array_equal(xy, xy2); np.testing.assert_array_equal(ns, ns2)
+    sample = np.array([0, 1, 31, 63])
+    po = ParityOracle(t, cx, cy, k, length, N, widths[sample], i_start)
+    batch_parity(xy[sample], po, "N=4000, max_iter=5, sample of 4 of 64")
 
 
 def test_degree3_sweep_vs_oracle(rl, fits):
@@ -599,57 +651,49 @@ def test_mixed_batch_monza_and_oval(rl, fits, rings):
         assert np.abs(ctrl - np.stack([c0x, c0y], axis=1)).max() > 0.5   # the lines moved
 
 
-JOINT_CASES = [(200, [28]), (400, [15]), (500, [25]), (1000, [17]), (2000, [24]), (300, [3]),
-               (200, [10, 30, 45]), (500, [20, 40]), (500, [7, 52])]
-
+# Sliding-window cases on the real Monza rings.  ROBUST = the strict oracle, its FMA build and 24 seeded +-1 ulp
+# re-roundings all end within 1e-6 m of each other (found by scanning start indices with the oracle alone,
+# tests/golden/scan_wellconditioned.py): the reference's arithmetic DEFINES the answer there, so the HIP line must
+# reproduce it to the north_star tolerance with equal window counts -- these are the end-to-end asserts of a13.
+JOINT_ROBUST_CASES = [(200, [29]), (200, [35]), (200, [10]), (200, [47]), (200, [41]), (300, [5]), (300, [56]), (400, [54]),
+                      (400, [57]), (1000, [3, 30]), (2000, [2]), (2000, [57])]
+# CHAOTIC = the oracle itself moves by 10-60 m under the same re-roundings (a window's feasibility is decided by the last
+# bit of a bound point): no end-to-end statement exists for these -- not for the oracle against the
+# reference's run either -- and none is asserted; what pins the kernel on them is the teacher-forced replay of EVERY window
+# (test_joint_windows_teacher_forced) and the re-solved window QPs (test_joint_window_qps_replayed).
+JOINT_CHAOTIC_CASES = [(200, [28]), (400, [15]), (500, [25]), (1000, [17]), (2000, [24]), (300, [3]),
+                       (200, [10, 30, 45]), (500, [20, 40]), (500, [7, 52])]
 
 N_REROUND = 12     # re-roundings of the oracle per case (seeds 1..12 of orc_set_rerounding); fixed, not tuned per case
 
 
-def _joint_conditioning(run_oracle):
+def _joint_conditioning(run_oracle, n_reround=N_REROUND):
     """How well the REFERENCE'S formulation defines the answer of a sliding-window case, measured on the oracle alone
-    (independently of the HIP result): the strict oracle and its N_REROUND seeded +-1 ulp re-roundings.
-    Returns (strict cx, cy, window counts, spread [m])."""
+    (independently of the HIP result): the strict oracle and its seeded +-1 ulp re-roundings.
+    Returns (strict cx, cy, window counts, spread [m], all runs)."""
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(8) as ex:                     # ctypes releases the GIL; the re-rounding state is thread-local
-        runs = list(ex.map(run_oracle, range(0, N_REROUND + 1)))
+        runs = list(ex.map(run_oracle, range(0, n_reround + 1)))
     ocx, ocy, ons = runs[0]
     spread = max(float(np.hypot(rcx - ocx, rcy - ocy).max()) for rcx, rcy, _ in runs[1:])
-    return ocx, ocy, ons, spread
+    return ocx, ocy, ons, spread, runs
 
 
-def _joint_rule(label, hcx, hcy, run_oracle):
-    """Per-case rule for the sliding-window driver, with no constant to tune after a run:
-      * ROBUST case -- all N_REROUND re-roundings of the oracle end within 1e-4 m of the strict oracle: the reference's
-        arithmetic defines the answer there, and the HIP line MUST be within 1e-4 m of it;
-      * otherwise the case is chaotic in the rounding (the oracle itself cannot reproduce it under a +-1 ulp change): the
-        HIP line must stay within 10x the oracle's own spread, and what pins the kernel is the teacher-forced replay of
-        every window (test_joint_windows_teacher_forced), which runs on every case either way.
-    Returns (dev, spread, robust, within)."""
-    ocx, ocy, ons, spread = _joint_conditioning(run_oracle)
-    dev = float(np.hypot(hcx - ocx, hcy - ocy).max())
-    robust = spread <= TOL_M
-    if robust:
-        assert dev <= TOL_M, (label, "robust case: HIP must agree with the oracle", dev, spread)
-    else:
-        assert dev <= TOL_M or dev <= 10.0 * spread, (label, dev, spread)
-    return dev, spread, robust, dev <= TOL_M
+def _joint_invariants(hcx, hcy, pts, ns, cx, cy):
+    n = len(cx)
+    assert np.isfinite(hcx).all() and np.isfinite(hcy).all() and np.isfinite(pts[:, :2]).all()
+    assert hcx[0] == hcx[n - 5] and hcx[1] == hcx[n - 4] and hcx[n - 3] == hcx[2] and hcx[n - 1] == hcx[4]
+    assert 0 <= ns.min() and ns.max() <= n - 8 - 2        # windows per iteration: i_max - i_min
+    assert np.hypot(hcx - cx, hcy - cy).max() > 0.5        # the line moved
 
 
 def test_joint_sweep_vs_oracle(rl, fits, rings):
     """run_joint_min_curvature_qp (optimizer.py:163-220): sliding 5-control-point windows, each a
-    10-variable QP solved exactly (two 5-variable dual active-set solves) -- HIP vs the oracle.
-
-    The window QP has a row for EVERY sample of the track, so it is infeasible as soon as one sample
-    anywhere sits outside its own bound box -- and after a clamp samples sit ON a ring, where "inside
-    or outside by one ulp" is decided by rounding (tools/joint_divergence.py shows the mechanism on fixture G9: the
-    states of kernel and oracle stay 1e-11 m apart for 60 windows, then ONE window whose verdict the oracle itself
-    reverses when its bounds move by 4e-12 m is accepted by one and rejected by the other, and the lines are 5 m apart).
-    Rule per case: _joint_rule -- agreement is REQUIRED wherever the oracle's own re-roundings agree."""
+    10-variable QP solved exactly (two 5-variable dual active-set solves) -- HIP vs the oracle, END TO END, on the
+    well-conditioned cases: within 1e-4 m (north_star) with the same number of accepted windows per iteration.  The
+    premise (the case IS robust under re-rounding) is re-checked here, so a case cannot silently turn chaotic."""
     t, cx, cy, k, length = spline(fits, "c100")
-    n = len(cx)
-    agree = n_robust = 0
-    for N, i_start in JOINT_CASES:
+    for N, i_start in JOINT_ROBUST_CASES:
         trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
         trk.set_rings(rings[0], rings[1])
         hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, i_start)
@@ -657,28 +701,65 @@ def test_joint_sweep_vs_oracle(rl, fits, rings):
         def run_oracle(seed):
             ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start, rerounding=seed)
             return ocx, ocy, ons
-        dev, spread, robust, within = _joint_rule((N, i_start), hcx, hcy, run_oracle)
-        agree += within; n_robust += robust
-        print(f"joint N={N} i_start={i_start}: windows HIP {ns.tolist()}  HIP-oracle {dev:.1e} m  oracle re-rounding spread "
-              f"{spread:.1e} m ({'robust' if robust else 'chaotic'})  kernel {st.kernel_ms:.2f} ms")
-        assert np.isfinite(hcx).all() and np.isfinite(hcy).all() and np.isfinite(pts[:, :2]).all()
-        assert hcx[0] == hcx[n - 5] and hcx[1] == hcx[n - 4] and hcx[n - 3] == hcx[2] and hcx[n - 1] == hcx[4]
-        assert 0 <= ns.min() and ns.max() <= n - 8 - 2        # windows per iteration: i_max - i_min
-        assert np.hypot(hcx - cx, hcy - cy).max() > 0.5        # the line moved
-    print(f"joint driver: {agree} of {len(JOINT_CASES)} cases inside 1e-4 m; {n_robust} robust under re-rounding (all of those agree)")
-    assert agree >= n_robust
+        ocx, ocy, ons, spread, _ = _joint_conditioning(run_oracle)
+        dev = float(np.hypot(hcx - ocx, hcy - ocy).max())
+        print(f"joint (robust) N={N} i_start={i_start}: windows HIP {ns.tolist()} oracle {ons.tolist()}  HIP-oracle {dev:.1e} m  "
+              f"oracle re-rounding spread {spread:.1e} m  kernel {st.kernel_ms:.2f} ms")
+        assert spread <= 1e-6, ("the case is listed as robust", N, i_start, spread)
+        assert dev <= TOL_M, (N, i_start, dev)
+        np.testing.assert_array_equal(ns, ons)
+        _joint_invariants(hcx, hcy, pts, ns, cx, cy)
+
+
+def test_joint_sweep_chaotic_cases(rl, fits, rings):
+    """The chaotic sliding-window cases: invariants only, and the distance to the nearest of the oracle's 12 re-roundings is
+    REPORTED (a case on which HIP happens to sit on an oracle branch is counted) -- no end-to-end assert can be written
+    for them that is not a tuned bar.  Every window of every one of these cases is re-derived by the oracle from the
+    kernel's own state in test_joint_windows_teacher_forced."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    on_branch = 0
+    for N, i_start in JOINT_CHAOTIC_CASES:
+        trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+        trk.set_rings(rings[0], rings[1])
+        hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, i_start)
+
+        def run_oracle(seed):
+            ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start, rerounding=seed)
+            return ocx, ocy, ons
+        ocx, ocy, ons, spread, runs = _joint_conditioning(run_oracle)
+        near = min(float(np.hypot(hcx - a, hcy - b).max()) for a, b, _ in runs)
+        on_branch += near <= TOL_M
+        print(f"joint (chaotic) N={N} i_start={i_start}: windows HIP {ns.tolist()}  nearest oracle branch {near:.1e} m  oracle "
+              f"re-rounding spread {spread:.1e} m  kernel {st.kernel_ms:.2f} ms")
+        assert spread > TOL_M, ("the case is listed as chaotic but the oracle's re-roundings agree: move it to the robust list", N, i_start)
+        _joint_invariants(hcx, hcy, pts, ns, cx, cy)
+    print(f"joint driver, chaotic cases: HIP on one of the oracle's {N_REROUND + 1} branches on {on_branch} of {len(JOINT_CHAOTIC_CASES)}")
 
 
 def test_joint_sweep_vs_reference_run(rl, fits, rings):
-    """a13 end to end against the REFERENCE'S OWN run (fixture G9: run_joint_min_curvature_qp executed by the reference's
-    loop, tests/golden/make_golden.py; the QP solver and fill_bounds inside that loop are stand-ins).
-    Per case, no tuned count: where the oracle's re-roundings all agree (the reference's arithmetic defines the answer) AND
-    the oracle reproduces the reference's run, the HIP line must reproduce it too -- within 1e-4 m, equal window counts;
-    every other case must be explained by the oracle's own spread.  The flag `<key>_oracle_reproduces_run` of the fixture
-    only says that the oracle's roundings happened to equal numpy's on that case."""
+    """a13 end to end against the REFERENCE'S OWN run.  Fixture G9b (round 4): run_joint_min_curvature_qp executed by the
+    reference's loop (tests/golden/make_golden.py; the QP solver and fill_bounds inside that loop are stand-ins, DESIGN.md
+    section 4) on eight WELL-CONDITIONED cases -- the fixture records the oracle's spread over 24 re-roundings + the FMA build,
+    < 1e-6 m on each.  On every one of them the HIP line must reproduce the reference's run within 1e-4 m with the same
+    number of accepted windows.  Fixture G9 (round 2: six cases that all turned out chaotic) is reported, not asserted."""
+    g = golden("G9b_joint_wellconditioned.npz")
+    for key in g["cases"]:
+        key = str(key)
+        tag, Ns, _ = key.split("_")
+        N = int(Ns[1:])
+        t, cx, cy, k, length = spline(fits, tag)
+        ist = g[f"{key}_i_start"]
+        assert float(g[f"{key}_oracle_spread_m"]) < 1e-6
+        trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+        trk.set_rings(rings[0], rings[1])
+        hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, ist)
+        dev_ref = float(np.hypot(hcx - g[f"{key}_cx"], hcy - g[f"{key}_cy"]).max())
+        print(f"G9b {key}: HIP vs the reference's run {dev_ref:.2e} m, accepted windows {int(ns.sum())} vs {int(g[f'{key}_n_ok'])}")
+        assert dev_ref <= TOL_M, (key, dev_ref)
+        assert int(ns.sum()) == int(g[f"{key}_n_ok"]), (key, ns)
     g = golden("G9_run_joint_min_curvature_qp.npz")
     t, cx, cy, k, length = spline(fits, "c100")
-    exact = n_robust = 0
+    exact = 0
     for key in g["cases"]:
         key = str(key)
         N = int(key.split("_")[1][1:])
@@ -687,20 +768,10 @@ def test_joint_sweep_vs_reference_run(rl, fits, rings):
         trk.set_rings(rings[0], rings[1])
         hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, ist)
         dev_ref = float(np.hypot(hcx - g[f"{key}_cx"], hcy - g[f"{key}_cy"]).max())
-        same = dev_ref <= TOL_M and int(ns.sum()) == int(g[f"{key}_n_ok"])
-        exact += bool(same)
-
-        def run_oracle(seed):
-            ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist, rerounding=seed)
-            return ocx, ocy, ons
-        dev, spread, robust, within = _joint_rule(key, hcx, hcy, run_oracle)
-        n_robust += robust
-        print(f"G9 {key}: HIP vs the reference's run {dev_ref:.2e} m, windows {int(ns.sum())} vs {int(g[f'{key}_n_ok'])}; "
-              f"oracle re-rounding spread {spread:.1e} m ({'robust' if robust else 'chaotic'}); the oracle "
-              f"{'reproduces' if bool(g[f'{key}_oracle_reproduces_run']) else 'does not reproduce'} the run")
-        if robust and bool(g[f"{key}_oracle_reproduces_run"]):
-            assert same, (key, "robust case reproduced by the oracle: HIP must reproduce the reference's run", dev_ref)
-    print(f"G9: the HIP line reproduces the reference's own run on {exact} of {len(g['cases'])} cases ({n_robust} robust under re-rounding)")
+        exact += dev_ref <= TOL_M and int(ns.sum()) == int(g[f"{key}_n_ok"])
+        print(f"G9 (chaotic, reported only) {key}: HIP vs the reference's run {dev_ref:.2e} m, windows {int(ns.sum())} vs {int(g[f'{key}_n_ok'])}")
+        _joint_invariants(hcx, hcy, pts, ns, cx, cy)
+    print(f"G9: the HIP line reproduces the reference's own run on {exact} of {len(g['cases'])} chaotic cases")
 
 
 def test_joint_sweep_search_modes_and_api(rl, fits, rings, monkeypatch):
@@ -939,6 +1010,22 @@ def test_bench_mixed_workload_two_ranks(tmp_path):
     res = _bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                   "--share-gpu", "--batch", "64", "--workload", "mixed"], root)
     assert res["n_gpus"] == 2 and res["value"] > 0 and "mixed" in res["config"]["workload"]
+
+
+def test_bench_mixed_workload_four_ranks(tmp_path):
+    """More than two ranks through bench.py's N > 1 path (mixed workload: two groups, two gathers per step, double
+    buffered) on this box's one GPU over gloo.  Four ranks, not configs[2]'s eight: a GPU box admits at most 6 processes
+    on its card and this test process is one of them; the 8-rank shard / gather arithmetic itself runs on CPU in
+    tests/test_host_cpu.py::test_uneven_shards_and_gather_gloo_world8."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = _bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+                  "--share-gpu", "--batch", "64", "--workload", "mixed"], root)
+    assert res["n_gpus"] == 4 and res["value"] > 0
+    gc = res["gather_check"]
+    assert gc == dict(gc, groups=2, ranks=4, shards_equal=8), gc
+    assert "world size 4" in res["config"]["parallelism"]
 
 
 def test_bench_mixed_workload_full_share_two_ranks(tmp_path):

@@ -142,6 +142,68 @@ def test_sharded_solve_and_gather_gloo_world2(tmp_path):
     assert "GLOO_OK" in out.stdout and "ASYNC_OK" in out.stdout
 
 
+_GLOO_WORKER8 = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["RL_ROOT"])
+from spline_trajectory_optimization_amd import batch
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+# BASELINE configs[2] runs on 8 ranks: an UNEVEN split (B = 1000 over 8 -> shards of 125; B = 1003 -> 126/125) through
+# gather_to_root(total=...), every instance tagged with its global index
+for B, N in ((1000, 16), (1003, 8), (5, 4)):
+    lo, hi = batch.shard_range(B, rank, world)
+    mine = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1, 1).repeat(1, N, 2) if hi > lo else torch.zeros((0, N, 2), dtype=torch.float64)
+    full = batch.gather_to_root(mine, rank, world, dist, total=B)
+    if rank == 0:
+        assert full.shape == (B, N, 2), full.shape
+        assert torch.equal(full[:, 0, 0], torch.arange(B, dtype=torch.float64)) and torch.equal(full[:, N - 1, 1], full[:, 0, 0])
+    else:
+        assert full is None
+# integer control data (status words) through the same gather
+lo, hi = batch.shard_range(1000, rank, world)
+st = batch.gather_to_root(torch.arange(lo, hi, dtype=torch.int32), rank, world, dist, total=1000)
+if rank == 0:
+    assert torch.equal(st, torch.arange(1000, dtype=torch.int32))
+    print("GLOO8_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_uneven_shards_and_gather_gloo_world8(tmp_path):
+    """The world size BASELINE configs[2] names (8 ranks): uneven contiguous shards, empty shards (B < world), float and
+    integer payloads, all through batch.gather_to_root on gloo."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_GLOO_WORKER8)
+    env = dict(os.environ, RL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GLOO8_OK" in out.stdout
+
+
+def test_g11_sectional_lengths():
+    """eval_sectional_length / eval_dx_sectional_length / eval_dy_sectional_length (reference trajectory.py:232-245;
+    host quadrature in the reference and here) against values the reference's own methods produced (fixture G11)."""
+    import pickle
+    from spline_trajectory_optimization_amd.models.trajectory import BSplineTrajectory
+    from scipy import interpolate
+    g = np.load(os.path.join(ROOT, "tests", "golden", "G11_sectional_lengths.npz"))
+    f = np.load(os.path.join(ROOT, "tests", "golden", "G1_spline_fits.npz"))
+    for tag in ("c100", "l10"):
+        sp = BSplineTrajectory.__new__(BSplineTrajectory)
+        k = int(f[f"{tag}_k"])
+        sp._spl_x = interpolate.BSpline(f[f"{tag}_t"], f[f"{tag}_cx"], k)
+        sp._spl_y = interpolate.BSpline(f[f"{tag}_t"], f[f"{tag}_cy"], k)
+        for q, iv in enumerate(g["intervals"]):
+            assert abs(sp.eval_sectional_length(tuple(iv)) - g[f"{tag}_len"][q]) <= 1e-9 * max(1.0, abs(g[f"{tag}_len"][q]))
+            assert abs(sp.eval_dx_sectional_length(tuple(iv)) - g[f"{tag}_dx"][q]) <= 1e-9 * max(1.0, abs(g[f"{tag}_dx"][q]))
+            assert abs(sp.eval_dy_sectional_length(tuple(iv)) - g[f"{tag}_dy"][q]) <= 1e-9 * max(1.0, abs(g[f"{tag}_dy"][q]))
+
+
 def test_ttl_and_csv_formats_roundtrip(tmp_path, built):
     """Wire formats of the reference (models/trajectory.py:202-209, 312-358): Trajectory CSV and the
     TTL file (header ttl_num,N,length,origin + 17 columns per row) -- host-side, no GPU involved."""

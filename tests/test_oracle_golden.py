@@ -376,8 +376,44 @@ def test_g9_run_joint_min_curvature_qp(fits, rings):
             for seed in range(1, 7):
                 rcx, rcy, _, _ = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], ist, rerounding=seed)
                 spread = max(spread, np.hypot(rcx - ocx, rcy - ocy).max())
-            assert spread > 1e-4 and dev <= 10.0 * spread, (key, dev, spread)
+            # certified chaotic: the oracle's own re-roundings part by more than the tolerance, so neither the oracle nor
+            # anything else can be required to reproduce this run (no multiple of the spread is accepted as "agreement")
+            assert spread > 1e-4, (key, dev, spread)
     assert n_good >= 5
+
+
+def test_g9b_g7c_wellconditioned_reference_runs(fits, rings):
+    """Fixtures G9b / G7c (round 4): the reference's own run_joint_min_curvature_qp / run_min_curvature_qp loops on cases
+    where the oracle's 24 re-roundings + FMA build agree to < 1e-6 m (recorded per case in the fixture).  The strict
+    oracle must reproduce every one of these runs to 1e-6 m with equal window / success counts -- no exemption exists
+    on a well-conditioned case."""
+    g = golden("G9b_joint_wellconditioned.npz")
+    assert len(g["cases"]) >= 8
+    for key in g["cases"]:
+        key = str(key)
+        tag, Ns, _ = key.split("_")
+        N = int(Ns[1:])
+        t, cx, cy, k, length = spline(fits, tag)
+        assert float(g[f"{key}_oracle_spread_m"]) < 1e-6
+        ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], g[f"{key}_i_start"])
+        dev = np.hypot(ocx - g[f"{key}_cx"], ocy - g[f"{key}_cy"]).max()
+        assert dev < 1e-6 and int(ons.sum()) == int(g[f"{key}_n_ok"]) > 0, (key, dev, ons)
+        # and the premise, re-checked on a few re-roundings so that it cannot rot
+        for seed in (1, 2, 3):
+            rcx, rcy, _, _ = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], g[f"{key}_i_start"], rerounding=seed)
+            assert np.hypot(rcx - ocx, rcy - ocy).max() < 1e-6, (key, seed)
+    g = golden("G7c_wellconditioned.npz")
+    assert len(g["cases"]) >= 4
+    for key in g["cases"]:
+        key = str(key)
+        tag, Ns, _ = key.split("_")
+        N = int(Ns[1:])
+        t, cx, cy, k, length = spline(fits, tag)
+        assert float(g[f"{key}_oracle_spread_m"]) < 1e-6
+        ocx, ocy, _, ons = orc.run_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], g[f"{key}_i_start"])
+        dev = np.hypot(ocx - g[f"{key}_cx"], ocy - g[f"{key}_cy"]).max()
+        assert dev < 1e-6, (key, dev)
+        np.testing.assert_array_equal(ons, g[f"{key}_n_success"])
 
 
 def test_replay_of_the_first_steps_equals_the_plain_pipeline(fits, rings):
