@@ -1291,6 +1291,11 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
         RL_HIP(hipEventRecord(ctx->ev_chunk[g], grp[g].q));
         RL_HIP(hipStreamWaitEvent(ctx->poll_stream, ctx->ev_chunk[g], 0));
       }
+      // The copy is ordered after THIS chunk's kernels only; the next chunk's kernels, enqueued below, may already be writing
+      // `scal` while it runs -- an unsynchronised read, deliberately: the host looks at nothing but word 5 of every instance
+      // (status: 0 -> 1 / 2, written once, never back; an aligned 8-byte word is copied whole), so a stale value can only
+      // delay the early exit by one chunk and a fresh one cannot end it early: `all` needs EVERY instance finished, and a
+      // finished instance's kernels return at their first line.
       RL_HIP(hipMemcpyAsync(ctx->poll_host + (size_t)slot * ctx->poll_cap, st.scal, (size_t)B * 16 * sizeof(double),
                             hipMemcpyDeviceToHost, ctx->poll_stream));
       RL_HIP(hipEventRecord(ctx->ev_poll[slot], ctx->poll_stream));

@@ -815,9 +815,15 @@ __device__ __forceinline__ void mt_to_k(double vi, int q, double (&vk)[4]) {
 // pivot k one v_readlane pair (the pivot), five ds_bpermute pairs (column k for the lane's row, row k for the
 // lane's four columns) and four lane-local updates.  Returns the number of negative pivots (they are the LDL'
 // pivots of the block: their signs, summed over the whole elimination, are the inertia of the KKT matrix), or
-// -1 when a pivot is negligible / not finite.  (Measured and dropped: issuing the moves of pivot k + 1 before the
-// update of pivot k and advancing the moved values by the update formula, which shortens the dependent chain to
-// 1/p_k -> p_{k+1} -- 11 % slower: the step is bound by its instruction count, not by the chain.)
+// -1 when a pivot is negligible / not finite.  Measured and dropped:
+//   * (round 3) issuing the moves of pivot k + 1 before the update of pivot k and advancing the moved values by the
+//     update formula, which shortens the dependent chain to 1/p_k -> p_{k+1}: 11 % slower;
+//   * (round 4) the cross-lane moves without LDS -- row k by DPP row_newbcast (two v_mov_b32_dpp per value), column k by
+//     v_permlane32_swap + v_permlane16_swap (row Q of the wave into all four rows): bit-identical results, one NLP (the latency-bound
+//     case the change was meant for) 0.1026 s against 0.1020 s: no gain.  The ten ds_bpermute of a pivot are LDS
+//     instructions; their replacement is ~28 VALU instructions (moves that seed the DPP destinations, the swaps' operand
+//     copies, wait states), so the VALU stream of a pivot grows by a third and the chain -- set by 1/p and its two Newton
+//     steps -- does not shrink.
 __device__ __forceinline__ int mt_invert(MtBlk& S, int lane) {
   const int i = lane & 15, q = lane >> 4;
   int neg = 0;
@@ -1341,6 +1347,28 @@ __device__ __forceinline__ double mt_block_reduce(double v, double* red, int op 
   return r;
 }
 
+// NV values at once (op[v]: 0 sum, 1 min): one wave reduction each, ONE round trip through LDS and two barriers for all of
+// them (the per-instance kernels are latency bound: k_mt_step spent its time in 4 + 2 kMtTrials single-value reductions of
+// three barriers each).  The wave partials are combined in wave order, as mt_block_reduce does: same sums bit for bit.
+template <int BLOCK, int NV>
+__device__ __forceinline__ void mt_block_reduce_n(double (&v)[NV], const int (&op)[NV], double* red /* [NV * BLOCK / 64] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = op[k] == 0 ? wave_sum(v[k]) : wave_min(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[k * (BLOCK / 64) + wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double r = red[k * (BLOCK / 64)];
+    for (int q = 1; q < BLOCK / 64; ++q) r = op[k] == 0 ? r + red[k * (BLOCK / 64) + q] : fmin(r, red[k * (BLOCK / 64) + q]);
+    v[k] = r;
+  }
+}
+
 // k_mt_prepare2 (one workgroup per instance, after k_mt_node): convergence test and barrier update as k_mt_prepare (the stationarity
 // residual comes per node from k_mt_node), then the right-hand side rhs = rhs0 - mu r1.  (Measured: as a prologue of the elimination
 // kernel instead of a kernel of its own it is 1.5 % faster for 1024 instances and 13 % slower for 256: a kernel of its own.)
@@ -1371,9 +1399,12 @@ __device__ __forceinline__ bool mt_prepare2(const MtProblem& P, const MtState& s
     compl_ = fmax(compl_, s_ * z_);
     errmu = fmax(errmu, fabs(s_ * z_ - mu));
   }
-  kkt = -mt_block_reduce<BLOCK>(-kkt, red, 1); viol = -mt_block_reduce<BLOCK>(-viol, red, 1);
-  compl_ = -mt_block_reduce<BLOCK>(-compl_, red, 1); errmu = -mt_block_reduce<BLOCK>(-errmu, red, 1);
-  lap = mt_block_reduce<BLOCK>(lap, red, 0);
+  {
+    double v[5] = {-kkt, -viol, -compl_, -errmu, lap};
+    const int op[5] = {1, 1, 1, 1, 0};
+    mt_block_reduce_n<BLOCK, 5>(v, op, red);
+    kkt = -v[0]; viol = -v[1]; compl_ = -v[2]; errmu = -v[3]; lap = v[4];
+  }
   if (tid == 0) { scal[2] = kkt; scal[3] = viol; scal[4] = compl_; scal[11] = lap; }
   if (fmax(kkt, fmax(viol, compl_)) <= st.tol) {
     if (tid == 0) scal[5] = 1.0;
@@ -1395,7 +1426,7 @@ __device__ __forceinline__ bool mt_prepare2(const MtProblem& P, const MtState& s
 
 
 __global__ void __launch_bounds__(256) k_mt_prepare2(MtProblem P, MtState st) {
-  __shared__ double red[8];
+  __shared__ double red[5 * 4];
   if (st.scal[(size_t)blockIdx.x * 16 + 5] != 0.0) return;
   (void)mt_prepare2<256>(P, st, blockIdx.x, threadIdx.x, red);
 }
@@ -1452,7 +1483,7 @@ __global__ void __launch_bounds__(128) k_mt_kkt(MtProblem P, MtState st) {
   // coupling of node j to the NEXT node of its front, in the role of E_j of the ascending recursion
   auto ld_e = [&](int j) { return wave == 0 ? ld(Eg + (size_t)j * 256) : ld_t(Eg + (size_t)(j - 1) * 256); };
 
-  int attempt = 0;
+  int attempt = 0, fails = 0;
   bool ok = false;
   for (; attempt < 12 && !ok; ++attempt) {
     bool bad = false;
@@ -1557,13 +1588,14 @@ __global__ void __launch_bounds__(128) k_mt_kkt(MtProblem P, MtState st) {
     __syncthreads();
     if (!fronts_ok || X.ok == 0) {
       delta = fmax(10.0 * delta, 1e-4);
+      ++fails;
       __syncthreads();                   // everybody has read the flags before the next attempt rewrites them
       if (delta > 1e8) break;
       continue;
     }
     ok = true;
   }
-  if (threadIdx.x == 0) { scal[1] = delta; scal[10] += (double)(attempt - 1); }
+  if (threadIdx.x == 0) { scal[1] = delta; scal[10] += (double)fails; }   // refactorisations = failed attempts (also on the give-up path)
   if (!ok) {
     if (threadIdx.x == 0) scal[5] = 2.0;
     return;
@@ -1704,7 +1736,7 @@ __global__ void __launch_bounds__(256, 2) k_mt_kkt4(MtProblem P, MtState st) {
   auto node = [&](int s_) { return asc ? first + s_ : first - s_; };
   auto ld_e = [&](int j) { return asc ? ld(Eg + (size_t)j * 256) : ld_t(Eg + (size_t)(j - 1) * 256); };   // coupling to the next node of the front
 
-  int attempt = 0;
+  int attempt = 0, fails = 0;
   bool ok = false;
   for (; attempt < 12 && !ok; ++attempt) {
     bool bad = false;
@@ -1834,13 +1866,14 @@ __global__ void __launch_bounds__(256, 2) k_mt_kkt4(MtProblem P, MtState st) {
     __syncthreads();
     if (!fronts_ok || X.ok == 0) {
       delta = fmax(10.0 * delta, 1e-4);
+      ++fails;
       __syncthreads();
       if (delta > 1e8) break;
       continue;
     }
     ok = true;
   }
-  if (threadIdx.x == 0) { scal[1] = delta; scal[10] += (double)(attempt - 1); }
+  if (threadIdx.x == 0) { scal[1] = delta; scal[10] += (double)fails; }   // refactorisations = failed attempts (also on the give-up path)
   if (!ok) {
     if (threadIdx.x == 0) scal[5] = 2.0;
     return;
@@ -2087,9 +2120,14 @@ __device__ __forceinline__ void mt_trial_node(const MtProblem& P, const MtStepPt
   }
 }
 
-// grid (node blocks, B): the first kMtTrials trial points (ap, ap / 2, ap / 4: 97 % of the accepted steps on the benchmark batch),
-// one node pair per thread -> vec[b][j][2 k .. 2 k + 1], k = trial (the shares of k_mt_dir there have been consumed)
-constexpr int kMtTrials = 3;
+// grid (node blocks, B): the first kMtTrials trial points, one node pair per thread -> vec[b][j][2 k .. 2 k + 1], k = trial.
+// Round 4: ONE trial point (a = ap: 72 % of the accepted steps of the benchmark batch take it, tools/mintime_halvings.py);
+// the 28 % that need ap / 2, ap / 4, ... evaluate them in k_mt_step, whose halving loop forms the same per-node shares and
+// adds them in the same order, so the decisions are bit for bit those of the three-point build (RL_MT_TRIALS=3 rebuilds it).
+#ifndef RL_MT_TRIALS
+#define RL_MT_TRIALS 1
+#endif
+constexpr int kMtTrials = RL_MT_TRIALS;
 __global__ void __launch_bounds__(64) k_mt_trial(MtProblem P, MtState st) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
   const MtStepPtrs q = mt_step_ptrs(st, b, N);
@@ -2115,7 +2153,7 @@ __global__ void __launch_bounds__(64) k_mt_trial(MtProblem P, MtState st) {
 }
 
 __global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
-  __shared__ double red[8];
+  __shared__ double red[(4 + 2 * kMtTrials) * 4];
   const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
   const MtStepPtrs q = mt_step_ptrs(st, b, N);
   if (q.scal[5] != 0.0) return;
@@ -2140,8 +2178,6 @@ __global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
       for (int a = 5; a < 8; ++a) c += 1e-4 * wj[a] * wj[a] + 1e-1 * (wn[a] - wj[a]) * (wn[a] - wj[a]);
       phi0 += c;
     }
-    ap = mt_block_reduce<256>(ap, red, 1); ad = mt_block_reduce<256>(ad, red, 1);
-    theta0 = mt_block_reduce<256>(theta0, red, 0); phi0 = mt_block_reduce<256>(phi0, red, 0);
   }
   // ---- the trial points of k_mt_trial: the first acceptable one
   const double* tp = st.vec + (size_t)b * N * 16;
@@ -2152,8 +2188,17 @@ __global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
 #pragma unroll
     for (int k = 0; k < kMtTrials; ++k) { th[k] += tp[(size_t)j * 16 + 2 * k]; ph[k] += tp[(size_t)j * 16 + 2 * k + 1]; }
   }
+  {
+    double v[4 + 2 * kMtTrials];
+    int op[4 + 2 * kMtTrials];
+    v[0] = ap; v[1] = ad; v[2] = theta0; v[3] = phi0; op[0] = 1; op[1] = 1; op[2] = 0; op[3] = 0;
 #pragma unroll
-  for (int k = 0; k < kMtTrials; ++k) { th[k] = mt_block_reduce<256>(th[k], red, 0); ph[k] = mt_block_reduce<256>(ph[k], red, 0); }
+    for (int k = 0; k < kMtTrials; ++k) { v[4 + 2 * k] = th[k]; v[5 + 2 * k] = ph[k]; op[4 + 2 * k] = 0; op[5 + 2 * k] = 0; }
+    mt_block_reduce_n<256, 4 + 2 * kMtTrials>(v, op, red);
+    ap = v[0]; ad = v[1]; theta0 = v[2]; phi0 = v[3];
+#pragma unroll
+    for (int k = 0; k < kMtTrials; ++k) { th[k] = v[4 + 2 * k]; ph[k] = v[5 + 2 * k]; }
+  }
   const int nfilt_total = (int)q.scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
   double a = ap;
   int taken = -1;
@@ -2164,11 +2209,20 @@ __global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
       else a *= 0.5;
     }
   }
-  // ---- all three rejected (3 % of the steps of the benchmark batch): further halvings, evaluated here
+  // ---- the precomputed trial point(s) rejected: further halvings, evaluated here
   for (int trial = kMtTrials; trial < 12 && taken < 0; ++trial) {
     double theta = 0.0, phi = 0.0;
-    for (int j = tid; j < N; j += 256) mt_trial_node(P, q, N, j, a, mu, theta, phi);
-    theta = mt_block_reduce<256>(theta, red, 0); phi = mt_block_reduce<256>(phi, red, 0);
+    for (int j = tid; j < N; j += 256) {   // per-node shares from zero, then added: the association of k_mt_trial's path
+      double tj = 0.0, pj = 0.0;
+      mt_trial_node(P, q, N, j, a, mu, tj, pj);
+      theta += tj; phi += pj;
+    }
+    {
+      double v[2] = {theta, phi};
+      const int op[2] = {0, 0};
+      mt_block_reduce_n<256, 2>(v, op, red);
+      theta = v[0]; phi = v[1];
+    }
     if (mt_accept(st, q.filt, nfilt, N, theta, phi, theta0, phi0)) taken = trial;
     else a *= 0.5;
   }

@@ -55,7 +55,10 @@ if tot > 0 and "run" in out:
     json.dump({"source": f"profiles/{tag}_kernels.json", "batch": out["run"]["batch"], "iterations_mean": out["run"]["iterations_mean"],
                "fp64_flops_per_instance": out["fp64_flops_per_instance"],
                "fp64_flops_mfma_share": out["fp64_flops_mfma_per_call"] / tot,
-               "kkt_avg_us": next((k["avg_us"] for n_, k in out["kernels"].items() if "k_mt_kkt" in n_), None)},
+               "kkt_avg_us": next((k["avg_us"] for n_, k in out["kernels"].items() if "k_mt_kkt" in n_), None),
+               # the kernel set the counters belong to (> 100 calls = the iteration's kernels): bench.py prints it, so that a
+               # profile of another build of the solver is visible in the line
+               "iteration_kernels": sorted(n_.split("(")[0].replace("void ", "") for n_, k in out["kernels"].items() if k["calls"] > 100)},
               open(os.path.join(dst, "mintime_counters_latest.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, f"{tag}_kernels.json"), "w"), indent=1)
 print(json.dumps({n: {a: b for a, b in k.items() if a != "counters"} for n, k in out["kernels"].items()}, indent=1))
