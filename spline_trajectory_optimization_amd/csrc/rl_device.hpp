@@ -226,38 +226,94 @@ constexpr int kWinEdges = kWinChunks * kChunk;  // 24; rings must be longer than
 constexpr int kRingPad = kWinEdges + 1;         // vertices repeated behind the ring
 constexpr int kWinBatch = 8;
 
-template <typename RingPtr>
-__device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, double px, double py,
+// `lo` addresses the vertices (ring[lo .. lo + kWinEdges]); `lo_edge` numbers the edges (edge q of the window is edge
+// lo_edge + q of the ring, modulo nr).  Scanning the ring itself: lo == lo_edge; scanning a staged stretch: lo = offset
+// of the window inside the stretch.
+template <int BATCH = kWinBatch, typename RingPtr>
+__device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo_edge, double px, double py,
                                             double dx, double dy, Hit& h) {
   unsigned cand = 0u;
   {
     double2 v = ring[lo];
     double ea = edge_side(v.x - px, v.y - py, dx, dy);
 #pragma unroll
-    for (int q0 = 0; q0 < kWinEdges; q0 += kWinBatch) {
-      double2 w[kWinBatch];
+    for (int q0 = 0; q0 < kWinEdges; q0 += BATCH) {
+      double2 w[BATCH];
 #pragma unroll
-      for (int u = 0; u < kWinBatch; ++u) w[u] = ring[lo + q0 + u + 1];
+      for (int u = 0; u < BATCH; ++u) w[u] = ring[lo + q0 + u + 1];
 #pragma unroll
-      for (int u = 0; u < kWinBatch; ++u) {
+      for (int u = 0; u < BATCH; ++u) {
         const double eb = edge_side(w[u].x - px, w[u].y - py, dx, dy);
         if (!(ea * eb > 0.0)) cand |= 1u << (q0 + u);
         ea = eb;
       }
+      if constexpr (BATCH != kWinBatch) __builtin_amdgcn_sched_barrier(0);   // staged scan: keep the next batch's LDS reads behind this batch's arithmetic (registers)
     }
   }
-  static_assert(kWinEdges % kWinBatch == 0, "window scan is unrolled in whole batches");
+  static_assert(kWinEdges % BATCH == 0, "window scan is unrolled in whole batches");
   while (__any(cand != 0u)) {
     if (cand != 0u) {
       const int q = __ffs((int)cand) - 1;
       cand &= cand - 1u;
-      const int j = lo + q;
+      const int j = lo + q, je = lo_edge + q;
       const double2 va = ring[j], vb = ring[j + 1];
       const double ax = va.x - px, ay = va.y - py, bx = vb.x - px, by = vb.y - py;
       edge_hit(ax, ay, edge_side(ax, ay, dx, dy), bx, by, edge_side(bx, by, dx, dy), dx, dy,
-               j >= nr ? j - nr : j, h);
+               je >= nr ? je - nr : je, h);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// STAGED windows (round 4).  When the ring vertices live in global memory (the residency of full batches), a wave copies
+// the stretch of the ring its 64 lanes are about to scan -- kStage consecutive vertices from a chunk-aligned `base` --
+// into a wave-private LDS buffer with two LDS-DMA instructions (global_load_lds_dwordx4: lane t -> slot t, no VGPR
+// destination), and every lane whose window lies inside the stretch scans it from LDS.  The windows of 64 consecutive
+// samples span 8-9 chunk starts on a width-form ring (vertex i sits on sample i's normal), the stretch holds 9.  Lanes whose
+// window does not fit (seam, a hint far away) are served by re-staging from their own window start: ONE scan path, whatever
+// the hints.  Measured on the benchmarked batch (same box, interleaved, bit-identical results; tools/sweep_variant.py):
+// direct loads 9.66-9.88 ms, staged 9.48-9.75 ms (-1.5 %), vector-memory read instructions per launch 2.04e8 -> 0.96e8.
+// Requesting the stretches at the START of a step (before the cost pass, so that the refresh waits for no vertex at all)
+// was 2 % SLOWER than direct loads (9.88-10.02 ms): the step is not waiting for these loads.
+constexpr int kStage = 96;
+constexpr int kStageBatch = 4;   // LDS reads in flight per lane (the latency of an LDS read is a sixth of an L2 round trip)
+static_assert(kStage >= kWinEdges + 1 + 64 && kStage <= 104, "a stretch holds the windows of 64 consecutive chunk starts; two DMA instructions fill it");
+// LDS image of a stretch: vertex v of the stretch sits in slot v + (v >> 3) -- one empty 16-byte slot behind every chunk of 8.
+// The lanes of a wave scan windows that start 0, 8, 16, ... vertices into the stretch; unpadded, those starts are 128 bytes
+// apart and every second one falls on the same banks (measured: SQ_LDS_BANK_CONFLICT 34 % of the LDS cycles); padded, chunk c
+// starts 144 c bytes in: 0, 36, 8, 44, 16, ... dwords modulo 64 -- disjoint 4-bank groups.  The DMA writes slot t from lane t
+// (lane-linear destination), so the padding is made on the SOURCE side: lane t fetches the vertex whose slot is t.
+constexpr int kStageSlots = kStage + kStage / kChunk;   // 108
+__device__ __forceinline__ int stage_slot(int v) { return v + (v >> 3); }
+
+__device__ __forceinline__ void stage_issue(const double2* ring, int nr, int base, double2* stg, int lane) {
+#pragma unroll
+  for (int t0 = 0; t0 < kStageSlots; t0 += kWave) {
+    const int t = t0 + lane;                 // slot
+    if (t < kStageSlots) {
+      const int v = t - t / 9;               // the vertex of slot t (slots 8, 17, 26, ... are the pads: they fetch a neighbour)
+      int idx = base + (v < kStage ? v : kStage - 1);
+      if (idx >= nr) idx -= nr;              // (base + v) mod nr: base < nr and v < kStage <= nr (the caller checks)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ring + idx),
+                                       (__attribute__((address_space(3))) void*)(stg + t0), 16, 0, 0);
+    }
+  }
+}
+// a window inside a staged stretch: vertex k of the window (its start is chunk aligned) -> its padded slot
+struct StagedWindow {
+  const double2* p;   // slot of the window's first vertex
+  __device__ __forceinline__ double2 operator[](int k) const { return p[k + (k >> 3)]; }
+};
+// the stretch has landed and is visible to this wave's LDS reads
+__device__ __forceinline__ void stage_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// first edge of the chunk-aligned window around `hint` (an edge index < nr)
+__device__ __forceinline__ int window_start(int hint, int nchunk) {
+  int cs = hint / kChunk - 1;
+  if (cs < 0) cs += nchunk;
+  return cs * kChunk;
 }
 
 // brute force over all edges; ring vertices as double2 (x,y), any address space
@@ -347,23 +403,45 @@ __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>
 // with wave-uniform LDS addresses, every chunk some lane still needs.
 // Either way the result is the lexicographic minimum of (|s|, edge) over a set of edges that
 // contains every edge with a crossing not farther than the best one == search_ring_brute, bit for bit.
-template <typename RingPtr, typename CirclePtr>
+// STAGED: the window is scanned from the wave's LDS stretch `stg` (staged_base = first vertex of what it holds now, -1 =
+// nothing yet); `ring` is then the global ring (slow path and re-staging).
+template <bool STAGED = false, typename RingPtr, typename CirclePtr>
 __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, CirclePtr circ,
                                                     CirclePtr sep, int nchunk, bool active, int hint,
                                                     double px, double py, double dx, double dy,
                                                     double dlen, bool skip_guard = false,
-                                                    unsigned long long* stamps = nullptr) {
+                                                    unsigned long long* stamps = nullptr,
+                                                    double2* stg = nullptr, int staged_base = -1) {
   const int lane = threadIdx.x & (kWave - 1);
   Hit h{INFINITY, 0.0, kNoEdge};
   const bool windowed = active && hint >= 0 && hint < nr;
-  int cs = hint / kChunk - 1;  // first chunk of the window
-  if (cs < 0) cs += nchunk;
-  const int lo = cs * kChunk;  // first edge of the window (the lanes of one chunk read the same addresses)
+  const int lo = window_start(hint, nchunk);  // first edge of the window (the lanes of one chunk read the same addresses)
 #ifdef RL_STAMPS
   unsigned long long w0 = 0, w1 = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0) :: "memory");
 #endif
-  if (windowed) scan_window(ring, nr, lo, px, py, dx, dy, h);
+  if constexpr (!STAGED) {
+    if (windowed) scan_window(ring, nr, lo, lo, px, py, dx, dy, h);
+  } else {
+    bool todo = windowed;
+    int base = staged_base;
+    for (;;) {
+      if (base >= 0) {
+        int off = lo - base;
+        if (off < 0) off += nr;
+        if (todo && off + kWinEdges + 1 <= kStage) {
+          scan_window<kStageBatch>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h);
+          todo = false;
+        }
+      }
+      const unsigned long long left = __ballot(todo);
+      if (left == 0ull) break;
+      base = __builtin_amdgcn_readlane(lo, __ffsll((long long)left) - 1);   // the first unserved lane's window start
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // nobody still reads the stretch it replaces
+      stage_issue(reinterpret_cast<const double2*>(ring), nr, base, stg, lane);
+      stage_wait();
+    }
+  }
 #ifdef RL_STAMPS
   asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1) :: "memory");
   if (stamps) stamps[0] += w1 - w0;   // window scan (loads, sign pass, exact tests)

@@ -328,10 +328,15 @@ struct SweepArgs {
 // LDS carve (doubles).  cpad = n rounded up to even so every later array is 16-byte aligned.
 struct SweepLds {
   int cpad, nLp, nRp, ncL, ncR;
-  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, off_joint, total;
+  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, off_joint, off_stage, total;
 };
+constexpr int kSweepWaves = 4;   // waves of the 256-thread sweep workgroup (the staged stretches are per wave)
 
-__host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds, bool sigma_in_lds) {
+// joint: the sliding-window instantiation (its QP scratch and per-sample flags are carved only then).  With the rings in
+// global memory every wave gets two staged stretches (left / right ring, rl_device.hpp: kStage vertices each): at N = 2000
+// the workgroup then takes 39.5 KB -- four of them still fit a CU's 160 KB, which is what the batch size asks for.
+__host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds, bool sigma_in_lds,
+                                                     bool joint = false) {
   SweepLds L;
   L.cpad = (n + 1) & ~1;
   L.nLp = nL; L.nRp = nR;
@@ -340,21 +345,24 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   size_t o = 0;
   L.off_cx = o; o += L.cpad;
   L.off_cy = o; o += L.cpad;
-  L.off_red = o; o += 16 * 24 + 4;       // up to 16 waves x 24 partials + verdict
+  L.off_red = o; o += 8 * 24 + 4;        // up to 8 waves x 24 partials + verdict
   L.off_cL = o; o += (size_t)((3 * L.ncL + 1) & ~1);
   L.off_cR = o; o += (size_t)((3 * L.ncR + 1) & ~1);
   L.off_pL = o; o += (size_t)((L.ncL + 1) & ~1);
   L.off_pR = o; o += (size_t)((L.ncR + 1) & ~1);
-  L.off_joint = o; o += 128 + (size_t)((N + 15) / 16) * 2;  // joint variant: QP scratch + 1 byte per sample
+  L.off_joint = o; o += joint ? 128 + (size_t)((N + 15) / 16) * 2 : 0;  // joint variant: QP scratch + 1 byte per sample
   L.off_hint = o; o += (size_t)(((size_t)2 * ((N + 3) & ~3) * sizeof(unsigned short) + 15) / 16) * 2;  // u16 [2][Npad]
   L.off_sL = L.off_sR = L.off_rL = L.off_rR = 0;
   if (sigma_in_lds) {
     L.off_sL = o; o += (size_t)((N + 1) & ~1);
     L.off_sR = o; o += (size_t)((N + 1) & ~1);
   }
+  L.off_stage = 0;
   if (rings_in_lds) {
     L.off_rL = o; o += (size_t)2 * (nL + kRingPad);
     L.off_rR = o; o += (size_t)2 * (nR + kRingPad);
+  } else {
+    L.off_stage = o; o += (size_t)kSweepWaves * 2 * kStageSlots * 2;   // [wave][ring][kStageSlots] double2
   }
   L.total = o;
   return L;
@@ -367,7 +375,7 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
 constexpr int kSweepDumpHead = 16;
 
 template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false, bool SIGMA_LDS = RINGS_LDS>
-__global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 4 : 1) void k_sweep(SweepArgs a) {
+__global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS && !JOINT)) ? 4 : 1) void k_sweep(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
   const TrackDev& tr = a.tr;
@@ -376,7 +384,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 4 : 1) void k_sweep(SweepArgs
   const int tid = threadIdx.x;
   const int lane = tid % kWave, wave = tid / kWave;
   constexpr int NW = BLOCK / kWave;
-  const SweepLds L = sweep_lds_layout(n, N, a.nL, a.nR, RINGS_LDS, SIGMA_LDS);
+  const SweepLds L = sweep_lds_layout(n, N, a.nL, a.nR, RINGS_LDS, SIGMA_LDS, JOINT);
+  // staged windows: rings in global memory, four waves (the eight-wave ablation variant keeps the direct loads)
+  constexpr bool STAGED = !RINGS_LDS && BLOCK == 64 * kSweepWaves;
+  double2* stgL = reinterpret_cast<double2*>(smem + L.off_stage) + (STAGED ? wave * 2 * kStageSlots : 0);
+  double2* stgR = stgL + kStageSlots;
   double* cx = smem + L.off_cx;
   double* cy = smem + L.off_cy;
   double* red = smem + L.off_red;
@@ -555,18 +567,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 4 : 1) void k_sweep(SweepArgs
         const bool skip = RL_ABLATE(a, 2);
 #ifdef RL_STAMPS
         unsigned long long ws[2] = {0, 0};
-        const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
-                                            dx, dy, a.max_dist, skip, ws);
+        const Hit hl = search_ring_windowed<STAGED>(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
+                                                    dx, dy, a.max_dist, skip, ws, stgL);
         RL_FSTAMP(1);
-        const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
-                                            c.y, -dx, -dy, a.max_dist, skip, ws);  // yaw - pi/2
+        const Hit hr = search_ring_windowed<STAGED>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
+                                                    c.y, -dx, -dy, a.max_dist, skip, ws, stgR);  // yaw - pi/2
         RL_FSTAMP(2);
         st_fine[4] += ws[0];
 #else
-        const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
-                                            dx, dy, a.max_dist, skip);
-        const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
-                                            c.y, -dx, -dy, a.max_dist, skip);  // yaw - pi/2
+        const Hit hl = search_ring_windowed<STAGED>(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
+                                                    dx, dy, a.max_dist, skip, nullptr, stgL);
+        const Hit hr = search_ring_windowed<STAGED>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
+                                                    c.y, -dx, -dy, a.max_dist, skip, nullptr, stgR);  // yaw - pi/2
 #endif
         if (active) {
           sL[i] = hl.best_s;
@@ -615,7 +627,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? 4 : 1) void k_sweep(SweepArgs
   };
 
   // the windowed mode needs rings longer than its window and edge indices that fit 16 bits
-  const int mode = (a.search == 2 && nL > 2 * kWinEdges && nR > 2 * kWinEdges && nL < 0xFFFF && nR < 0xFFFF) ? 2
+  const int mode = (a.search == 2 && nL > 2 * kWinEdges && nR > 2 * kWinEdges && nL < 0xFFFF && nR < 0xFFFF &&
+                    (!STAGED || (nL >= kStage && nR >= kStage))) ? 2
                    : (a.search >= 1 ? 1 : 0);
   if (mode == 2 && a.form != 0) {
     // rings built from per-sample widths / bound points: vertex i sits on sample i's normal

@@ -253,7 +253,7 @@ struct SweepPlan {
   int block;
 };
 
-SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B) {
+SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, bool joint = false) {
   SweepPlan p;
   p.block = 256;
   // Residency of the per-instance state (ring vertices 16 B x (nL + nR), crossings 8 B x 2N):
@@ -268,15 +268,15 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B) {
   int want = B >= 2 * ctx->num_cu ? 0 : 1;    // 0 all global, 1 all LDS, 2 crossings in LDS
   if (force && (force[0] == '0' || force[0] == '1')) want = force[0] == '1' ? 0 : 1;
   if (const char* r = getenv("RL_FORCE_RESIDENCY")) if (r[0] >= '0' && r[0] <= '2') want = r[0] - '0';
-  rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true, true);
+  rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true, true, joint);
   if (want == 1 && in.total * sizeof(double) > (size_t)ctx->max_lds) want = 0;
   if (want == 2) {
-    rl::SweepLds mid = rl::sweep_lds_layout(n, N, nL, nR, false, true);
+    rl::SweepLds mid = rl::sweep_lds_layout(n, N, nL, nR, false, true, joint);
     if (mid.total * sizeof(double) > (size_t)ctx->max_lds) want = 0;
   }
   p.rings_in_lds = want == 1;
   p.sigma_in_lds = want != 0;
-  rl::SweepLds L = rl::sweep_lds_layout(n, N, nL, nR, p.rings_in_lds, p.sigma_in_lds);
+  rl::SweepLds L = rl::sweep_lds_layout(n, N, nL, nR, p.rings_in_lds, p.sigma_in_lds, joint);
   p.lds_bytes = L.total * sizeof(double);
   p.gscratch_doubles = (p.sigma_in_lds ? 0 : (size_t)2 * ((N + 1) & ~1)) +
                        (p.rings_in_lds ? 0 : (size_t)2 * (nL + rl::kRingPad) + (size_t)2 * (nR + rl::kRingPad));
@@ -719,11 +719,11 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_points = out_points;
   a.n_success = n_success; a.status = status;
   RL_HIP(hipSetDevice(ctx->device));
-  SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR, B);
+  SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR, B, joint);
   if (p.lds_bytes > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "problem does not fit LDS");
   if (p.sigma_in_lds && !p.rings_in_lds && (joint || k != 5 || a.dbg)) {   // the mixed residency exists for the k = 5 sweep only
     p.sigma_in_lds = false;
-    p.lds_bytes = rl::sweep_lds_layout(n, N, a.nL, a.nR, false, false).total * sizeof(double);
+    p.lds_bytes = rl::sweep_lds_layout(n, N, a.nL, a.nR, false, false, joint).total * sizeof(double);
     p.gscratch_doubles += (size_t)2 * ((N + 1) & ~1);
   }
   if (p.gscratch_doubles) {
