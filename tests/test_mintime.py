@@ -463,7 +463,8 @@ def test_cli_lines_against_the_facade(tmp_path):
     # the yaml's tolerance (0.1) is IPOPT's SCALED NLP error; the facade maps it onto the solver's absolute KKT tolerance
     # (min(tol, 1e-4)) and says so: a user running the stock yaml gets the optimum, not a lap stopped seconds short of it
     st0 = opti.stats()
-    assert st0["requested_tol"] == defaults.SOLVER["tol"] and st0["effective_tol"] == min(defaults.SOLVER["tol"], optm.IPOPT_TOL_CAP)
+    from spline_trajectory_optimization_amd.min_time_optm.min_time_optimizer import IPOPT_TOL_CAP
+    assert st0["requested_tol"] == defaults.SOLVER["tol"] and st0["effective_tol"] == min(defaults.SOLVER["tol"], IPOPT_TOL_CAP)
     assert max(st0["dual_inf"], st0["constr_viol"], st0["compl"]) <= st0["effective_tol"]
     # a second solve from that point at 1e-6: the yaml-settings lap is within 0.1 % of it (measured: 1e-3 s of 46.7 s)
     with pytest.warns(RuntimeWarning, match="without a counterpart"):
