@@ -1168,6 +1168,30 @@ __device__ __forceinline__ double ppoly_eval(const double* __restrict__ xb, cons
   return res;
 }
 
+// The same look-up for a table of at most two pieces held in REGISTERS (the reference's vehicles: three look-up points, two
+// cubic pieces): no LDS round trips on the dependent chain of a front step.  Same operations in the same order as ppoly_eval.
+struct Ppoly2 {
+  double x0, x1, brk;        // breakpoints of piece 0 / 1, and the value from which piece 1 applies (+inf for one piece)
+  double c0[4], c1[4];       // c[0] x^3 + c[1] x^2 + c[2] x + c[3] per piece (scipy's order)
+  __device__ __forceinline__ void load(const double* xb, const double* c, int m) {
+    x0 = xb[0]; x1 = m > 1 ? xb[1] : xb[0]; brk = m > 1 ? xb[1] : INFINITY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c0[q] = c[q * m]; c1[q] = m > 1 ? c[q * m + 1] : c[q * m]; }
+  }
+  __device__ __forceinline__ double eval(double x) const {
+#pragma clang fp contract(off)
+    const bool hi = x >= brk;
+    const double s = x - (hi ? x1 : x0);
+    double res = 0.0, z = 1.0;
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+      res = res + (hi ? c1[3 - kp] : c0[3 - kp]) * z;
+      if (kp < 3) z *= s;
+    }
+    return res;
+  }
+};
+
 __device__ __forceinline__ double qss_acc_circle_lon(const QssArgs& a, double lon) {
 #pragma clang fp contract(off)
   lon = lon < a.max_lon_dcc ? a.max_lon_dcc : (lon > a.max_lon_acc ? a.max_lon_acc : lon);  // np.clip
@@ -1197,7 +1221,17 @@ __device__ __forceinline__ double qss_lat_acc(double v, double r, double bank) {
 // stop without writing (the common case) never conflict, and chains of actual writes degrade to the
 // sequential order.  Spawned fronts are appended in list order (ballot prefix) and finished fronts
 // compacted away by all lanes at the end of each global iteration.
-constexpr int kQssStamp = 1024;  // stamp buckets (point index mod 1024): a shared bucket only costs a false conflict
+// Round 4: the commit rule is no longer "the prefix before the first conflicted lane".  A lane BEHIND the first conflicted one
+// commits in the same round when (a) no earlier lane actually writes its source or target this round (the dynamic test above)
+// and (b) it is STATICALLY independent of every still-pending lane between the first conflicted one and itself: none of
+// them targets its source or target point, none of them reads (as source or target) the point it writes -- positions only,
+// whatever those lanes will decide when they are re-run.  Several trains of adjacent fronts inside one 64-front chunk then
+// advance together (rounds per chunk = the longest train, not the sum of the trains); a single train is still one front per
+// round.  List-order semantics are untouched: (b) is exactly "swapping this front with the pending ones before it changes
+// nothing", and spawned fronts are appended per chunk in lane order after the chunk has drained.
+constexpr int kQssStamp = 1024;  // stamp words: [0,512) actual writers, [512,768) potential targets, [768,1024) sources (index mod table size: a shared bucket only costs a false conflict)
+constexpr int kQssWr = 512, kQssSt = 256;
+constexpr int kQssStaticMin = 4;   // fronts still pending after a chunk's first round from which the static mode pays for its set-up
 __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
 #pragma clang fp contract(off)  // decisions below compare freshly computed speeds: keep the reference's roundings
   extern __shared__ double qss_lds[];
@@ -1241,6 +1275,9 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
     fE[i] = i; fT[i] = i; fX[i] = i; sE[i] = 0; sX[i] = 0;
   }
   __syncthreads();
+  const bool small_tabs = a.acc_m <= 2 && a.dcc_m <= 2;   // wave-uniform
+  Ppoly2 pa2, pd2;
+  pa2.load(t_ax, t_ac, a.acc_m < 2 ? 1 : 2); pd2.load(t_dx, t_dc, a.dcc_m < 2 ? 1 : 2);   // (read within bounds for any m >= 1; used only when small_tabs)
   int nf = N, itr = 0, err = 0;
   while (true) {
     int nnew = 0;
@@ -1258,8 +1295,19 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
         double dd = 0.0, rn = 0.0, gsn = 0.0;
         if (active) { dd = SEG[side == 0 ? li : ni]; rn = RAD[ni]; gsn = GS[ni]; }
         unsigned long long pending = __ballot(active);
+        int* WR = STAMP; int* ST = STAMP + kQssWr; int* SS = ST + kQssSt;
+        const int b_li = li & (kQssSt - 1), b_ni = ni & (kQssSt - 1);   // this front's static buckets (positions are fixed within a chunk)
+        bool my_spawn = false;
+        // A chunk starts in the SPECULATIVE mode (stamps, above).  If fronts are still pending after its first round -- trains --
+        // it switches to the STATIC mode: every pending lane's dependencies on the earlier pending lanes of the chunk are
+        // worked out once from the positions (exact, no buckets: lane j < k blocks k iff j targets k's source or target or k
+        // targets j's source), and from then on a round is: the lanes none of whose blockers is still pending compute and
+        // commit -- no stamps, no atomics, one LDS fence per round instead of five.
+        bool static_mode = false;
+        unsigned long long dep = 0ull;
         while (pending != 0ull && !err) {
-          const bool mine = (pending >> lane) & 1ull;
+          const bool pend = (pending >> lane) & 1ull;
+          const bool mine = pend && (!static_mode || (dep & pending) == 0ull);
           int new_stop = 0, e = 0, spawned = 0, wr = 0, nown = 0;
           double nv = 0.0, na = 0.0;
           if (mine) {
@@ -1269,8 +1317,8 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
               const double dt = dd / lv;
               const double max_dacc = dt * a.max_jerk;
               double max_acc = la + max_dacc, min_acc = la - max_dacc;
-              const double vmax_acc = ppoly_eval(t_ax, t_ac, a.acc_m, lv);
-              const double vmax_dcc = ppoly_eval(t_dx, t_dc, a.dcc_m, lv);
+              const double vmax_acc = small_tabs ? pa2.eval(lv) : ppoly_eval(t_ax, t_ac, a.acc_m, lv);
+              const double vmax_dcc = small_tabs ? pd2.eval(lv) : ppoly_eval(t_dx, t_dc, a.dcc_m, lv);
               max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
               min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
               double min_state, max_state;
@@ -1305,28 +1353,77 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
                 }
               }
             }
-            if (wr) atomicMin(&STAMP[ni & (kQssStamp - 1)], lane);
+            if (wr && !static_mode) atomicMin(&WR[ni & (kQssWr - 1)], lane);
+          }
+          if (static_mode) {
+            // every lane that computed is independent of every pending lane before it: commit
+            if (mine) {
+              if (wr) { V[ni] = nv; A[ni] = na; OWN[ni] = (unsigned short)nown; }
+              li = ni;
+              if (new_stop != 0) my_stop = new_stop;
+              if (spawned) my_spawn = true;
+            }
+            if (__any(mine && e)) err = 1;
+            pending &= ~__ballot(mine);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            continue;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           bool confl = false;
-          if (mine) { const int s1 = STAMP[li & (kQssStamp - 1)], s2 = STAMP[ni & (kQssStamp - 1)]; confl = (s1 < s2 ? s1 : s2) < lane; }
+          if (mine) { const int s1 = WR[li & (kQssWr - 1)], s2 = WR[ni & (kQssWr - 1)]; confl = (s1 < s2 ? s1 : s2) < lane; }
           const unsigned long long cm = __ballot(confl);
           const int qstar = cm != 0ull ? __ffsll((long long)cm) - 1 : 64;
-          const bool commit = mine && lane < qstar;
+          bool commit = mine && lane < qstar;
+          // ---- lanes behind the first conflicted one: static independence of the pending lanes in [qstar, lane)
+          const bool behind = mine && lane >= qstar;
+          if (__any(behind && lane > qstar)) {      // wave-uniform; rounds without a conflict skip all of this
+            if (behind) { atomicMin(&ST[b_ni], lane); atomicMin(&SS[b_li], lane); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (behind && !confl) {
+              // no earlier pending lane targets my source or my target, none reads what I write as its source
+              // (an earlier lane with the same target is an earlier target of my target: first test)
+              const bool clear = ST[b_ni] >= lane && ST[b_li] >= lane && SS[b_ni] >= lane;
+              commit = clear;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (behind) { ST[b_ni] = kFree; SS[b_li] = kFree; }
+          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (mine && wr) STAMP[ni & (kQssStamp - 1)] = kFree;
+          if (mine && wr) WR[ni & (kQssWr - 1)] = kFree;
           if (commit) {
             if (wr) { V[ni] = nv; A[ni] = na; OWN[ni] = (unsigned short)nown; }
-            li = ni;
-            ni = side == 0 ? (li - 1 < 0 ? N - 1 : li - 1) : (li + 1 == N ? 0 : li + 1);  // unused: one step per sub-pass
+            li = ni;   // (ni is not advanced: one step per sub-pass)
             if (new_stop != 0) my_stop = new_stop;
+            if (spawned) my_spawn = true;
           }
           if (__any(commit && e)) err = 1;
-          const unsigned long long sm = __ballot(commit && spawned);
-          if (commit && spawned) {
+          pending &= ~__ballot(commit);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (__popcll(pending) >= kQssStaticMin) {
+            // trains: switch to the static mode.  One pass over the pending lanes j; lane k > j records j as a blocker.
+            const bool still = (pending >> lane) & 1ull;
+            for (unsigned long long m = pending; m != 0ull; m &= m - 1ull) {
+              const int j = __ffsll((long long)m) - 1;
+              const int lj = __builtin_amdgcn_readlane(li, j), nj = __builtin_amdgcn_readlane(ni, j);
+              if (still && lane > j && (nj == li || nj == ni || lj == ni)) dep |= 1ull << j;
+            }
+            static_mode = true;
+          }
+        }
+        // spawned fronts of this chunk, appended in list (= lane) order whatever round they committed in
+        {
+          const unsigned long long sm = __ballot(my_spawn);
+          if (my_spawn) {
             const int idx = nnew + __popcll(sm & ((1ull << lane) - 1ull));
             if (nf + idx < cap) nw[idx] = li;
           }
@@ -1334,10 +1431,6 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
           // the reference appends without limit; a full front list here is reported like a raised error
           // (iters = -1) rather than dropping fronts and returning a different profile
           if (nf + nnew > cap) { nnew = cap - nf; err = 1; }
-          pending &= ~__ballot(commit);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (in && active) { pos[f] = li; stp[f] = my_stop; }
       }
