@@ -45,7 +45,7 @@ FILTER = 8
 TH_FILTER = 1e-4
 DUAL_CAP = 1.0
 MU_KAPPA = 30.0                                   # the barrier problem counts as solved at MU_KAPPA * mu
-D_DOWN, D_UP, A_HI, A_LO = 0.4, 3.0, 0.9, 0.2     # Levenberg parameter x D_DOWN after a step > A_HI, x D_UP after one <= A_LO
+D_DOWN, D_UP, A_HI, A_LO = 0.4, 3.0, 0.25, 0.1    # Levenberg parameter x D_DOWN after a step > A_HI, x D_UP after one <= A_LO (round 4: 0.9 / 0.2 before)
 THETA_FLOOR = 1e-5     # ... above 1e-5 per row (next to a feasible point twice nothing is nothing)   # a step may not more than double the l1 infeasibility, whatever it does to the objective
 # reduced variable a -> (array, column): X cols 1..5, U cols 0,2,3, T
 _XCOL = [1, 2, 3, 4, 5]

@@ -1,5 +1,5 @@
 """Helper of test_mintime.py: solve the coarse MGKT problem for a few iterations in THIS process (whose environment
-selects the Hessian implementation of the library) and save the iterate.   python mintime_run.py out.npz iterations [node spacing, m]"""
+selects the Hessian implementation of the library) and save the iterate.   python mintime_run.py out.npz iterations [node spacing, m] [tol]"""
 import os
 import sys
 
@@ -17,5 +17,5 @@ P = tw.Problem(defaults.MODEL, d["s"], d["kappa"], d["left"], d["right"], d["L"]
                defaults.SOLVER["speed_cap"])
 X0, U0, T0 = P.unpack(tw.initial_point(P, d["speed"], d["seg_time"]))
 X, U, T, st = ops.mintime_solve_batch(P.m, P.s, P.kappa, P.left, P.right, P.margin, P.L, X0[None], U0[None], T0[None],
-                                      max_iter=int(sys.argv[2]), tol=1e-12)
+                                      max_iter=int(sys.argv[2]), tol=float(sys.argv[4]) if len(sys.argv) > 4 else 1e-12)
 np.savez(sys.argv[1], X=X, U=U, T=T, st=st)
