@@ -550,12 +550,18 @@ def run_rank(args):
         if gather_check is not None:
             res["gather_check"] = gather_check
         if world == 1 and args.workload == "monza" and not args.no_global:
-            res["global_qp"] = global_qp_leg(groups[0]["trk"], groups[0]["d_widths"], groups[0], args, torch,
-                                             with_cpu=not args.no_cpu_baseline)
+            try:      # a failing secondary leg is reported in the line, it does not take the headline with it
+                res["global_qp"] = global_qp_leg(groups[0]["trk"], groups[0]["d_widths"], groups[0], args, torch,
+                                                 with_cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                res["global_qp"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.workload == "monza" and not args.no_mintime:
             res["mintime_nlp"] = mintime_leg(args.mintime_batch, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
+            try:
+                res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
+            except Exception as e:
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         if ref_run:
             per = {d_["instance"]: d_ for d_ in res.get("cpu_baseline", {}).get("gpu_vs_oracle", {}).get("per_instance", [])}
             res["gpu_vs_reference_run"] = {
