@@ -1149,6 +1149,9 @@ struct QssArgs {
   // The lookup tables BY VALUE (acc_x [m+1], acc_c [4m], dcc_x [m'+1], dcc_c [4m'] back to back) when they fit: the
   // launch then reads no host memory after the call returns.  tab_n = 0: the four pointers above are device arrays.
   int tab_n;
+  int* dbg;              // optional [B][12]: passes, chunks, examinations, steps, wake pushes, numbering events, spawned fronts, bail reason
+  int df_bail_at;        // k_qss_df only, tests: hand the instance back once a step of this iteration has run (0: never)
+  int redo;              // k_qss_sim only: 1 = run just the instances k_qss_df handed back (iters[b] == -2)
   double tab[kQssTabMax];
 };
 
@@ -1236,6 +1239,7 @@ __global__ __launch_bounds__(64) void k_qss_sim(QssArgs a) {
 #pragma clang fp contract(off)  // decisions below compare freshly computed speeds: keep the reference's roundings
   extern __shared__ double qss_lds[];
   const int b = blockIdx.x, N = a.N, lane = threadIdx.x, cap = a.cap;
+  if (a.redo && a.iters[b] != -2) return;
   double* P = a.points + (size_t)b * N * 19;
   double* V = qss_lds;             // [N] SPEED
   double* A = qss_lds + N;         // [N] LON_ACC

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "rl_kernels.hpp"
+#include "rl_qss_df.hpp"
 #include "rl_global.hpp"
 #include "rl_global2.hpp"
 #include "rl_dtrack.hpp"
@@ -1018,7 +1019,8 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   a.max_lon_acc = params[0]; a.max_lon_dcc = params[1]; a.max_left_acc = params[2];
   a.max_right_acc = params[3]; a.max_speed = params[4]; a.max_jerk = params[5];
   a.flags = dfl; a.fresh = dnw; a.cst = dcst; a.cap = cap; a.iters = iters;
-  a.tab_n = 0;
+  a.tab_n = 0; a.redo = 0; a.dbg = nullptr; a.df_bail_at = 0;
+  if (const char* ba = getenv("RL_QSS_DF_BAIL_AT")) a.df_bail_at = atoi(ba);
   if (by_value) {
     double* q = a.tab;
     for (int i = 0; i <= acc_m; ++i) *q++ = acc_x[i];
@@ -1026,6 +1028,39 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     for (int i = 0; i <= dcc_m; ++i) *q++ = dcc_x[i];
     for (int i = 0; i < 4 * dcc_m; ++i) *q++ = dcc_c[i];
     a.tab_n = tab_n;
+  }
+  // The dataflow kernel takes the sizes its LDS tables hold; what it hands back (iters = -2: front or iteration counts beyond its
+  // tables) is re-run by the list-order kernel right behind it, which returns at once for every other instance.
+  // Which kernel: the dataflow kernel holds one instance per CU (its tables fill the LDS) and finishes it several times sooner;
+  // the list-order kernel holds four per CU.  Up to two instances per CU the dataflow kernel is the faster one for the whole
+  // call (measured); RL_QSS_DF=1 / 0 forces one or the other (tests run both).
+  const char* v1 = getenv("RL_QSS_V1");
+  const char* fdf = getenv("RL_QSS_DF");
+  bool use_df = B <= 2 * ctx->num_cu;
+  if (fdf && (fdf[0] == '0' || fdf[0] == '1')) use_df = fdf[0] == '1';
+  if (v1 && v1[0] == '1') use_df = false;
+  use_df = use_df && rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
+  if (use_df) {
+    const size_t lds_df = rl::df_layout(N, acc_m, dcc_m).bytes;
+    RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_df), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+    const char* dbg = getenv("RL_QSS_DEBUG");
+    int* ddbg = nullptr;
+    if (dbg && dbg[0] == '1') { RL_HIP(hipMalloc(&ddbg, (size_t)B * 12 * sizeof(int))); a.dbg = ddbg; }
+    hipLaunchKernelGGL(rl::k_qss_df, dim3(B), dim3(64), lds_df, ctx->stream, a);
+    RL_HIP(hipGetLastError());
+    if (ddbg) {   // diagnostics only: synchronous
+      std::vector<int> hd((size_t)B * 12);
+      RL_HIP(hipStreamSynchronize(ctx->stream));
+      RL_HIP(hipMemcpy(hd.data(), ddbg, hd.size() * sizeof(int), hipMemcpyDeviceToHost));
+      RL_HIP(hipFree(ddbg));
+      long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int handed = 0;
+      for (int i = 0; i < B; ++i) { for (int q = 0; q < 8; ++q) tot[q] += hd[(size_t)i * 12 + q]; handed += hd[(size_t)i * 12 + 7] != 0; }
+      fprintf(stderr, "k_qss_df: B=%d N=%d lds=%zu  per instance: passes %.0f chunks %.0f examinations %.0f steps %.0f longest queue %.0f numberings %.0f spawned %.0f; handed back %d (reason of instance 0: %d)\n",
+              B, N, lds_df, (double)tot[0] / B, (double)tot[1] / B, (double)tot[2] / B, (double)tot[3] / B, (double)tot[4] / B, (double)tot[5] / B, (double)tot[6] / B, handed, hd[7]);
+      fprintf(stderr, "k_qss_df: instance 0, kilo-ticks of clock64 (100 MHz): examination %d, step %d, records + wake %d, end of pass %d\n", hd[8], hd[9], hd[10], hd[11]);
+      a.dbg = nullptr;
+    }
+    a.redo = 1;
   }
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_sim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(rl::k_qss_sim, dim3(B), dim3(64), lds, ctx->stream, a);

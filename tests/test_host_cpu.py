@@ -314,3 +314,16 @@ def test_set_up_double_track_problem_returns_the_reference_contract():
         with pytest.raises(Exception, match="no HIP device|librl_mincurv"):
             opti.solve()
         assert opti.stats()["success"] is False
+
+
+def test_qss_dataflow_schedule_model():
+    """tests/qss_schedule_model.py: the readiness rules of k_qss_df replayed on step logs of the sequential oracle -- every step
+    released only after all its true dependencies, progress in every pass, spawned fronts numbered in list order (the small
+    cases here; 24 trajectories up to N = 2000 when the kernel was written)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "qss_schedule_model.py"), "4", "24", "small"], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "no violation" in out.stdout and out.stdout.count("case ") >= 2, out.stdout[-1500:] + out.stderr[-1500:]
