@@ -1031,15 +1031,23 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   }
   // The dataflow kernel takes the sizes its LDS tables hold; what it hands back (iters = -2: front or iteration counts beyond its
   // tables) is re-run by the list-order kernel right behind it, which returns at once for every other instance.
-  // Which kernel: the dataflow kernel holds one instance per CU (its tables fill the LDS) and finishes it several times sooner;
-  // the list-order kernel holds four per CU.  Up to two instances per CU the dataflow kernel is the faster one for the whole
-  // call (measured); RL_QSS_DF=1 / 0 forces one or the other (tests run both).
+  // Which kernel: the dataflow kernel finishes an instance ~3.5 times sooner but its tables fill the LDS (one instance per CU at
+  // N = 2000, three at N = 500), the list-order kernel holds four and more per CU.  Compare the number of ROUNDS the batch
+  // takes on the chip (measured, DESIGN.md 3c: N = 2000, B <= 768 dataflow, 1024 list order); RL_QSS_DF=1 / 0 forces one or
+  // the other (tests run both).
   const char* v1 = getenv("RL_QSS_V1");
   const char* fdf = getenv("RL_QSS_DF");
-  bool use_df = B <= 2 * ctx->num_cu;
-  if (fdf && (fdf[0] == '0' || fdf[0] == '1')) use_df = fdf[0] == '1';
+  bool use_df = rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
+  if (use_df) {
+    const long long per_cu_df = (long long)((size_t)ctx->max_lds / rl::df_layout(N, acc_m, dcc_m).bytes);
+    long long per_cu_list = (long long)((size_t)ctx->max_lds / lds);
+    per_cu_list = per_cu_list > 8 ? 8 : per_cu_list;
+    const long long cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
+    const long long rounds_df = (B + per_cu_df * cus - 1) / (per_cu_df * cus), rounds_list = (B + per_cu_list * cus - 1) / (per_cu_list * cus);
+    use_df = rounds_df <= 3 * rounds_list;
+  }
+  if (fdf && (fdf[0] == '0' || fdf[0] == '1')) use_df = fdf[0] == '1' && rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
   if (v1 && v1[0] == '1') use_df = false;
-  use_df = use_df && rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
   if (use_df) {
     const size_t lds_df = rl::df_layout(N, acc_m, dcc_m).bytes;
     RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_df), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
@@ -1057,7 +1065,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
       for (int i = 0; i < B; ++i) { for (int q = 0; q < 8; ++q) tot[q] += hd[(size_t)i * 12 + q]; handed += hd[(size_t)i * 12 + 7] != 0; }
       fprintf(stderr, "k_qss_df: B=%d N=%d lds=%zu  per instance: passes %.0f chunks %.0f examinations %.0f steps %.0f longest queue %.0f numberings %.0f spawned %.0f; handed back %d (reason of instance 0: %d)\n",
               B, N, lds_df, (double)tot[0] / B, (double)tot[1] / B, (double)tot[2] / B, (double)tot[3] / B, (double)tot[4] / B, (double)tot[5] / B, (double)tot[6] / B, handed, hd[7]);
-      fprintf(stderr, "k_qss_df: instance 0, kilo-ticks of clock64 (100 MHz): examination %d, step %d, records + wake %d, end of pass %d\n", hd[8], hd[9], hd[10], hd[11]);
+      fprintf(stderr, "k_qss_df: instance 0, thousands of clock64 ticks: examination %d, step %d, records + wake %d, end of pass %d\n", hd[8], hd[9], hd[10], hd[11]);
       a.dbg = nullptr;
     }
     a.redo = 1;

@@ -20,15 +20,26 @@
 //     [gmin, gmin + kDfR] so that every range is at most 64 worldlines wide.  The logically earliest pending step is never
 //     blocked, so there is always progress; steps that are ready at the same time never conflict with each other.
 //   * blocked agents sleep on the worldline (or the window) that blocks them and are re-examined when that worldline's agent
-//     steps or dies: about 2.5 examinations per step instead of one per agent per round.
+//     steps or dies; an agent that has just stepped goes to sleep at once on the neighbour that blocks its next step (the usual
+//     case in a train): 1.5 examinations per step instead of one per agent per round.
+//   * iteration 0 runs in list order first (its enter sub-pass is conflict-free, its exit sub-pass is taken a chunk at a time):
+//     under the dataflow rules a front would have to wait for the front before it even where that one turns out to stop
+//     without writing -- one chain through all N fronts, which delays every later iteration too.
+//   * the one rule that concerns fronts NOT YET BORN (an enter agent that lags far behind could still spawn a front whose exit
+//     side would have had to run before mine) never fires on real profiles but would cost a scan of up to 45 worldlines per
+//     examination; it is answered from lower bounds of 2 g - w per block of four enter worldlines, which only grow (so need no
+//     ordering among the lanes that refresh them) and cannot raise a false alarm by what lies beyond the range asked about.
 //
-// tools/qss_schedule_model.py is the executable specification of the rules below: it replays a step log of the sequential
-// oracle under this scheduler and checks every executed step against the TRUE read/write dependencies of the sequential order
-// (24 random trajectories, N = 257 ... 2000, banked and not, two vehicles: no violation, no deadlock, spawn numbering equal).
-// Monza N = 2000: 217 k steps in ~6 k passes of ~2 chunks (the sequential order: 130 k rounds).
+// tests/qss_schedule_model.py is the executable specification of the rules below: it replays a step log of the sequential
+// oracle under this scheduler and checks every released step against the TRUE read/write dependencies of the sequential order
+// (24 random trajectories, N = 257 ... 2000, banked and not, two vehicles: no violation, no pass without progress, spawned
+// fronts numbered as in the reference's list).  Monza N = 2000: 213 k steps after iteration 0 in 3 686 passes of 1.9 chunks
+// (the list order: 130 k rounds); one trajectory 180 -> 48 ms on the GPU (profiles/r04_qss_*).
 //
-// One wave per instance; everything a step or a test touches lives in LDS.  Instances whose size or front count exceeds the
-// tables report iters = -2 and are re-run by k_qss_sim (launched right behind, a no-op for every other instance).
+// One wave per instance; everything a step or a test touches lives in LDS (160 KB at N = 2000: one instance per CU, which is
+// why rl_qss_sim_dev keeps k_qss_sim -- four instances per CU -- for batches of more than two instances per CU).  Instances
+// whose size or front count exceeds the tables report iters = -2 and are re-run by k_qss_sim (launched right behind, a no-op
+// for every other instance).
 #pragma once
 #include "rl_kernels.hpp"
 
@@ -61,7 +72,7 @@ __host__ __device__ inline DfLayout df_layout(int N, int acc_m, int dcc_m) {
   L.o_hX = take((size_t)N * 2); L.o_sG = take((size_t)N * 2); L.o_sId = take((size_t)N * 2); L.o_sRec = take((size_t)N * 2);
   L.o_xg = take((size_t)L.HX * 2); L.o_xid = take((size_t)L.HX * 2); L.o_xt = take((size_t)L.HX * 2);
   L.o_xn = take((size_t)L.HX * 2); L.o_xw = take((size_t)L.HX * 2);
-  L.o_WN = take((size_t)L.QC * 2); L.o_pfx = take((size_t)(kDfIdMax / 64) * 2); L.o_blk = take((size_t)(L.NB + 2) * 2);
+  L.o_WN = take((size_t)L.QC * 2); L.o_pfx = take((size_t)(kDfIdMax / 64) * 2); L.o_blk = take((size_t)((N + 3) / 4 + 8) * 2);
   L.o_Q = take((size_t)L.QC * 2); L.o_Q2 = take((size_t)L.QC * 2);
   L.bytes = o;
   return L;
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
   u16* xw = reinterpret_cast<u16*>(lds + L.o_xw);                  //   worldline
   u16* WN = reinterpret_cast<u16*>(lds + L.o_WN);                  // wait-list links, by agent handle
   u16* PFX = reinterpret_cast<u16*>(lds + L.o_pfx);
-  u16* BLK = reinterpret_cast<u16*>(lds + L.o_blk);                // lower bound of the enter agents' g per block of 64 worldlines
+  u16* KAP = reinterpret_cast<u16*>(lds + L.o_blk);                // per block of 4 enter worldlines: a lower bound of min (2 g - w) + N over its agents
   u16* Q = reinterpret_cast<u16*>(lds + L.o_Q);
   u16* Q2 = reinterpret_cast<u16*>(lds + L.o_Q2);
   const int HX = L.HX, NB = L.NB;
@@ -168,20 +179,14 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
     gE[i] = 0; idE[i] = (u16)i; tE[i] = (u16)i;
     hX[i] = (u16)i; sG[i] = 0; sId[i] = (u16)i; sRec[i] = (u16)i;
     xg[i] = 0; xid[i] = (u16)i; xt[i] = (u16)i; xn[i] = (u16)kDfNone; xw[i] = (u16)i;
-    // Front 0 starts; every other agent is blocked by its neighbour of the same iteration with the smaller id (the enter agent
-    // one sample behind has not read the sample this one writes; the exit agent one sample behind writes the sample this one
-    // reads) and sleeps on that neighbour's worldline from the start.
-    if (i > 0) { WH[i - 1] = (unsigned)i; WH[N + i - 1] = (unsigned)(N + i); }
     WN[i] = (u16)kDfNone; WN[N + i] = (u16)kDfNone;
   }
-  if (lane == 0) { Q[0] = 0; Q[1] = (u16)N; }
   for (int i = N + lane; i < HX; i += 64) xn[i] = (u16)(i + 1 < HX ? i + 1 : kDfNone);   // free records
   for (int i = lane; i < L.NW; i += 64) {
     const int lo = i * 64;
     const u64 m = lo >= N ? 0ull : (N - lo >= 64 ? ~0ull : ((1ull << (N - lo)) - 1ull));
     bmE[i] = m; bmX[i] = m;
   }
-  for (int i = lane; i < NB + 2; i += 64) BLK[i] = 0;
   for (int i = lane; i < kDfCnt; i += 64) { cntE[i] = i == 0 ? N : 0; cntX[i] = i == 0 ? N : 0; bcnt[i] = 0; }
   if (lane < 16) scal[lane] = 0;
   __syncthreads();
@@ -189,15 +194,139 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
   Ppoly2 pa2, pd2;
   pa2.load(t_ax, t_ac, a.acc_m < 2 ? 1 : 2); pd2.load(t_dx, t_dc, a.dcc_m < 2 ? 1 : 2);
 
-  int qn = 2, free_head = N < HX ? N : (int)kDfNone;
-  int gminE = 0, gminX = 0, gmin = 0, nE = N, nX = N;
-  int next_id = N, nU = 0, Ulo = 0, numbered_upto = -1;
   int err = 0, bail = 0, maxg = 0;
-  int d_pass = 0, d_chunk = 0, d_exam = 0, d_step = 0, d_num = 0, d_qmax = 0;
-  long long t_chk = 0, t_stp = 0, t_upd = 0, t_end = 0, t0 = 0, t1 = 0;
-  const bool timing = a.dbg != nullptr;
-  const int g_cap = N - 1;   // iterations beyond this: positions would need a true modulo -- k_qss_sim takes over
+  // One step of one side of one front (:154-254 enter, :257-348 exit) -- the arithmetic of k_qss_sim, expression for expression.
+  struct StepOut { int new_stop, e, spawned, wr, nown; double nv, na; };
+  auto step_calc = [&](int side, int li, int ni, double dd, double rn, double gsn, int turn) {
+    StepOut o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+    const double lv = V[li], la = A[li];
+    if (lv == 0.0) { o.e = 1; return o; }
+    const double dt = dd / lv;
+    const double max_dacc = dt * a.max_jerk;
+    double max_acc = la + max_dacc, min_acc = la - max_dacc;
+    const double vmax_acc = small_tabs ? pa2.eval(lv) : ppoly_eval(t_ax, t_ac, a.acc_m, lv);
+    const double vmax_dcc = small_tabs ? pd2.eval(lv) : ppoly_eval(t_dx, t_dc, a.dcc_m, lv);
+    max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
+    min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
+    double min_state, max_state;
+    if (side == 0) {  // v0^2 = v^2 - 2 a x
+      const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
+      min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+    } else {          // v^2 = 2 a x + v0^2
+      const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
+      max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+    }
+    const double max_curve = sqrt(fabs(fabs(qss_acc_circle_lon(a, la)) - gsn) * rn);  // calc_v, :54-55
+    double greedy = max_state < max_curve ? max_state : max_curve;
+    if (a.max_speed < greedy) greedy = a.max_speed;
+    if (greedy != greedy) { o.e = 1; return o; }
+    if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve && greedy <= a.max_speed) {
+      const double pv = V[ni], pa = A[ni];
+      if (OWN[ni] != 0xFFFF && pv < greedy) {
+        o.new_stop = 1;  // a slower profile already owns this point: stop
+      } else {
+        if (!(min_acc <= pa && pa <= max_acc)) o.new_stop = -1;  // merge mode
+        o.wr = 1; o.nv = greedy; o.nown = turn;
+        o.na = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
+      }
+    } else {
+      o.new_stop = 1;
+      if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
+        o.spawned = 1; o.wr = 1;
+        const double v = sqrt(fabs(fabs(lat0) - gsn) * rn);
+        o.nv = v < a.max_speed ? v : a.max_speed;
+        o.na = 0.0; o.nown = ni;
+      }
+    }
+    return o;
+  };
 
+  // ---- Iteration 0 in LIST ORDER.  Under the dataflow rules front f of iteration 0 would have to wait for front f - 1 to have
+  // run even where that one turns out to stop without writing -- one chain through all N fronts, which then delays every
+  // later iteration (5 700 passes instead of 3 800 on Monza).  Here the stops are known as soon as they are computed.
+  // Enter sub-pass: front f reads sample f and writes f - 1; f is written only by front f + 1, i.e. after it has been read:
+  // every front steps off the initial profile, a chunk at a time (reads of a chunk before its writes).
+  int nsp = 0;   // fronts spawned in iteration 0: ids N, N + 1, ... in list order
+  for (int base = 0; base < N && !err && !bail; base += 64) {
+    const int f = base + lane;
+    const bool in = f < N;
+    const int ni = f == 0 ? N - 1 : f - 1;
+    StepOut o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+    if (in) o = step_calc(0, f, ni, SEG[f], RAD[ni], GS[ni], f);
+    DF_SYNC();
+    if (__any(in && o.e)) { err = 1; break; }
+    if (in && o.wr) { V[ni] = o.nv; A[ni] = o.na; OWN[ni] = (u16)o.nown; }
+    const u64 sm = __ballot(in && o.spawned);
+    if (nsp + __popcll(sm) > HX - N) { bail = 4; break; }
+    if (in) {
+      if (o.new_stop != 1) gE[f] = 1;
+      else if (o.spawned) {
+        const int rank = nsp + __popcll(sm & ((1ull << lane) - 1ull)), rec = N + rank;
+        gE[f] = 1; idE[f] = (u16)(N + rank); tE[f] = (u16)ni;
+        xg[rec] = 1; xid[rec] = (u16)(N + rank); xt[rec] = (u16)ni; xw[rec] = (u16)df_wrap(ni + 2 * N - 1, N);
+      } else gE[f] = (u16)kDfNone;
+    }
+    nsp += __popcll(sm);
+    DF_SYNC();
+  }
+  // Exit sub-pass: front f reads f and writes f + 1, which front f + 1 reads: a chain wherever fronts write.  A chunk at a time;
+  // per round every pending front computes, and a front's result holds iff no pending front of the unbroken run before it
+  // writes (its source is then what it has read): the first writer of each run and the stoppers before it commit.
+  for (int base = 0; base < N && !err && !bail; base += 64) {
+    const int f = base + lane;
+    const bool in = f < N;
+    const int ni = f + 1 == N ? 0 : f + 1;
+    double dd = 0.0, rn = 0.0, gsn = 0.0;
+    if (in) { dd = SEG[ni]; rn = RAD[ni]; gsn = GS[ni]; }
+    u64 pending = __ballot(in);
+    while (pending != 0ull) {
+      const bool pend = (pending >> lane) & 1ull;
+      StepOut o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+      if (pend) o = step_calc(1, f, ni, dd, rn, gsn, f);
+      const u64 wrm = __ballot(pend && o.wr);
+      const u64 lowm = (1ull << lane) - 1ull;
+      const u64 gaps = ~pending & lowm;                                  // lanes below me that are not pending
+      const u64 run = gaps ? lowm & ~((2ull << (63 - __clzll((long long)gaps))) - 1ull) : lowm;   // the pending lanes right below me
+      const bool ok = pend && (wrm & run) == 0ull;
+      DF_SYNC();
+      if (__any(ok && o.e)) { err = 1; break; }
+      if (ok && o.wr) { V[ni] = o.nv; A[ni] = o.na; OWN[ni] = (u16)o.nown; }
+      if (ok) xg[f] = o.new_stop == 1 ? (u16)kDfNone : (u16)1;
+      pending &= ~__ballot(ok);
+      DF_SYNC();
+    }
+  }
+  // ---- the tables at the start of iteration 1
+  int nE = 0, nX = 0, qn = 0;
+  if (!err && !bail) {
+    for (int i = lane; i < N; i += 64) { hX[i] = xg[i] == 1 ? (u16)i : (u16)kDfNone; xn[i] = (u16)kDfNone; }
+    DF_SYNC();
+    for (int k = lane; k < nsp; k += 64) {   // a new front's exit side: born at f - 1, so on worldline f - 2 (one per worldline)
+      const int rec = N + k, cxw = xw[rec];
+      xn[rec] = hX[cxw]; hX[cxw] = (u16)rec;
+      WN[N + rec] = (u16)kDfNone;
+    }
+    DF_SYNC();
+    for (int i = lane; i < L.NW; i += 64) { bmE[i] = 0ull; bmX[i] = 0ull; }
+    DF_SYNC();
+    for (int base = 0; base < N; base += 64) {
+      const int i = base + lane;
+      const bool in = i < N;
+      const bool ea = in && gE[i] != (u16)kDfNone, xa = in && hX[i] != (u16)kDfNone;
+      const u64 em = __ballot(ea), xm = __ballot(xa);
+      if (lane == 0) { bmE[base >> 6] = em; bmX[base >> 6] = xm; }
+      if (ea) Q[qn + __popcll(em & ((1ull << lane) - 1ull))] = (u16)i;
+      qn += __popcll(em); nE += __popcll(em);
+    }
+    DF_SYNC();
+    for (int base = 0; base < N + nsp; base += 64) {   // exit records: the originals that go on, and the new fronts'
+      const int i = base + lane;
+      const bool al = i < N + nsp && (i >= N || xg[i] == 1);
+      const u64 am = __ballot(al);
+      if (al) Q[qn + __popcll(am & ((1ull << lane) - 1ull))] = (u16)(N + i);
+      qn += __popcll(am); nX += __popcll(am);
+    }
+  }
   // the agent of an exit worldline that steps next
   auto summarise = [&](int cc) {
     int bg = (int)kDfNone, bi = (int)kDfNone, br = (int)kDfNone;
@@ -207,10 +336,59 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
     }
     sG[cc] = (u16)bg; sId[cc] = (u16)bi; sRec[cc] = (u16)br;
   };
+  for (int i = lane; i < N; i += 64) summarise(i);
+  if (lane == 0) { cntE[0] = 0; cntX[0] = 0; cntE[1] = nE; cntX[1] = nX; }
+  int free_head = N + nsp < HX ? N + nsp : (int)kDfNone;
+  int gminE = nE > 0 ? 1 : 0x7000, gminX = nX > 0 ? 1 : 0x7000, gmin = gminE < gminX ? gminE : gminX;
+  int next_id = N + nsp, nU = 0, Ulo = 0, numbered_upto = 0;
+  __syncthreads();
+  int d_pass = 0, d_chunk = 0, d_exam = 0, d_step = 0, d_num = 0, d_qmax = 0;
+  long long t_chk = 0, t_stp = 0, t_upd = 0, t_end = 0, t0 = 0, t1 = 0;
+  const bool timing = a.dbg != nullptr;
+  const int g_cap = N - 1;   // iterations beyond this: positions would need a true modulo -- k_qss_sim takes over
+
   auto sleep_on = [&](int key, int h) {
     const unsigned old = atomicExch(&WH[key], (unsigned)h);
     WN[h] = (u16)old;
   };
+  // kappa = 2 g - w of an enter agent only grows (a step adds 2, the front it spawns continues at + 2, its end removes it), so a
+  // block value computed from whatever a lane happens to read is a valid lower bound: concurrent refreshes need no ordering.
+  // Blocks of FOUR worldlines: the ranges asked about below end at most three worldlines short of agents that are known not to
+  // qualify (my own neighbours, already vetted by the rules before), so a block never raises a false alarm by what lies beyond
+  // the range's end.
+  const int NK = (N + 3) / 4;
+  auto kappa_refresh = [&](int blk) {
+    int m = 0xFFFF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int wq = blk * 4 + q;
+      const int gq = wq < N ? (int)gE[wq] : (int)kDfNone;
+      const int kq = gq == (int)kDfNone ? 0xFFFF : 2 * gq - wq + N;
+      m = kq < m ? kq : m;
+    }
+    KAP[blk] = (u16)m;
+  };
+  // may there be an enter agent with 2 g_e - wu < thr among the worldlines wu = start ... start + len - 1 (unwrapped, len <= 64)?
+  auto kappa_below = [&](int start, int len, int thr) {
+    const int s0 = df_wrap(start, N), off = start - s0;   // unwrapped = stored + off, and + N beyond the end of the ring
+    const int e = s0 + len - 1, eA = e < N ? e : N - 1;
+    int m = 0x7fffffff;
+    for (int blk = s0 >> 2; blk <= (eA >> 2); ++blk) {
+      const int kv = KAP[blk];
+      const int v = kv == 0xFFFF ? 0x7fffffff : kv - N - off;
+      m = v < m ? v : m;
+    }
+    if (e >= N) {
+      for (int blk = 0; blk <= ((e - N) >> 2); ++blk) {
+        const int kv = KAP[blk];
+        const int v = kv == 0xFFFF ? 0x7fffffff : kv - 2 * N - off;
+        m = v < m ? v : m;
+      }
+    }
+    return m < thr;
+  };
+  for (int blk = lane; blk < NK; blk += 64) kappa_refresh(blk);
+  DF_SYNC();
 
   while (qn > 0 && !err && !bail) {
     ++d_pass; d_qmax = qn > d_qmax ? qn : d_qmax;
@@ -246,8 +424,9 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
           else if (fg <= g) {                                                // the follower of this iteration writes my source
             if (fi < id) key = N + cm;
             else if (fg < g) {                                               //   (its next agent is not the one that matters: look at all)
-              for (int r2 = hX[cm]; r2 != (int)kDfNone; r2 = xn[r2])
+              for (int r2 = hX[cm]; r2 != (int)kDfNone; r2 = xn[r2]) {
                 if ((int)xid[r2] < id && (int)xg[r2] <= g) { key = N + cm; break; }
+              }
             }
           }
           if (key < 0 && win) {                                              // agents ahead of me that lag behind in iterations
@@ -265,6 +444,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
               } else key = N + cl;
             }
           }
+          int behind_top = p + gminE;                                        // enter worldlines up to here hold agents at or behind me
           if (key < 0 && g + 1 >= gminE) {                                   // enter agents coming towards me
             const int start = p + 1 + gminE, len = g - gminE + 2;
             u64 we = df_window(bmE, N, df_wrap(start, N)) & df_mask(len);
@@ -273,26 +453,22 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
               const int wu = start + bit, ws = df_wrap(wu, N);
               const int ge = gE[ws], pe = wu - ge;
               if (pe >= p + 2 || (pe == p + 1 && ge <= g)) { key = ws; break; }
-              if (pe <= p) break;
+              if (pe <= p) { behind_top = wu; break; }
               we &= ~(1ull << bit);
             }
           }
           if (key < 0 && g - 2 >= gminE) {                                   // fronts that enter agents behind me may still spawn
-            const int start = c + 2 + 2 * gminE, len = 2 * (g - gminE) - 3;
-            if (len > 0) {
-              const int s0 = df_wrap(start, N), s1 = df_wrap(start + len - 1, N);
-              int lo = BLK[s0 >> 6]; const int hi = BLK[s1 >> 6];
-              lo = hi < lo ? hi : lo;
-              if (s1 < s0) { const int t = BLK[NB - 1]; lo = t < lo ? t : lo; }   // (wrapped: the short last block lies in between)
-              if (g - 2 >= lo) {                            //   (no enter agent of these blocks is that far behind: the usual case)
-                u64 we = df_window(bmE, N, s0) & df_mask(len);
-                while (we) {
-                  const int bit = __ffsll((long long)we) - 1;
-                  const int wu = start + bit, ws = df_wrap(wu, N);
-                  const int ge = gE[ws], pe = wu - ge;
-                  if (pe <= p && ge + 1 + (p - pe) < g) { key = ws; break; }
-                  we &= we - 1ull;
-                }
+            const int start = c + 2 + 2 * gminE;
+            const int top = behind_top < c + 2 * g - 2 ? behind_top : c + 2 * g - 2;
+            const int len = top - start + 1;
+            if (len > 0 && kappa_below(start, len, -c - 1)) {                //   (no such agent lags that far behind: the usual case)
+              u64 we = df_window(bmE, N, df_wrap(start, N)) & df_mask(len);
+              while (we) {
+                const int bit = __ffsll((long long)we) - 1;
+                const int wu = start + bit, ws = df_wrap(wu, N);
+                const int ge = gE[ws], pe = wu - ge;
+                if (pe <= p && ge + 1 + (p - pe) < g) { key = ws; break; }
+                we &= we - 1ull;
               }
             }
           }
@@ -333,21 +509,15 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
           }
           if (key < 0 && g - 2 >= gminE) {                                   // fronts that enter agents behind me may still spawn
             const int len = 2 * (g - gminE) - 3;
-            if (len > 0) {
-              const int start = c + 2 * N - 2 * (g - gminE) + 1;
-              const int s0 = df_wrap(start, N), s1 = df_wrap(start + len - 1, N);
-              int lo = BLK[s0 >> 6]; const int hi = BLK[s1 >> 6];
-              lo = hi < lo ? hi : lo;
-              if (s1 < s0) { const int t = BLK[NB - 1]; lo = t < lo ? t : lo; }   // (wrapped: the short last block lies in between)
-              if (g - 2 >= lo) {
-                u64 we = df_window(bmE, N, s0) & df_mask(len);
-                while (we) {
-                  const int bit = __ffsll((long long)we) - 1;
-                  const int wu = start + bit, ws = df_wrap(wu, N);
-                  const int ge = gE[ws], pe = wu - ge;
-                  if (pe <= p - 1 && ge + (p - pe) < g) { key = ws; break; }
-                  we &= we - 1ull;
-                }
+            const int start = c + 2 * N - 2 * (g - gminE) + 1;
+            if (len > 0 && kappa_below(start, len, 2 * g - c - 2 * N)) {
+              u64 we = df_window(bmE, N, df_wrap(start, N)) & df_mask(len);
+              while (we) {
+                const int bit = __ffsll((long long)we) - 1;
+                const int wu = start + bit, ws = df_wrap(wu, N);
+                const int ge = gE[ws], pe = wu - ge;
+                if (pe <= p - 1 && ge + (p - pe) < g) { key = ws; break; }
+                we &= we - 1ull;
               }
             }
           }
@@ -360,53 +530,11 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
         else sleep_on(key, h);
       }
       if (timing) { t1 = clock64(); t_chk += t1 - t0; t0 = t1; }
-      // ------------------------------------------------------------------ the step (same arithmetic as k_qss_sim)
-      int new_stop = 0, e = 0, spawned = 0, wr = 0, nown = 0;
-      double nv = 0.0, na = 0.0;
-      if (ready) {
-        const double lv = V[li], la = A[li];
-        if (lv == 0.0) { e = 1; }
-        else {
-          const double dt = dd / lv;
-          const double max_dacc = dt * a.max_jerk;
-          double max_acc = la + max_dacc, min_acc = la - max_dacc;
-          const double vmax_acc = small_tabs ? pa2.eval(lv) : ppoly_eval(t_ax, t_ac, a.acc_m, lv);
-          const double vmax_dcc = small_tabs ? pd2.eval(lv) : ppoly_eval(t_dx, t_dc, a.dcc_m, lv);
-          max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
-          min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
-          double min_state, max_state;
-          if (side == 0) {  // v0^2 = v^2 - 2 a x
-            const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
-            min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-          } else {          // v^2 = 2 a x + v0^2
-            const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
-            max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-          }
-          const double max_curve = sqrt(fabs(fabs(qss_acc_circle_lon(a, la)) - gsn) * rn);  // calc_v, :54-55
-          double greedy = max_state < max_curve ? max_state : max_curve;
-          if (a.max_speed < greedy) greedy = a.max_speed;
-          if (greedy != greedy) { e = 1; }
-          else if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve &&
-                   greedy <= a.max_speed) {
-            const double pv = V[ni], pa = A[ni];
-            if (OWN[ni] != 0xFFFF && pv < greedy) {
-              new_stop = 1;  // a slower profile already owns this point: stop
-            } else {
-              if (!(min_acc <= pa && pa <= max_acc)) new_stop = -1;  // merge mode
-              wr = 1; nv = greedy; nown = turn;
-              na = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
-            }
-          } else {
-            new_stop = 1;
-            if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
-              spawned = 1; wr = 1;
-              const double v = sqrt(fabs(fabs(lat0) - gsn) * rn);
-              nv = v < a.max_speed ? v : a.max_speed;
-              na = 0.0; nown = ni;
-            }
-          }
-        }
-      }
+      // ------------------------------------------------------------------ the step
+      StepOut o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+      if (ready) o = step_calc(side, li, ni, dd, rn, gsn, turn);
+      const int new_stop = o.new_stop, e = o.e, spawned = o.spawned, wr = o.wr, nown = o.nown;
+      const double nv = o.nv, na = o.na;
       DF_SYNC();   // every step of the chunk has read its inputs
       if (timing) { t1 = clock64(); t_stp += t1 - t0; t0 = t1; }
       if (__any(ready && e)) { err = 1; break; }
@@ -424,29 +552,34 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
           atomicAdd(&cntE[(g + 1) & (kDfCnt - 1)], 1);
           atomicAdd(&bcnt[g & (kDfCnt - 1)], 1);
         } else { gE[w] = (u16)kDfNone; atomicAnd(&bmE[w >> 6], ~(1ull << (w & 63))); }
+        kappa_refresh(w >> 2);   // (with my own new value; what the neighbours of the block are writing right now may or may not be in: a bound either way)
       }
       if (ready && isX) {
         atomicSub(&cntX[g & (kDfCnt - 1)], 1);
         if (!die) { xg[r] = (u16)(g + 1); atomicAdd(&cntX[(g + 1) & (kDfCnt - 1)], 1); }
       }
       nE -= __popcll(__ballot(ready && !isX && die && !spawned));
-      // exit agents that stopped leave their worldline's list; new fronts get an exit record (one lane at a time: shared lists)
+      // exit agents that stopped leave their worldline's list (all at once: only the next agent of a worldline can have stepped,
+      // so the lists are different ones) and their records go back on the free list in lane order
       {
-        u64 m = __ballot(ready && isX && die);
-        nX -= __popcll(m);
-        for (; m != 0ull; m &= m - 1ull) {
-          const int j = __ffsll((long long)m) - 1;
-          if (lane == j) {
+        const bool dx = ready && isX && die;
+        const u64 m = __ballot(dx);
+        if (m != 0ull) {
+          nX -= __popcll(m);
+          if (dx) {
             int prev = (int)kDfNone, cur = hX[w];
             while (cur != r) { prev = cur; cur = xn[cur]; }
             if (prev == (int)kDfNone) hX[w] = xn[r]; else xn[prev] = xn[r];
-            if (hX[w] == (u16)kDfNone) bmX[w >> 6] &= ~(1ull << (w & 63));
-            xn[r] = (u16)free_head;
+            if (hX[w] == (u16)kDfNone) atomicAnd(&bmX[w >> 6], ~(1ull << (w & 63)));
           }
-          free_head = __builtin_amdgcn_readlane(r, j);
-          DF_SYNC();
+          const u64 lower = m & ((1ull << lane) - 1ull);
+          const int pl = lower ? 63 - __clzll((long long)lower) : 0;
+          const int rp = __shfl(r, pl);
+          if (dx) xn[r] = (u16)(lower ? rp : free_head);
+          free_head = __builtin_amdgcn_readlane(r, 63 - __clzll((long long)m));
         }
       }
+      DF_SYNC();
       int cx = 0;
       {
         const u64 sm = __ballot(ready && spawned);
@@ -479,9 +612,11 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
           nU += cnt; nX += cnt;
         }
       }
-      DF_SYNC();
       // the next agent of every exit worldline whose list or iteration counters have changed
-      if (ready && isX) summarise(w);
+      if (ready && isX) {
+        if (!die && (int)hX[w] == r && xn[r] == (u16)kDfNone) sG[w] = (u16)(g + 1);   // alone on its worldline: the usual case
+        else summarise(w);
+      }
       if (ready && spawned) summarise(cx);
       DF_SYNC();
       // ------------------------------------------------------------------ wake whoever sleeps on my worldline; queue myself --
@@ -495,8 +630,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
           cur = WN[cur];
         }
       }
-      DF_SYNC();
-      if (ready && !die) {
+      if (ready && !die) {   // (whether this lands before or after the neighbour's wake-up above: it is blocked by that neighbour's NEXT step)
         int skey = -1;
         const int g1 = g + 1;
         if (isX) {
@@ -530,14 +664,6 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
         for (int i = lane; i < nw; i += 64) { const int slot = atomicAdd(&scal[0], 1); Q2[slot] = WINQ[i]; }
         __syncthreads();
         if (lane == 0) scal[1] = 0;
-      }
-    }
-    if ((d_pass & 7) == 0) {   // lower bounds of the enter agents' iteration per block (they only grow: a stale bound is a valid one)
-      for (int k = 0; k < NB; ++k) {
-        const int i = k * 64 + lane;
-        int v = i < N ? (int)gE[i] : (int)kDfNone;
-        for (int d = 32; d >= 1; d >>= 1) { const int t = __shfl_xor(v, d); v = t < v ? t : v; }
-        if (lane == 0) BLK[k] = (u16)v;
       }
     }
     // fronts born in iterations every enter agent has finished get their ids: by (birth, id of the parent) = list order
@@ -608,6 +734,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
     int* d = a.dbg + 12 * b;
     d[0] = d_pass; d[1] = d_chunk; d[2] = d_exam; d[3] = d_step; d[4] = d_qmax; d[5] = d_num; d[6] = nU; d[7] = bail;
     d[8] = (int)(t_chk >> 10); d[9] = (int)(t_stp >> 10); d[10] = (int)(t_upd >> 10); d[11] = (int)(t_end >> 10);
+
   }
   if (bail && !err) { if (lane == 0) a.iters[b] = -2; return; }
   if (lane == 0) a.iters[b] = err ? -1 : maxg;

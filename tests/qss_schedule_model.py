@@ -11,7 +11,7 @@ pass without a step) and that spawned fronts are numbered in the reference's lis
 The log comes from an instrumented copy of oracle/mincurv_oracle.c's orc_qss_sim, generated and compiled here into a temporary
 directory (test infrastructure only; nothing of it is linked into the product).
 
-    python tests/qss_schedule_model.py [cases] [window]      # random trajectories as in tools/validate_qss.py
+    python tests/qss_schedule_model.py [cases] [window] [all|small] [start]      # random trajectories as in tools/validate_qss.py
 """
 import collections
 import ctypes
@@ -81,8 +81,10 @@ def step_log(lib, points, veh):
 
 
 # ------------------------------------------------------------------------------------------------ the scheduler
-def run(lg, N, R):
-    """Replay the log under the kernel's rules; returns pass / step / examination counts.  Raises on any violation."""
+def run(lg, N, R, start=1):
+    """Replay the log under the kernel's rules; returns pass / step / examination counts.  Raises on any violation.
+    start = 1: iteration 0 has been run in list order (as the kernel does) and the dataflow begins with the fronts that survive it;
+    start = 0: the dataflow begins with the N original fronts."""
     n = len(lg)
     seq = collections.defaultdict(list)
     for i in range(n):
@@ -128,10 +130,24 @@ def run(lg, N, R):
             X[a.w].append(a)
             cnt_x[g] += 1
         return a
-    Q = [a for f in range(N) for a in (make(0, f, 0, f, f), make(1, f, 0, f, f)) if a]
-    gmin_e = gmin_x = gmin = 0
-    unnumbered, next_id = [], N
     done = np.full(n, -1)
+    if start == 0:
+        Q = [a for f in range(N) for a in (make(0, f, 0, f, f), make(1, f, 0, f, f)) if a]
+        next_id = N
+    else:       # the state after `start` iterations in list order: every front that steps in iteration `start`, ids as in the list
+        done[lg[:, 0] < start] = 0
+        for k in list(seq.keys()):
+            seq[k] = [i for i in seq[k] if lg[i, 0] >= start]
+        Q = []
+        for (fid, d), steps_of in sorted(seq.items()):
+            if steps_of and lg[steps_of[0], 0] == start:
+                li = int(lg[steps_of[0], 3])
+                a = make(d, li + start if d == 0 else li - start, start, fid, fid)
+                if a:
+                    Q.append(a)
+        next_id = max([N] + [child_of[i] + 1 for i in child_of if lg[i, 0] < start])
+    gmin_e = gmin_x = gmin = start
+    unnumbered = []
     passes = exams = steps = maxg = 0
     INF = 1 << 40
 
@@ -311,6 +327,7 @@ def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     only_small = len(sys.argv) > 3 and sys.argv[3] == "small"
+    start = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     with tempfile.TemporaryDirectory() as wd:
         lib = build_logging_oracle(wd)
         for case, N, p, veh in cases(count):
@@ -320,7 +337,7 @@ def main():
             if lg is None:
                 print(f"case {case}: N={N} the reference raises / log too long: skipped")
                 continue
-            res = run(lg, N, R)
+            res = run(lg, N, R, start)
             assert res["iterations"] == it
             print(f"case {case}: N={N} iterations {it}: {res}", flush=True)
     print("no violation")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Wall time of Simulator.run_simulation on the GPU (rl_qss_sim, host call incl. copies): one Monza trajectory at N = 2000 and
-N = 500, and batches of them.   python tools/time_qss.py"""
+"""Wall time of Simulator.run_simulation on the GPU (rl_qss_sim, host call incl. copies): Monza trajectories at N = 2000 and
+N = 500, one at a time and in batches, with the kernel rl_qss_sim_dev picks and with each of the two forced (RL_QSS_DF = 1: the
+dataflow kernel k_qss_df, 0: the list-order kernel k_qss_sim).   python tools/time_qss.py [B ...]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,10 +12,20 @@ from spline_trajectory_optimization_amd import batch, ops
 acc = CubicSpline([0.0, 50.0, 100.0], [10.0, 7.0, 0.5]); dcc = CubicSpline([0.0, 50.0, 100.0], [-13.0, -15.0, -20.0])
 veh = (acc.x, acc.c, dcc.x, dcc.c, np.array([10.0, -20.0, 15.0, -15.0, 100.0, 30.0]))
 line = batch.monza_centerline(100.0, 5)
+Bs = [int(v) for v in sys.argv[1:]] or [1, 1024]
+forced = os.environ.get("RL_QSS_DF")
+modes = [("as set" if forced is not None else "auto", forced)] if (forced is not None or len(sys.argv) == 1) else [("auto", None), ("dataflow", "1"), ("list-order", "0")]
 for N in (2000, 500):
     pts = line.sample_along(ts=np.linspace(0, 1, N, endpoint=False)).points
-    for B in (1, 1024):
+    for B in Bs:
         P = np.repeat(pts[None], B, axis=0) if B > 1 else pts
-        ops.qss_sim(P, *veh)
-        t0 = time.perf_counter(); out, it = ops.qss_sim(P, *veh); dt = time.perf_counter() - t0
-        print(f"N={N} B={B}: {dt * 1e3:.1f} ms  ({B / dt:.0f} simulations/s)  global iterations {int(np.atleast_1d(it)[0])}  checksum {float(np.asarray(out)[..., 4].sum()):.9f}")
+        for name, val in modes:
+            if val is None:
+                os.environ.pop("RL_QSS_DF", None)
+            else:
+                os.environ["RL_QSS_DF"] = val
+            ops.qss_sim(P, *veh)
+            best = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter(); out, it = ops.qss_sim(P, *veh); best = min(best, time.perf_counter() - t0)
+            print(f"N={N} B={B} [{name}]: {best * 1e3:.1f} ms  ({B / best:.0f} simulations/s)  global iterations {int(np.atleast_1d(it)[0])}  checksum {float(np.asarray(out)[..., 4].sum()):.9f}", flush=True)
