@@ -294,6 +294,60 @@ def mintime_leg(B, with_cpu):
     return leg
 
 
+def qss_leg(B, with_cpu):
+    """Fourth leg: Simulator.run_simulation on B Monza tables of N = 2000 whose turn radii are scaled
+    by 0.9 ... 1.1 per instance (different profiles and iteration counts), device resident (rl_qss_sim_dev on torch's stream),
+    timed with events around one call after a warm-up; and one table alone.  The kernel is latency bound (a dependent chain
+    of front steps), so the leg reports times and rates, not a roofline.  cpu_baseline / parity: the C oracle's
+    list-order loop on the first instances, one core."""
+    try:
+        import torch
+        from scipy.interpolate import CubicSpline
+        from spline_trajectory_optimization_amd import batch, ops
+        acc = CubicSpline([0.0, 50.0, 100.0], [10.0, 7.0, 0.5]); dcc = CubicSpline([0.0, 50.0, 100.0], [-13.0, -15.0, -20.0])
+        veh = (acc.x, acc.c, dcc.x, dcc.c, np.array([10.0, -20.0, 15.0, -15.0, 100.0, 30.0]))   # the vehicle of the reference's simulator test
+        N = 2000
+        pts = batch.monza_centerline(100.0, 5).sample_along(ts=np.linspace(0, 1, N, endpoint=False)).points
+        rng = np.random.default_rng(7)
+        P = np.repeat(pts[None], B, axis=0)
+        P[:, :, 5] *= rng.uniform(0.9, 1.1, size=(B, 1))
+        leg = {"workload": f"Monza centre line, N = {N}, {B} tables with turn radii scaled by 0.9 ... 1.1; the reference test's vehicle",
+               "instances": B}
+        for name, tab in (("batch", P), ("single", P[:1])):
+            d = torch.from_numpy(tab).cuda()
+            ops.qss_sim_torch(d.clone(), *veh); torch.cuda.synchronize()
+            best = None
+            for _ in range(2):
+                w = d.clone()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); it = ops.qss_sim_torch(w, *veh); e1.record(); torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                if best is None or ms < best[0]:
+                    best = (ms, w, it)
+            ms, w, it = best
+            its = it.cpu().numpy()
+            leg[name] = {"instances": int(tab.shape[0]), "ms": ms, "simulations_per_s": tab.shape[0] / ms * 1e3,
+                         "global_iterations_mean": float(its.mean()), "raised": int((its < 0).sum())}
+            if name == "batch":
+                out, its_batch = w.cpu().numpy(), its
+        leg["kernel"] = "k_qss_df (the reference's steps as a dataflow) up to the batch size rl_qss_sim_dev gives it, else k_qss_sim (list order)"
+        if with_cpu:
+            from oracle import oracle as orc
+            k = min(3, B)
+            t0 = time.perf_counter()
+            refs = [orc.qss_sim(P[i], *veh) for i in range(k)]
+            dt = time.perf_counter() - t0
+            leg["cpu_baseline"] = {"value": k / dt, "unit": "simulations/s", "cores": 1, "kind": "port",
+                                   "sample": f"{k} of the {B} tables, oracle/mincurv_oracle.c orc_qss_sim (list order)"}
+            leg["parity"] = {"instances": k,
+                             "owner_flags_equal": bool(all(np.array_equal(out[i][:, 18], refs[i][0][:, 18]) for i in range(k))),
+                             "iterations_equal": bool(all(int(its_batch[i]) == int(refs[i][1]) for i in range(k))),
+                             "max_speed_dev": float(max(np.abs(out[i][:, 4] - refs[i][0][:, 4]).max() for i in range(k)))}
+        return leg
+    except Exception as e:   # the headline must not depend on this leg
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def valu_block(prof, kernel_ms):
     """FP64 VALU view of a kernel from the committed counters + this run's kernel time.
       valu_active_frac = SQ_ACTIVE_INST_VALU [quad-cycles] x 4 / (1024 SIMDs x kernel cycles), kernel cycles =
@@ -557,6 +611,8 @@ def run_rank(args):
                 res["global_qp"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.workload == "monza" and not args.no_mintime:
             res["mintime_nlp"] = mintime_leg(args.mintime_batch, with_cpu=not args.no_cpu_baseline)
+        if world == 1 and args.workload == "monza" and not args.no_qss:
+            res["qss_sim"] = qss_leg(args.qss_batch, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
@@ -602,6 +658,8 @@ def main():
     ap.add_argument("--no-global", action="store_true", help="skip the global-QP leg")
     ap.add_argument("--no-mintime", action="store_true", help="skip the min-time NLP leg")
     ap.add_argument("--mintime-batch", type=int, default=1024)
+    ap.add_argument("--no-qss", action="store_true", help="skip the QSS simulator leg")
+    ap.add_argument("--qss-batch", type=int, default=256)
     ap.add_argument("--cpu-instances", type=int, default=8)
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST HOOK: all ranks use cuda:0 and the gloo backend (exercises the N>1 code path "

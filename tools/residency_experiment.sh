@@ -4,9 +4,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/residency; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 for v in 0 1 2; do
   export RL_FORCE_RESIDENCY=$v
-  python3 $R/bench.py --no-global --no-mintime --no-cpu-baseline --steps 10 > $O/bench_$v.json 2> /dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O -o fetch_$v -- python3 $R/bench.py --no-global --no-mintime --no-cpu-baseline --steps 5 > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O -o write_$v -- python3 $R/bench.py --no-global --no-mintime --no-cpu-baseline --steps 5 > /dev/null 2>&1
+  python3 $R/bench.py --no-global --no-mintime --no-qss --no-cpu-baseline --steps 10 > $O/bench_$v.json 2> /dev/null
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O -o fetch_$v -- python3 $R/bench.py --no-global --no-mintime --no-qss --no-cpu-baseline --steps 5 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O -o write_$v -- python3 $R/bench.py --no-global --no-mintime --no-qss --no-cpu-baseline --steps 5 > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, json
