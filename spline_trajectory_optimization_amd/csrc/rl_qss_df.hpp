@@ -655,8 +655,12 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
     DF_SYNC();
     {
       const int og = gmin;
-      if (nE > 0) { while (cntE[gminE & (kDfCnt - 1)] == 0) ++gminE; } else gminE = 0x7000;
-      if (nX > 0) { while (cntX[gminX & (kDfCnt - 1)] == 0) ++gminX; } else gminX = 0x7000;
+      // (every live agent's iteration lies in [gmin, gmin + kDfR + 1]: the searches end within the circular counters; the
+      // bound only keeps a corrupted count from hanging the wave)
+      int guard = 0;
+      if (nE > 0) { while (cntE[gminE & (kDfCnt - 1)] == 0 && ++guard <= kDfCnt) ++gminE; } else gminE = 0x7000;
+      if (nX > 0) { while (cntX[gminX & (kDfCnt - 1)] == 0 && ++guard <= 2 * kDfCnt) ++gminX; } else gminX = 0x7000;
+      if (guard > kDfCnt) { bail = 8; break; }
       gmin = gminE < gminX ? gminE : gminX;
       if (gmin != og) {
         __syncthreads();
@@ -725,6 +729,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
     if (lane == 0) scal[0] = 0;
     { u16* t = Q; Q = Q2; Q2 = t; }
     if (qn == 0 && nE + nX > 0) bail = 6;   // (cannot happen: the earliest pending step is never blocked)
+    if (d_pass > 64 * N) bail = 9;          // (every pass runs at least one of at most ~N^2 steps; far beyond any real profile)
     DF_SYNC();
     if (timing) t_end += clock64() - t0;
   }
