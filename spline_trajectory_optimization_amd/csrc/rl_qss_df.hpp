@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
   int* cntE = reinterpret_cast<int*>(lds + L.o_cntE);              // live enter agents per iteration (mod kDfCnt)
   int* cntX = reinterpret_cast<int*>(lds + L.o_cntX);
   int* bcnt = reinterpret_cast<int*>(lds + L.o_bcnt);              // fronts born per iteration, not numbered yet
-  int* scal = reinterpret_cast<int*>(lds + L.o_scal);              // [0] length of the next queue, [1] window sleepers
+  int* scal = reinterpret_cast<int*>(lds + L.o_scal);              // [1] window sleepers
   u16* OWN = reinterpret_cast<u16*>(lds + L.o_OWN);
   u16* gE = reinterpret_cast<u16*>(lds + L.o_gE);                  // enter agent of worldline w: next iteration (kDfNone: none)
   u16* idE = reinterpret_cast<u16*>(lds + L.o_idE);                //   its front's id (kDfNone: not numbered yet)
@@ -350,6 +350,13 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
   auto sleep_on = [&](int key, int h) {
     const unsigned old = atomicExch(&WH[key], (unsigned)h);
     WN[h] = (u16)old;
+  };
+  // the next pass's queue: appended a wave at a time (ballot + prefix count; call sites are wave-uniform)
+  int q2n = 0;
+  auto push_next = [&](bool want, int h) {
+    const u64 m = __ballot(want);
+    if (want) Q2[q2n + __popcll(m & ((1ull << lane) - 1ull))] = (u16)h;
+    q2n += __popcll(m);
   };
   // kappa = 2 g - w of an enter agent only grows (a step adds 2, the front it spawns continues at + 2, its end removes it), so a
   // block value computed from whatever a lane happens to read is a valid lower bound: concurrent refreshes need no ordering.
@@ -621,17 +628,16 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
       DF_SYNC();
       // ------------------------------------------------------------------ wake whoever sleeps on my worldline; queue myself --
       // or go to sleep at once on the neighbour that blocks the next step (the usual case in a train)
-      if (ready) {
-        const int mykey = isX ? N + w : w;
-        unsigned cur = atomicExch(&WH[mykey], kDfNone);
-        while (cur != kDfNone) {
-          const int slot = atomicAdd(&scal[0], 1);
-          Q2[slot] = (u16)cur;
-          cur = WN[cur];
+      {
+        unsigned cur = kDfNone;
+        if (ready) cur = atomicExch(&WH[isX ? N + w : w], kDfNone);
+        while (__any(cur != kDfNone)) {
+          push_next(cur != kDfNone, (int)cur);
+          if (cur != kDfNone) cur = WN[cur];
         }
       }
+      int skey = -1;
       if (ready && !die) {   // (whether this lands before or after the neighbour's wake-up above: it is blocked by that neighbour's NEXT step)
-        int skey = -1;
         const int g1 = g + 1;
         if (isX) {
           const int cm = w == 0 ? N - 1 : w - 1;
@@ -644,8 +650,8 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
           else if (bg != (int)kDfNone && bg <= g1 && !(bg == g1 && (int)idE[cd] > id)) skey = cd;
         }
         if (skey >= 0) sleep_on(skey, h);
-        else { const int slot = atomicAdd(&scal[0], 1); Q2[slot] = (u16)h; }
       }
+      push_next(ready && !die && skey < 0, h);
       DF_SYNC();
       if (timing) { t1 = clock64(); t_upd += t1 - t0; }
     }
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
       if (gmin != og) {
         __syncthreads();
         const int nw = scal[1];
-        for (int i = lane; i < nw; i += 64) { const int slot = atomicAdd(&scal[0], 1); Q2[slot] = WINQ[i]; }
+        for (int base = 0; base < nw; base += 64) { const int i = base + lane; push_next(i < nw, i < nw ? (int)WINQ[i] : 0); }
         __syncthreads();
         if (lane == 0) scal[1] = 0;
       }
@@ -701,14 +707,14 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
         }
       }
       DF_SYNC();
-      for (int i = Ulo + lane; i < nU; i += 64) {
-        u16* u = U + (size_t)4 * i;
-        if (u[0] == (u16)bth) {
-          summarise(xw[u[3]]);   // (the same worldline by several lanes: the same result)
-          const int slot = atomicAdd(&scal[0], 2);
-          Q2[slot] = u[2]; Q2[slot + 1] = (u16)(N + u[3]);
-          u[0] = (u16)kDfNone;
-        }
+      for (int base = Ulo; base < nU; base += 64) {
+        const int i = base + lane;
+        u16* u = U + (size_t)4 * (i < nU ? i : Ulo);
+        const bool sel = i < nU && u[0] == (u16)bth;
+        if (sel) summarise(xw[u[3]]);   // (the same worldline by several lanes: the same result)
+        push_next(sel, u[2]);
+        push_next(sel, N + u[3]);
+        if (sel) u[0] = (u16)kDfNone;
       }
       next_id += total;
       if (lane == 0) bcnt[bth & (kDfCnt - 1)] = 0;
@@ -724,9 +730,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
     }
     if (bail) break;
     DF_SYNC();
-    qn = scal[0];
-    DF_SYNC();
-    if (lane == 0) scal[0] = 0;
+    qn = q2n; q2n = 0;
     { u16* t = Q; Q = Q2; Q2 = t; }
     if (qn == 0 && nE + nX > 0) bail = 6;   // (cannot happen: the earliest pending step is never blocked)
     if (d_pass > 64 * N) bail = 9;          // (every pass runs at least one of at most ~N^2 steps; far beyond any real profile)
