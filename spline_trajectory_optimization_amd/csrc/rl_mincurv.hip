@@ -1031,10 +1031,9 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   }
   // The dataflow kernel takes the sizes its LDS tables hold; what it hands back (iters = -2: front or iteration counts beyond its
   // tables) is re-run by the list-order kernel right behind it, which returns at once for every other instance.
-  // Which kernel: the dataflow kernel finishes an instance ~3.5 times sooner but its tables fill the LDS (one instance per CU at
+  // Which kernel: the dataflow kernel finishes an instance 2 - 4.5 times sooner but its tables fill the LDS (one instance per CU at
   // N = 2000, three at N = 500), the list-order kernel holds four and more per CU.  Compare the number of ROUNDS the batch
-  // takes on the chip (measured, DESIGN.md 3c: N = 2000, B <= 768 dataflow, 1024 list order); RL_QSS_DF=1 / 0 forces one or
-  // the other (tests run both).
+  // takes on the chip (measured); RL_QSS_DF=1 / 0 forces one or the other (tests run both).
   const char* v1 = getenv("RL_QSS_V1");
   const char* fdf = getenv("RL_QSS_DF");
   bool use_df = rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
@@ -1044,7 +1043,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     per_cu_list = per_cu_list > 8 ? 8 : per_cu_list;
     const long long cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
     const long long rounds_df = (B + per_cu_df * cus - 1) / (per_cu_df * cus), rounds_list = (B + per_cu_list * cus - 1) / (per_cu_list * cus);
-    use_df = rounds_df <= 3 * rounds_list;
+    use_df = rounds_df <= (N >= 1024 ? 4 : 2) * rounds_list;   // (a round of the dataflow kernel: ~1/4.3 of a list-order round with four waves, ~1/2.2 with one)
   }
   if (fdf && (fdf[0] == '0' || fdf[0] == '1')) use_df = fdf[0] == '1' && rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
   if (v1 && v1[0] == '1') use_df = false;
@@ -1054,7 +1053,20 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     const char* dbg = getenv("RL_QSS_DEBUG");
     int* ddbg = nullptr;
     if (dbg && dbg[0] == '1') { RL_HIP(hipMalloc(&ddbg, (size_t)B * 12 * sizeof(int))); a.dbg = ddbg; }
-    hipLaunchKernelGGL(rl::k_qss_df, dim3(B), dim3(64), lds_df, ctx->stream, a);
+    // RL_QSS_DF_WAVES = 1: the one-wave kernel k_qss_df; 2 / 4: k_qss_dfw, the same scheduler with the agents of a pass spread over
+    // that many waves of the (one) workgroup an instance's tables leave room for.
+    // Measured: four waves 37 against 46 ms at N = 2000, one wave 4.7 against 5.2 ms at N = 500.
+    int df_waves = N >= 1024 ? 4 : 1;
+    if (const char* dw = getenv("RL_QSS_DF_WAVES")) df_waves = atoi(dw);
+    if (df_waves == 4) {
+      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+      hipLaunchKernelGGL(rl::k_qss_dfw<4>, dim3(B), dim3(256), lds_df, ctx->stream, a);
+    } else if (df_waves == 2) {
+      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+      hipLaunchKernelGGL(rl::k_qss_dfw<2>, dim3(B), dim3(128), lds_df, ctx->stream, a);
+    } else {
+      hipLaunchKernelGGL(rl::k_qss_df, dim3(B), dim3(64), lds_df, ctx->stream, a);
+    }
     RL_HIP(hipGetLastError());
     if (ddbg) {   // diagnostics only: synchronous
       std::vector<int> hd((size_t)B * 12);

@@ -34,7 +34,8 @@
 // oracle under this scheduler and checks every released step against the TRUE read/write dependencies of the sequential order
 // (24 random trajectories, N = 257 ... 2000, banked and not, two vehicles: no violation, no pass without progress, spawned
 // fronts numbered as in the reference's list).  Monza N = 2000: 213 k steps after iteration 0 in 3 686 passes of 1.9 chunks
-// (the list order: 130 k rounds); one trajectory 180 -> 48 ms on the GPU (profiles/r04_qss_*).
+// (the list order: 130 k rounds); one trajectory 167 -> 46 ms on the GPU with this kernel, 37 ms with k_qss_dfw<4> at the end of
+// this file, which spreads the agents of a pass over four waves (profiles/r04_qss_*).
 //
 // One wave per instance; everything a step or a test touches lives in LDS (160 KB at N = 2000: one instance per CU, which is
 // why rl_qss_sim_dev keeps k_qss_sim -- four instances per CU -- for batches of more than two instances per CU).  Instances
@@ -53,7 +54,7 @@ constexpr unsigned kDfNone = 0xFFFFu;
 struct DfLayout {
   int n_tab, NW, NB, HX, QC;
   size_t o_V, o_A, o_tab, o_bmE, o_bmX, o_idbm, o_WH, o_cntE, o_cntX, o_bcnt, o_scal, o_OWN, o_gE, o_idE, o_tE, o_hX, o_sG, o_sId, o_sRec,
-      o_xg, o_xid, o_xt, o_xn, o_xw, o_WN, o_pfx, o_blk, o_Q, o_Q2, bytes;
+      o_xg, o_xid, o_xt, o_xn, o_xw, o_WN, o_pfx, o_blk, o_Q, o_Q2, o_req, bytes;
 };
 __host__ __device__ inline DfLayout df_layout(int N, int acc_m, int dcc_m) {
   DfLayout L;
@@ -67,13 +68,14 @@ __host__ __device__ inline DfLayout df_layout(int N, int acc_m, int dcc_m) {
   L.o_V = take((size_t)N * 8); L.o_A = take((size_t)N * 8); L.o_tab = take((size_t)L.n_tab * 8);
   L.o_bmE = take((size_t)L.NW * 8); L.o_bmX = take((size_t)L.NW * 8); L.o_idbm = take((size_t)(kDfIdMax / 64) * 8);
   L.o_WH = take((size_t)(2 * N + 1) * 4);
-  L.o_cntE = take(kDfCnt * 4); L.o_cntX = take(kDfCnt * 4); L.o_bcnt = take(kDfCnt * 4); L.o_scal = take(16 * 4);
+  L.o_cntE = take(kDfCnt * 4); L.o_cntX = take(kDfCnt * 4); L.o_bcnt = take(kDfCnt * 4); L.o_scal = take(32 * 4);
   L.o_OWN = take((size_t)N * 2); L.o_gE = take((size_t)N * 2); L.o_idE = take((size_t)N * 2); L.o_tE = take((size_t)N * 2);
   L.o_hX = take((size_t)N * 2); L.o_sG = take((size_t)N * 2); L.o_sId = take((size_t)N * 2); L.o_sRec = take((size_t)N * 2);
   L.o_xg = take((size_t)L.HX * 2); L.o_xid = take((size_t)L.HX * 2); L.o_xt = take((size_t)L.HX * 2);
   L.o_xn = take((size_t)L.HX * 2); L.o_xw = take((size_t)L.HX * 2);
   L.o_WN = take((size_t)L.QC * 2); L.o_pfx = take((size_t)(kDfIdMax / 64) * 2); L.o_blk = take((size_t)((N + 3) / 4 + 8) * 2);
   L.o_Q = take((size_t)L.QC * 2); L.o_Q2 = take((size_t)L.QC * 2);
+  L.o_req = take((size_t)5 * 256 * 2);   // k_qss_dfw: records released / fronts born in the current batch of agents (<= 256 each)
   L.bytes = o;
   return L;
 }
@@ -757,6 +759,701 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
   }
   if (err) return;
   for (int i = lane; i < N; i += 64) {
+    const int nx = i + 1 == N ? 0 : i + 1;
+    P[(size_t)nx * 19 + 16] = SEG[nx] / (0.5 * (V[i] + V[nx]));
+  }
+}
+
+
+// ================================================================================================================
+// The same scheduler with W waves per instance (k_qss_dfw<W>).  The LDS tables of one instance fill a CU, so the other
+// three SIMDs idle while one wave works through a pass chunk by chunk (1.9 chunks of 64 on average).  Here a pass is
+// taken 64 W agents at a time, each phase once for all of them: examination | step arithmetic | profile + records |
+// lists (one lane, the few agents that die or are born) | next agents | wake-ups -- separated by workgroup barriers.
+// Rules, tables and results are those of k_qss_df above; what changes is who keeps the counters (LDS scalars and
+// atomics instead of wave-uniform registers) and that list surgery is queued for one lane instead of done in place.
+struct DfTab {
+  int N;
+  double *V, *A;
+  unsigned long long *bmE, *bmX;
+  unsigned* WH;
+  unsigned short *OWN, *gE, *idE, *tE, *hX, *sG, *sId, *sRec, *xg, *xid, *xt, *xn, *xw, *WN, *KAP;
+};
+
+__device__ __forceinline__ void dfw_summarise(const DfTab& T, int cc) {
+  int bg = (int)kDfNone, bi = (int)kDfNone, br = (int)kDfNone;
+  for (int r2 = T.hX[cc]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
+    const int g2 = T.xg[r2], i2 = T.xid[r2];
+    if (g2 < bg || (g2 == bg && i2 < bi) || br == (int)kDfNone) { bg = g2; bi = i2; br = r2; }
+  }
+  T.sG[cc] = (unsigned short)bg; T.sId[cc] = (unsigned short)bi; T.sRec[cc] = (unsigned short)br;
+}
+__device__ __forceinline__ void dfw_kappa_refresh(const DfTab& T, int blk) {
+  int m = 0xFFFF;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int wq = blk * 4 + q;
+    const int gq = wq < T.N ? (int)T.gE[wq] : (int)kDfNone;
+    const int kq = gq == (int)kDfNone ? 0xFFFF : 2 * gq - wq + T.N;
+    m = kq < m ? kq : m;
+  }
+  T.KAP[blk] = (unsigned short)m;
+}
+__device__ __forceinline__ bool dfw_kappa_below(const DfTab& T, int start, int len, int thr) {
+  const int N = T.N;
+  const int s0 = df_wrap(start, N), off = start - s0;
+  const int e = s0 + len - 1, eA = e < N ? e : N - 1;
+  int m = 0x7fffffff;
+  for (int blk = s0 >> 2; blk <= (eA >> 2); ++blk) {
+    const int kv = T.KAP[blk];
+    const int v = kv == 0xFFFF ? 0x7fffffff : kv - N - off;
+    m = v < m ? v : m;
+  }
+  if (e >= N) {
+    for (int blk = 0; blk <= ((e - N) >> 2); ++blk) {
+      const int kv = T.KAP[blk];
+      const int v = kv == 0xFFFF ? 0x7fffffff : kv - 2 * N - off;
+      m = v < m ? v : m;
+    }
+  }
+  return m < thr;
+}
+// may the agent (exit record r / enter worldline w, iteration g, id) take its next step?  -1: yes; else the list it sleeps on
+__device__ __forceinline__ int dfw_exam(const DfTab& T, bool isX, int r, int w, int g, int id, int gmin, int gminE, int gminX) {
+  typedef unsigned long long u64;
+  const int N = T.N;
+  int key = -1;
+  if (g > gmin + kDfR) return 2 * N;
+  if (isX) {
+    const int c = w, p = c + g;
+    const int cm = c == 0 ? N - 1 : c - 1;
+    const int my_min = T.sRec[c];
+    const int fg = T.sG[cm], fi = T.sId[cm];
+    u64 win = df_window(T.bmX, N, df_wrap(c + 1, N)) & df_mask(kDfR + 2);
+    if (my_min != r) key = N + c;
+    else if (fg <= g) {
+      if (fi < id) key = N + cm;
+      else if (fg < g) {
+        for (int r2 = T.hX[cm]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
+          if ((int)T.xid[r2] < id && (int)T.xg[r2] <= g) { key = N + cm; break; }
+        }
+      }
+    }
+    if (key < 0 && win) {
+      const int k = __ffsll((long long)win);
+      const int cl = df_wrap(c + k, N);
+      const int lg = T.sG[cl];
+      if (lg <= g - k + 1) {
+        if (k == 1 && lg == g && (int)T.sId[cl] > id) {
+          win &= win - 1ull;
+          if (win) {
+            const int k2 = __ffsll((long long)win);
+            const int cl2 = df_wrap(c + k2, N);
+            if ((int)T.sG[cl2] <= g - k2 + 1) key = N + cl2;
+          }
+        } else key = N + cl;
+      }
+    }
+    int behind_top = p + gminE;
+    if (key < 0 && g + 1 >= gminE) {
+      const int start = p + 1 + gminE, len = g - gminE + 2;
+      u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
+      while (we) {
+        const int bit = 63 - __clzll((long long)we);
+        const int wu = start + bit, ws = df_wrap(wu, N);
+        const int ge = T.gE[ws], pe = wu - ge;
+        if (pe >= p + 2 || (pe == p + 1 && ge <= g)) { key = ws; break; }
+        if (pe <= p) { behind_top = wu; break; }
+        we &= ~(1ull << bit);
+      }
+    }
+    if (key < 0 && g - 2 >= gminE) {
+      const int start = c + 2 + 2 * gminE;
+      const int top = behind_top < c + 2 * g - 2 ? behind_top : c + 2 * g - 2;
+      const int len = top - start + 1;
+      if (len > 0 && dfw_kappa_below(T, start, len, -c - 1)) {
+        u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
+        while (we) {
+          const int bit = __ffsll((long long)we) - 1;
+          const int wu = start + bit, ws = df_wrap(wu, N);
+          const int ge = T.gE[ws], pe = wu - ge;
+          if (pe <= p && ge + 1 + (p - pe) < g) { key = ws; break; }
+          we &= we - 1ull;
+        }
+      }
+    }
+  } else {
+    const int c = w, p = c + 2 * N - g;
+    const int cu = c + 1 == N ? 0 : c + 1;
+    const int ag = T.gE[cu], ai = T.idE[cu];
+    u64 win = df_window(T.bmE, N, df_wrap(c + N - (kDfR + 2), N)) & df_mask(kDfR + 2);
+    if (ag != (int)kDfNone && ai < id && ag <= g) key = cu;
+    if (key < 0 && win) {
+      const int j = 63 - __clzll((long long)win);
+      const int k = kDfR + 2 - j;
+      const int ws = df_wrap(c + N - k, N);
+      const int gh = T.gE[ws];
+      if (gh <= g - k + 1) {
+        if (k == 1 && gh == g && (int)T.idE[ws] > id) {
+          win &= ~(1ull << j);
+          if (win) {
+            const int j2 = 63 - __clzll((long long)win);
+            const int k2 = kDfR + 2 - j2;
+            const int ws2 = df_wrap(c + N - k2, N);
+            if ((int)T.gE[ws2] <= g - k2 + 1) key = ws2;
+          }
+        } else key = ws;
+      }
+    }
+    if (key < 0 && g >= gminX) {
+      const int start = p - 1 - g, len = g - gminX + 1;
+      u64 wx = df_window(T.bmX, N, df_wrap(start, N)) & df_mask(len);
+      while (wx) {
+        const int bit = __ffsll((long long)wx) - 1;
+        const int cu2 = start + bit, cs = df_wrap(cu2, N);
+        const int g2 = T.sG[cs], px = cu2 + g2;
+        if (px <= p - 2 || (px == p - 1 && g2 < g)) { key = N + cs; break; }
+        if (px >= p) break;
+        wx &= wx - 1ull;
+      }
+    }
+    if (key < 0 && g - 2 >= gminE) {
+      const int len = 2 * (g - gminE) - 3;
+      const int start = c + 2 * N - 2 * (g - gminE) + 1;
+      if (len > 0 && dfw_kappa_below(T, start, len, 2 * g - c - 2 * N)) {
+        u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
+        while (we) {
+          const int bit = __ffsll((long long)we) - 1;
+          const int wu = start + bit, ws = df_wrap(wu, N);
+          const int ge = T.gE[ws], pe = wu - ge;
+          if (pe <= p - 1 && ge + (p - pe) < g) { key = ws; break; }
+          we &= we - 1ull;
+        }
+      }
+    }
+  }
+  return key;
+}
+
+struct DfStep { int new_stop, e, spawned, wr, nown; double nv, na; };
+struct DfStepCtx {
+  const QssArgs* a; const DfTab* T; double lat0; bool small_tabs; const Ppoly2 *pa2, *pd2;
+  const double *t_ax, *t_ac, *t_dx, *t_dc;
+};
+// One step of one side of one front (:154-254 enter, :257-348 exit) -- the arithmetic of k_qss_sim, expression for expression.
+__device__ __forceinline__ DfStep dfw_step(const DfStepCtx& C, int side, int li, int ni, double dd, double rn, double gsn, int turn) {
+#pragma clang fp contract(off)
+  const QssArgs& a = *C.a;
+  const DfTab& T = *C.T;
+  DfStep o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+  const double lv = T.V[li], la = T.A[li];
+  if (lv == 0.0) { o.e = 1; return o; }
+  const double dt = dd / lv;
+  const double max_dacc = dt * a.max_jerk;
+  double max_acc = la + max_dacc, min_acc = la - max_dacc;
+  const double vmax_acc = C.small_tabs ? C.pa2->eval(lv) : ppoly_eval(C.t_ax, C.t_ac, a.acc_m, lv);
+  const double vmax_dcc = C.small_tabs ? C.pd2->eval(lv) : ppoly_eval(C.t_dx, C.t_dc, a.dcc_m, lv);
+  max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
+  min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
+  double min_state, max_state;
+  if (side == 0) {  // v0^2 = v^2 - 2 a x
+    const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
+    min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+  } else {          // v^2 = 2 a x + v0^2
+    const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
+    max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+  }
+  const double max_curve = sqrt(fabs(fabs(qss_acc_circle_lon(a, la)) - gsn) * rn);  // calc_v, :54-55
+  double greedy = max_state < max_curve ? max_state : max_curve;
+  if (a.max_speed < greedy) greedy = a.max_speed;
+  if (greedy != greedy) { o.e = 1; return o; }
+  if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve && greedy <= a.max_speed) {
+    const double pv = T.V[ni], pa = T.A[ni];
+    if (T.OWN[ni] != 0xFFFF && pv < greedy) {
+      o.new_stop = 1;
+    } else {
+      if (!(min_acc <= pa && pa <= max_acc)) o.new_stop = -1;
+      o.wr = 1; o.nv = greedy; o.nown = turn;
+      o.na = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
+    }
+  } else {
+    o.new_stop = 1;
+    if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
+      o.spawned = 1; o.wr = 1;
+      const double v = sqrt(fabs(fabs(C.lat0) - gsn) * rn);
+      o.nv = v < a.max_speed ? v : a.max_speed;
+      o.na = 0.0; o.nown = ni;
+    }
+  }
+  return o;
+}
+
+
+enum { DFS_Q2N = 0, DFS_NWIN, DFS_ERR, DFS_BAIL, DFS_NFREE, DFS_NSPQ, DFS_GMINE, DFS_GMINX, DFS_GMIN, DFS_CHG, DFS_NE, DFS_NX, DFS_MAXG,
+       DFS_QN, DFS_NU, DFS_DEXAM, DFS_DSTEP, DFS_COUNT };
+static_assert(DFS_COUNT <= 32, "scalars");
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
+#pragma clang fp contract(off)  // decisions below compare freshly computed speeds: keep the reference's roundings
+  extern __shared__ double qss_lds[];
+  typedef unsigned short u16;
+  typedef unsigned long long u64;
+  constexpr int TT = 64 * W;
+  const int b = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const DfLayout L = df_layout(N, a.acc_m, a.dcc_m);
+  char* lds = reinterpret_cast<char*>(qss_lds);
+  DfTab T;
+  T.N = N;
+  T.V = reinterpret_cast<double*>(lds + L.o_V); T.A = reinterpret_cast<double*>(lds + L.o_A);
+  double* tab = reinterpret_cast<double*>(lds + L.o_tab);
+  double* t_ax = tab; double* t_ac = t_ax + a.acc_m + 1;
+  double* t_dx = t_ac + 4 * a.acc_m; double* t_dc = t_dx + a.dcc_m + 1;
+  T.bmE = reinterpret_cast<u64*>(lds + L.o_bmE); T.bmX = reinterpret_cast<u64*>(lds + L.o_bmX);
+  u64* IDBM = reinterpret_cast<u64*>(lds + L.o_idbm);
+  T.WH = reinterpret_cast<unsigned*>(lds + L.o_WH);
+  int* cntE = reinterpret_cast<int*>(lds + L.o_cntE);
+  int* cntX = reinterpret_cast<int*>(lds + L.o_cntX);
+  int* bcnt = reinterpret_cast<int*>(lds + L.o_bcnt);
+  int* scal = reinterpret_cast<int*>(lds + L.o_scal);
+  T.OWN = reinterpret_cast<u16*>(lds + L.o_OWN);
+  T.gE = reinterpret_cast<u16*>(lds + L.o_gE); T.idE = reinterpret_cast<u16*>(lds + L.o_idE); T.tE = reinterpret_cast<u16*>(lds + L.o_tE);
+  T.hX = reinterpret_cast<u16*>(lds + L.o_hX); T.sG = reinterpret_cast<u16*>(lds + L.o_sG);
+  T.sId = reinterpret_cast<u16*>(lds + L.o_sId); T.sRec = reinterpret_cast<u16*>(lds + L.o_sRec);
+  T.xg = reinterpret_cast<u16*>(lds + L.o_xg); T.xid = reinterpret_cast<u16*>(lds + L.o_xid); T.xt = reinterpret_cast<u16*>(lds + L.o_xt);
+  T.xn = reinterpret_cast<u16*>(lds + L.o_xn); T.xw = reinterpret_cast<u16*>(lds + L.o_xw);
+  T.WN = reinterpret_cast<u16*>(lds + L.o_WN);
+  u16* PFX = reinterpret_cast<u16*>(lds + L.o_pfx);
+  T.KAP = reinterpret_cast<u16*>(lds + L.o_blk);
+  u16* Q = reinterpret_cast<u16*>(lds + L.o_Q);
+  u16* Q2 = reinterpret_cast<u16*>(lds + L.o_Q2);
+  double* const V = T.V; double* const A = T.A;
+  u16* const OWN = T.OWN; u16* const gE = T.gE; u16* const idE = T.idE; u16* const tE = T.tE; u16* const hX = T.hX;
+  u16* const sG = T.sG; u16* const sId = T.sId; u16* const sRec = T.sRec;
+  u16* const xg = T.xg; u16* const xid = T.xid; u16* const xt = T.xt; u16* const xn = T.xn; u16* const xw = T.xw; u16* const WN = T.WN;
+  u64* const bmE = T.bmE; u64* const bmX = T.bmX; unsigned* const WH = T.WH;
+  const int HX = L.HX;
+  // global scratch of this instance
+  double* P = a.points + (size_t)b * N * 19;
+  double* SEG = a.cst + (size_t)b * 3 * N;
+  double* RAD = SEG + N;
+  double* GS = RAD + N;
+  u16* U = reinterpret_cast<u16*>(a.flags + (size_t)b * 5 * a.cap);   // spawned fronts awaiting their number: birth, parent id, enter worldline, exit record
+  const int Ucap = (5 * a.cap * 4) / 8;
+  u16* FREEQ = reinterpret_cast<u16*>(lds + L.o_req);                  // exit records released in the current batch of agents
+  u16* SPQ = FREEQ + TT;                                               // fronts born in it: g, parent id, enter worldline, target sample
+  u16* WINQ = reinterpret_cast<u16*>(a.fresh + (size_t)b * a.cap);     // agents asleep on the iteration window: a ring of 2^k <= 2 cap entries
+  const int win_mask = (1 << (31 - __clz(2 * a.cap))) - 1;             //   (>= cap = 4 N + 16 > every agent there can be)
+  const double lat0 = qss_acc_circle_lon(a, 0.0);
+
+  if (a.tab_n > 0) {
+    for (int i = tid; i < a.tab_n; i += TT) tab[i] = a.tab[i];
+  } else {
+    for (int i = tid; i <= a.acc_m; i += TT) t_ax[i] = a.acc_x[i];
+    for (int i = tid; i < 4 * a.acc_m; i += TT) t_ac[i] = a.acc_c[i];
+    for (int i = tid; i <= a.dcc_m; i += TT) t_dx[i] = a.dcc_x[i];
+    for (int i = tid; i < 4 * a.dcc_m; i += TT) t_dc[i] = a.dcc_c[i];
+  }
+  for (int i = tid; i < 2 * N + 1; i += TT) WH[i] = kDfNone;
+  for (int i = tid; i < N; i += TT) {  // simulator.py:133-147
+    const double* p = P + (size_t)i * 19;
+    const double* q = P + (size_t)(i == 0 ? N - 1 : i - 1) * 19;
+    const double ddx = p[0] - q[0], ddy = p[1] - q[1];
+    SEG[i] = sqrt(ddx * ddx + ddy * ddy);
+    RAD[i] = p[5];
+    GS[i] = 9.81 * sin(p[13]);
+    const double v = qss_calc_v(lat0, p[5], p[13]);
+    V[i] = v < a.max_speed ? v : a.max_speed;
+    A[i] = 0.0;
+    OWN[i] = (u16)i;
+    gE[i] = 0; idE[i] = (u16)i; tE[i] = (u16)i;
+    hX[i] = (u16)i; sG[i] = 0; sId[i] = (u16)i; sRec[i] = (u16)i;
+    xg[i] = 0; xid[i] = (u16)i; xt[i] = (u16)i; xn[i] = (u16)kDfNone; xw[i] = (u16)i;
+  }
+  for (int i = N + tid; i < HX; i += TT) xn[i] = (u16)(i + 1 < HX ? i + 1 : kDfNone);   // free records
+  for (int i = tid; i < kDfCnt; i += TT) { cntE[i] = 0; cntX[i] = 0; bcnt[i] = 0; }
+  if (tid < 32) scal[tid] = 0;
+  __syncthreads();
+  const bool small_tabs = a.acc_m <= 2 && a.dcc_m <= 2;
+  Ppoly2 pa2, pd2;
+  pa2.load(t_ax, t_ac, a.acc_m < 2 ? 1 : 2); pd2.load(t_dx, t_dc, a.dcc_m < 2 ? 1 : 2);
+  DfStepCtx C;
+  C.a = &a; C.T = &T; C.lat0 = lat0; C.small_tabs = small_tabs; C.pa2 = &pa2; C.pd2 = &pd2;
+  C.t_ax = t_ax; C.t_ac = t_ac; C.t_dx = t_dx; C.t_dc = t_dc;
+
+  // ---- iteration 0 in list order (see k_qss_df): wave 0 alone; it also lays out the tables of iteration 1
+  int free_head = (int)kDfNone, next_id = N, Ulo = 0, numbered_upto = 0;   // kept by wave 0
+  if (wave == 0) {
+    int err0 = 0, bail0 = 0, nsp = 0;
+    for (int base = 0; base < N && !err0 && !bail0; base += 64) {
+      const int f = base + lane;
+      const bool in = f < N;
+      const int ni = f == 0 ? N - 1 : f - 1;
+      DfStep o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+      if (in) o = dfw_step(C, 0, f, ni, SEG[f], RAD[ni], GS[ni], f);
+      DF_SYNC();
+      if (__any(in && o.e)) { err0 = 1; break; }
+      if (in && o.wr) { V[ni] = o.nv; A[ni] = o.na; OWN[ni] = (u16)o.nown; }
+      const u64 sm = __ballot(in && o.spawned);
+      if (nsp + __popcll(sm) > HX - N) { bail0 = 4; break; }
+      if (in) {
+        if (o.new_stop != 1) gE[f] = 1;
+        else if (o.spawned) {
+          const int rank = nsp + __popcll(sm & ((1ull << lane) - 1ull)), rec = N + rank;
+          gE[f] = 1; idE[f] = (u16)(N + rank); tE[f] = (u16)ni;
+          xg[rec] = 1; xid[rec] = (u16)(N + rank); xt[rec] = (u16)ni; xw[rec] = (u16)df_wrap(ni + 2 * N - 1, N);
+        } else gE[f] = (u16)kDfNone;
+      }
+      nsp += __popcll(sm);
+      DF_SYNC();
+    }
+    for (int base = 0; base < N && !err0 && !bail0; base += 64) {
+      const int f = base + lane;
+      const bool in = f < N;
+      const int ni = f + 1 == N ? 0 : f + 1;
+      double dd = 0.0, rn = 0.0, gsn = 0.0;
+      if (in) { dd = SEG[ni]; rn = RAD[ni]; gsn = GS[ni]; }
+      u64 pending = __ballot(in);
+      while (pending != 0ull) {
+        const bool pend = (pending >> lane) & 1ull;
+        DfStep o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+        if (pend) o = dfw_step(C, 1, f, ni, dd, rn, gsn, f);
+        const u64 wrm = __ballot(pend && o.wr);
+        const u64 lowm = (1ull << lane) - 1ull;
+        const u64 gaps = ~pending & lowm;
+        const u64 run = gaps ? lowm & ~((2ull << (63 - __clzll((long long)gaps))) - 1ull) : lowm;
+        const bool ok = pend && (wrm & run) == 0ull;
+        DF_SYNC();
+        if (__any(ok && o.e)) { err0 = 1; break; }
+        if (ok && o.wr) { V[ni] = o.nv; A[ni] = o.na; OWN[ni] = (u16)o.nown; }
+        if (ok) xg[f] = o.new_stop == 1 ? (u16)kDfNone : (u16)1;
+        pending &= ~__ballot(ok);
+        DF_SYNC();
+      }
+    }
+    int nE = 0, nX = 0, qn0 = 0;
+    if (!err0 && !bail0) {
+      for (int i = lane; i < N; i += 64) { hX[i] = xg[i] == 1 ? (u16)i : (u16)kDfNone; xn[i] = (u16)kDfNone; }
+      DF_SYNC();
+      for (int k = lane; k < nsp; k += 64) {
+        const int rec = N + k, cxw = xw[rec];
+        xn[rec] = hX[cxw]; hX[cxw] = (u16)rec;
+      }
+      DF_SYNC();
+      for (int i = lane; i < L.NW; i += 64) { bmE[i] = 0ull; bmX[i] = 0ull; }
+      DF_SYNC();
+      for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        const bool in = i < N;
+        const bool ea = in && gE[i] != (u16)kDfNone, xa = in && hX[i] != (u16)kDfNone;
+        const u64 em = __ballot(ea), xm = __ballot(xa);
+        if (lane == 0) { bmE[base >> 6] = em; bmX[base >> 6] = xm; }
+        if (ea) Q[qn0 + __popcll(em & ((1ull << lane) - 1ull))] = (u16)i;
+        qn0 += __popcll(em); nE += __popcll(em);
+      }
+      DF_SYNC();
+      for (int base = 0; base < N + nsp; base += 64) {
+        const int i = base + lane;
+        const bool al = i < N + nsp && (i >= N || xg[i] == 1);
+        const u64 am = __ballot(al);
+        if (al) Q[qn0 + __popcll(am & ((1ull << lane) - 1ull))] = (u16)(N + i);
+        qn0 += __popcll(am); nX += __popcll(am);
+      }
+    }
+    free_head = N + nsp < HX ? N + nsp : (int)kDfNone;
+    next_id = N + nsp;
+    if (lane == 0) {
+      scal[DFS_ERR] = err0; scal[DFS_BAIL] = bail0; scal[DFS_QN] = qn0; scal[DFS_NE] = nE; scal[DFS_NX] = nX;
+      scal[DFS_GMINE] = nE > 0 ? 1 : 0x7000; scal[DFS_GMINX] = nX > 0 ? 1 : 0x7000;
+      scal[DFS_GMIN] = nE > 0 || nX > 0 ? 1 : 0x7000;
+      cntE[1] = nE; cntX[1] = nX;
+    }
+  }
+  __syncthreads();
+  const int NK = (N + 3) / 4;
+  if (!scal[DFS_ERR] && !scal[DFS_BAIL]) {
+    for (int i = tid; i < N; i += TT) dfw_summarise(T, i);
+    for (int blk = tid; blk < NK; blk += TT) dfw_kappa_refresh(T, blk);
+  }
+  __syncthreads();
+
+  int qn = scal[DFS_QN], gminE = scal[DFS_GMINE], gminX = scal[DFS_GMINX], gmin = scal[DFS_GMIN];
+  int err = scal[DFS_ERR], bail = scal[DFS_BAIL];
+  int d_pass = 0, d_chunk = 0, d_qmax = 0, d_num = 0, my_exam = 0, my_step = 0, my_maxg = 0;
+  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
+  const bool timing = a.dbg != nullptr;
+#define DFW_TICK(k) do { if (timing) { const long long tn = clock64(); tp[k] += tn - tq; tq = tn; } } while (0)
+  const int g_cap = N - 1;
+  // A sleeper is linked in with a compare-and-swap, its link written first: a wake-up of another wave that empties the list at
+  // the same moment either sees it complete or not at all.
+  auto sleep_on = [&](int key, int h) {
+    unsigned old = WH[key];
+    while (true) {
+      WN[h] = (u16)old;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      const unsigned seen = atomicCAS(&WH[key], old, (unsigned)h);
+      if (seen == old) break;
+      old = seen;
+    }
+  };
+  // the next pass's queue: each wave reserves room for its agents with one atomic on a counter that is never reset (q2base = its
+  // value when the pass began)
+  int q2base = 0, win_head = 0;
+  auto push_next = [&](bool want, int h) {
+    const u64 m = __ballot(want);
+    if (m != 0ull) {
+      int basew = 0;
+      if (lane == 0) basew = atomicAdd(&scal[DFS_Q2N], __popcll(m));
+      basew = __shfl(basew, 0);
+      if (want) Q2[basew - q2base + __popcll(m & ((1ull << lane) - 1ull))] = (u16)h;
+    }
+  };
+
+  while (qn > 0 && !err && !bail) {
+    ++d_pass; d_qmax = qn > d_qmax ? qn : d_qmax;
+    for (int base = 0; base < qn; base += TT) {
+      ++d_chunk;
+      if (timing) tq = clock64();
+      const int qi = base + tid;
+      const bool valid = qi < qn;
+      const int h = valid ? Q[qi] : 0;
+      const bool isX = h >= N;
+      const int r = isX ? h - N : 0;
+      const int w = isX ? xw[r] : h;
+      const int g = isX ? xg[r] : gE[w];
+      const int id = isX ? xid[r] : idE[w];
+      const int turn = isX ? xt[r] : tE[w];
+      const int side = isX ? 1 : 0;
+      const int li = side == 0 ? df_wrap(w + N - g, N) : df_wrap(w + g, N);
+      const int ni = side == 0 ? (li - 1 < 0 ? N - 1 : li - 1) : (li + 1 == N ? 0 : li + 1);
+      double dd = 0.0, rn = 0.0, gsn = 0.0;
+      if (valid) { dd = SEG[side == 0 ? li : ni]; rn = RAD[ni]; gsn = GS[ni]; }
+      // ---- examination (the tables are only read; sleepers are linked in with atomics)
+      const int key = valid ? dfw_exam(T, isX, r, w, g, id, gmin, gminE, gminX) : -1;
+      const bool ready = valid && key < 0;
+      my_exam += valid ? 1 : 0; my_step += ready ? 1 : 0;
+      if (valid && key >= 0) {
+        if (key == 2 * N) { const int slot = atomicAdd(&scal[DFS_NWIN], 1) & win_mask; WINQ[slot] = (u16)h; }
+        else sleep_on(key, h);
+      }
+      DFW_TICK(0);
+      // ---- the step
+      DfStep o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+      if (ready) o = dfw_step(C, side, li, ni, dd, rn, gsn, turn);
+      const int spawned = o.spawned;
+      const bool die = ready && o.new_stop == 1;
+      DFW_TICK(1);
+      __syncthreads();   // every examination and every step of the batch has read what it needs
+      DFW_TICK(2);
+      // ---- profile, own records, deaths and births queued for the one lane that edits the shared lists
+      if (ready && o.e) atomicOr(&scal[DFS_ERR], 1);
+      if (ready && o.wr) { V[ni] = o.nv; A[ni] = o.na; OWN[ni] = (u16)o.nown; }
+      if (ready && !die && g + 1 > g_cap) atomicMax(&scal[DFS_BAIL], 2);
+      if (ready && a.df_bail_at > 0 && g >= a.df_bail_at) atomicMax(&scal[DFS_BAIL], 7);
+      if (ready) my_maxg = g > my_maxg ? g : my_maxg;
+      if (ready && !isX) {
+        atomicSub(&cntE[g & (kDfCnt - 1)], 1);
+        if (!die) { gE[w] = (u16)(g + 1); atomicAdd(&cntE[(g + 1) & (kDfCnt - 1)], 1); }
+        else if (spawned) {
+          gE[w] = (u16)(g + 1); idE[w] = (u16)kDfNone; tE[w] = (u16)ni;
+          atomicAdd(&cntE[(g + 1) & (kDfCnt - 1)], 1);
+          atomicAdd(&bcnt[g & (kDfCnt - 1)], 1);
+          const int slot = atomicAdd(&scal[DFS_NSPQ], 1);
+          u16* sp = SPQ + 4 * slot;
+          sp[0] = (u16)g; sp[1] = (u16)id; sp[2] = (u16)w; sp[3] = (u16)ni;
+        } else { gE[w] = (u16)kDfNone; atomicAnd(&bmE[w >> 6], ~(1ull << (w & 63))); atomicSub(&scal[DFS_NE], 1); }
+        dfw_kappa_refresh(T, w >> 2);
+      }
+      if (ready && isX) {
+        atomicSub(&cntX[g & (kDfCnt - 1)], 1);
+        if (!die) { xg[r] = (u16)(g + 1); atomicAdd(&cntX[(g + 1) & (kDfCnt - 1)], 1); }
+        else {   // leaves its worldline's list (only the next agent of a worldline can have stepped: the lists differ)
+          int prev = (int)kDfNone, cur = hX[w];
+          while (cur != r) { prev = cur; cur = xn[cur]; }
+          if (prev == (int)kDfNone) hX[w] = xn[r]; else xn[prev] = xn[r];
+          if (hX[w] == (u16)kDfNone) atomicAnd(&bmX[w >> 6], ~(1ull << (w & 63)));
+          const int slot = atomicAdd(&scal[DFS_NFREE], 1);
+          FREEQ[slot] = (u16)r;
+          atomicSub(&scal[DFS_NX], 1);
+        }
+      }
+      DFW_TICK(3);
+      __syncthreads();
+      err = scal[DFS_ERR]; bail = scal[DFS_BAIL];
+      if (err || bail) break;
+      const int cx = df_wrap(ni + 2 * N - (g + 1), N);   // (of a front born here: its exit worldline)
+      {
+        const int nfree = scal[DFS_NFREE], nspq = scal[DFS_NSPQ];
+        if (nfree != 0 || nspq != 0) {
+          if (tid == 0) {
+            int nU = scal[DFS_NU], bl = 0;
+            for (int q = 0; q < nfree; ++q) { const int rr = FREEQ[q]; xn[rr] = (u16)free_head; free_head = rr; }
+            for (int q = 0; q < nspq && !bl; ++q) {
+              const u16* sp = SPQ + 4 * q;
+              const int sg = sp[0], sid = sp[1], sw = sp[2], sni = sp[3];
+              if (nU >= Ucap) { bl = 3; break; }
+              if (free_head == (int)kDfNone) { bl = 4; break; }
+              const int rec = free_head;
+              free_head = xn[rec];
+              const int cxx = df_wrap(sni + 2 * N - (sg + 1), N);
+              xg[rec] = (u16)(sg + 1); xid[rec] = (u16)kDfNone; xt[rec] = (u16)sni; xw[rec] = (u16)cxx;
+              xn[rec] = hX[cxx]; hX[cxx] = (u16)rec;
+              bmX[cxx >> 6] |= 1ull << (cxx & 63);
+              atomicAdd(&cntX[(sg + 1) & (kDfCnt - 1)], 1);
+              u16* u = U + (size_t)4 * nU;
+              u[0] = (u16)sg; u[1] = (u16)sid; u[2] = (u16)sw; u[3] = (u16)rec;
+              ++nU;
+              atomicAdd(&scal[DFS_NX], 1);
+            }
+            scal[DFS_NU] = nU;   // (the two request counters are cleared further down, once every thread has read them)
+            if (bl) atomicMax(&scal[DFS_BAIL], bl);
+          }
+          __syncthreads();
+          bail = scal[DFS_BAIL];
+          if (bail) break;
+        }
+      }
+      DFW_TICK(4);
+      // ---- the next agent of every exit worldline whose list or iteration counters have changed
+      if (ready && isX) {
+        if (!die && (int)hX[w] == r && xn[r] == (u16)kDfNone) sG[w] = (u16)(g + 1);
+        else dfw_summarise(T, w);
+      }
+      if (ready && spawned) dfw_summarise(T, cx);
+      __syncthreads();
+      if (tid == 0) { scal[DFS_NFREE] = 0; scal[DFS_NSPQ] = 0; }
+      DFW_TICK(5);
+      // ---- wake whoever sleeps on my worldline ...
+      {
+        unsigned cur = kDfNone;
+        if (ready) cur = atomicExch(&WH[isX ? N + w : w], kDfNone);
+        while (__any(cur != kDfNone)) {
+          push_next(cur != kDfNone, (int)cur);
+          if (cur != kDfNone) cur = WN[cur];
+        }
+      }
+      // ---- ... and queue myself, or go to sleep at once on the neighbour that blocks the next step
+      int skey = -1;
+      if (ready && !die) {
+        const int g1 = g + 1;
+        if (isX) {
+          const int cm = w == 0 ? N - 1 : w - 1;
+          if ((int)sRec[w] != r) skey = N + w;
+          else if ((int)sG[cm] <= g1 && (int)sId[cm] < id) skey = N + cm;
+        } else {
+          const int cu = w + 1 == N ? 0 : w + 1, cd = w == 0 ? N - 1 : w - 1;
+          const int ag = gE[cu], bg = gE[cd];
+          if (ag != (int)kDfNone && (int)idE[cu] < id && ag <= g1) skey = cu;
+          else if (bg != (int)kDfNone && bg <= g1 && !(bg == g1 && (int)idE[cd] > id)) skey = cd;
+        }
+        if (skey >= 0) sleep_on(skey, h);
+      }
+      push_next(ready && !die && skey < 0, h);
+      __syncthreads();
+      DFW_TICK(6);
+    }
+    if (err || bail) break;
+    if (timing) tq = clock64();
+    // ---- end of the pass: window (every thread from the same counters: nothing to broadcast), numbering (wave 0), next queue
+    {
+      const int og = gmin;
+      int guard = 0;
+      if (scal[DFS_NE] > 0) { while (cntE[gminE & (kDfCnt - 1)] == 0 && ++guard <= kDfCnt) ++gminE; } else gminE = 0x7000;
+      if (scal[DFS_NX] > 0) { while (cntX[gminX & (kDfCnt - 1)] == 0 && ++guard <= 2 * kDfCnt) ++gminX; } else gminX = 0x7000;
+      if (guard > kDfCnt) bail = 8;
+      gmin = gminE < gminX ? gminE : gminX;
+      if (gmin != og) {
+        const int tail = scal[DFS_NWIN];
+        for (int base = win_head; base < tail; base += TT) { const int i = base + tid; push_next(i < tail, i < tail ? (int)WINQ[i & win_mask] : 0); }
+        win_head = tail;
+      }
+    }
+    if (wave == 0) {   // fronts born in iterations every enter agent has finished get their ids: by (birth, id of the parent) = list order
+      const int nU = scal[DFS_NU];
+      int bl = 0;
+      while (numbered_upto + 1 < gminE && Ulo < nU && !bl) {
+        const int bth = numbered_upto + 1;
+        ++numbered_upto;
+        if (bcnt[bth & (kDfCnt - 1)] == 0) continue;
+        ++d_num;
+        IDBM[lane] = 0ull; IDBM[lane + 64] = 0ull;
+        DF_SYNC();
+        for (int i = Ulo + lane; i < nU; i += 64) {
+          const u16* u = U + (size_t)4 * i;
+          if (u[0] == (u16)bth) atomicOr(&IDBM[u[1] >> 6], 1ull << (u[1] & 63));
+        }
+        DF_SYNC();
+        const int c0 = __popcll(IDBM[2 * lane]), c1 = __popcll(IDBM[2 * lane + 1]);
+        int incl = c0 + c1;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const int excl = incl - c0 - c1;
+        PFX[2 * lane] = (u16)excl; PFX[2 * lane + 1] = (u16)(excl + c0);
+        const int total = __shfl(incl, 63);
+        if (next_id + total >= kDfIdMax) { bl = 5; break; }
+        DF_SYNC();
+        for (int i = Ulo + lane; i < nU; i += 64) {
+          u16* u = U + (size_t)4 * i;
+          if (u[0] == (u16)bth) {
+            const int pid = u[1];
+            const int nid = next_id + PFX[pid >> 6] + __popcll(IDBM[pid >> 6] & ((1ull << (pid & 63)) - 1ull));
+            idE[u[2]] = (u16)nid; xid[u[3]] = (u16)nid;
+          }
+        }
+        DF_SYNC();
+        for (int base = Ulo; base < nU; base += 64) {
+          const int i = base + lane;
+          u16* u = U + (size_t)4 * (i < nU ? i : Ulo);
+          const bool sel = i < nU && u[0] == (u16)bth;
+          if (sel) dfw_summarise(T, xw[u[3]]);
+          push_next(sel, u[2]);
+          push_next(sel, N + u[3]);
+          if (sel) u[0] = (u16)kDfNone;
+        }
+        next_id += total;
+        if (lane == 0) bcnt[bth & (kDfCnt - 1)] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // (the marks just written to U, read back by other lanes below)
+        DF_SYNC();
+        while (Ulo < nU) {
+          const int i = Ulo + lane;
+          const bool open = i < nU && U[(size_t)4 * i] != (u16)kDfNone;
+          const u64 om = __ballot(open);
+          if (om != 0ull) { Ulo += __ffsll((long long)om) - 1; break; }
+          Ulo += 64;
+        }
+        if (Ulo > nU) Ulo = nU;
+      }
+      if (bl && lane == 0) atomicMax(&scal[DFS_BAIL], bl);
+    }
+    __syncthreads();
+    { const int bl = scal[DFS_BAIL]; bail = bl > bail ? bl : bail; }
+    if (bail) break;
+    { const int q2 = scal[DFS_Q2N]; qn = q2 - q2base; q2base = q2; }
+    { u16* t = Q; Q = Q2; Q2 = t; }
+    if (qn == 0 && scal[DFS_NE] + scal[DFS_NX] > 0) bail = 6;
+    if (d_pass > 64 * N) bail = 9;
+    DFW_TICK(7);
+  }
+  // the last iteration any step ran in = the reference's iteration counter
+  atomicMax(&scal[DFS_MAXG], my_maxg);
+  if (a.dbg) { atomicAdd(&scal[DFS_DEXAM], my_exam); atomicAdd(&scal[DFS_DSTEP], my_step); }
+  __syncthreads();
+  const int maxg = scal[DFS_MAXG];
+  if (a.dbg && tid == 0) {
+    int* d = a.dbg + 12 * b;
+    d[0] = d_pass; d[1] = d_chunk; d[2] = scal[DFS_DEXAM]; d[3] = scal[DFS_DSTEP]; d[4] = d_qmax; d[5] = d_num; d[6] = scal[DFS_NU]; d[7] = bail;
+    d[8] = (int)((tp[0] + tp[1]) >> 10); d[9] = (int)((tp[2] + tp[3]) >> 10); d[10] = (int)((tp[4] + tp[5] + tp[6]) >> 10); d[11] = (int)(tp[7] >> 10);
+  }
+  if (bail && !err) { if (tid == 0) a.iters[b] = -2; return; }
+  if (tid == 0) a.iters[b] = err ? -1 : maxg;
+  for (int i = tid; i < N; i += TT) {
+    double* p = P + (size_t)i * 19;
+    const double v = V[i];
+    p[4] = v; p[14] = A[i];
+    p[15] = v * v / RAD[i] + GS[i];
+    p[18] = OWN[i] == 0xFFFF ? -1.0 : (double)OWN[i];
+  }
+  if (err) return;
+  for (int i = tid; i < N; i += TT) {
     const int nx = i + 1 == N ? 0 : i + 1;
     P[(size_t)nx * 19 + 16] = SEG[nx] / (0.5 * (V[i] + V[nx]));
   }

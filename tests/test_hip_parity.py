@@ -611,35 +611,41 @@ def test_qss_simulator_batch_and_bank(rl, fits):
         np.testing.assert_allclose(out[b][:, [4, 14, 15, 16]], ref[:, [4, 14, 15, 16]], rtol=0, atol=1e-10)
 
 
-@pytest.mark.parametrize("kernel", ["dataflow", "list-order"])
+@pytest.mark.parametrize("kernel", ["dataflow, one wave", "dataflow, four waves", "list-order"])
 def test_qss_randomised_vs_oracle(rl, kernel):
-    """Both simulator kernels beside the oracle's list-order loop on random trajectories (tools/validate_qss.py: N = 257 ... 2000,
+    """The simulator kernels beside the oracle's list-order loop on random trajectories (tools/validate_qss.py: N = 257 ... 2000,
     with and without bank, 2- and 3/4-piece vehicle tables, three speed / jerk limits): owner flags and iteration counts equal,
-    profiles to 1e-10.  k_qss_df (round 4) executes the reference's steps OUT of list order, k_qss_sim in it; RL_QSS_DF picks."""
+    profiles to 1e-10.  k_qss_df / k_qss_dfw (round 4) execute the reference's steps OUT of list order, k_qss_sim in it."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RL_QSS_DF="1" if kernel == "dataflow" else "0")
+    env = dict(os.environ, RL_QSS_DF="0" if kernel == "list-order" else "1")
+    if kernel != "list-order":
+        env["RL_QSS_DF_WAVES"] = "4" if "four" in kernel else "1"
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "validate_qss.py"), "12"], capture_output=True, text=True, timeout=600,
                          env=env)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
 def test_qss_kernels_bitwise_equal_and_hand_back(rl, monkeypatch):
-    """The dataflow kernel and the list-order kernel return the same bits (G6 input, single and as a batch of 5), also when the
-    dataflow kernel gives an instance back half way (RL_QSS_DF_BAIL_AT: the path taken when its tables overflow)."""
+    """The dataflow kernels (one wave per instance: k_qss_df; two and four: k_qss_dfw) and the list-order kernel return the same bits
+    (G6 input, single and as a batch of 5), also when a dataflow kernel gives an instance back half way (RL_QSS_DF_BAIL_AT: the path
+    taken when its tables overflow)."""
     g, pts, veh = _sim_inputs()
     res = {}
-    for name, env in (("list", {"RL_QSS_DF": "0"}), ("flow", {"RL_QSS_DF": "1"}), ("back", {"RL_QSS_DF": "1", "RL_QSS_DF_BAIL_AT": "40"})):
-        for k in ("RL_QSS_DF", "RL_QSS_DF_BAIL_AT"):
+    for name, env in (("list", {"RL_QSS_DF": "0"}), ("flow", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "1"}),
+                      ("flow2", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "2"}), ("flow4", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "4"}),
+                      ("back", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "1", "RL_QSS_DF_BAIL_AT": "40"}),
+                      ("back4", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "4", "RL_QSS_DF_BAIL_AT": "40"})):
+        for k in ("RL_QSS_DF", "RL_QSS_DF_BAIL_AT", "RL_QSS_DF_WAVES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         one, it1 = rl.ops.qss_sim(pts, *veh)
         many, itb = rl.ops.qss_sim(np.repeat(pts[None], 5, axis=0), *veh)
         res[name] = (one, int(np.atleast_1d(it1)[0]), many, np.asarray(itb))
-    for name in ("flow", "back"):
+    for name in ("flow", "flow2", "flow4", "back", "back4"):
         np.testing.assert_array_equal(res[name][0], res["list"][0])
         assert res[name][1] == res["list"][1] > 10
         np.testing.assert_array_equal(res[name][2], res["list"][2])
