@@ -611,6 +611,22 @@ def test_qss_simulator_batch_and_bank(rl, fits):
         np.testing.assert_allclose(out[b][:, [4, 14, 15, 16]], ref[:, [4, 14, 15, 16]], rtol=0, atol=1e-10)
 
 
+def test_qss_sizes_around_the_dataflow_tables(rl, fits, monkeypatch):
+    """Trajectories the dataflow kernel's LDS tables do not hold (N > 2004: rl_qss_sim_dev runs the list-order kernel), the largest
+    they do (N = 2004) and the smallest (N = 256; below it the list order again), each against the oracle."""
+    g, pts, veh = _sim_inputs()
+    t, cx, cy, k, length = spline(fits, "c100")
+    for k_ in ("RL_QSS_DF", "RL_QSS_DF_WAVES", "RL_QSS_DF_BAIL_AT"):
+        monkeypatch.delenv(k_, raising=False)
+    for N in (200, 256, 2004, 2100):
+        p = orc.sample_along(t, cx, cy, k, length, np.linspace(0, 1, N, endpoint=False))
+        out, it = rl.ops.qss_sim(p, *veh)
+        ref, oit = orc.qss_sim(p, *veh)
+        assert int(np.atleast_1d(it)[0]) == oit > 5, N
+        np.testing.assert_array_equal(out[:, 18], ref[:, 18])
+        np.testing.assert_allclose(out[:, [4, 14, 15, 16]], ref[:, [4, 14, 15, 16]], rtol=0, atol=1e-10)
+
+
 @pytest.mark.parametrize("kernel", ["dataflow, one wave", "dataflow, four waves", "list-order"])
 def test_qss_randomised_vs_oracle(rl, kernel):
     """The simulator kernels beside the oracle's list-order loop on random trajectories (tools/validate_qss.py: N = 257 ... 2000,
