@@ -1064,7 +1064,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     } else if (df_waves == 2) {
       RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
       hipLaunchKernelGGL(rl::k_qss_dfw<2>, dim3(B), dim3(128), lds_df, ctx->stream, a);
-    } else {
+    } else {   // (k_qss_dfw<1> measures 20 % behind k_qss_df: barriers, shared counters and the list lane cost a lone wave more than they give)
       hipLaunchKernelGGL(rl::k_qss_df, dim3(B), dim3(64), lds_df, ctx->stream, a);
     }
     RL_HIP(hipGetLastError());

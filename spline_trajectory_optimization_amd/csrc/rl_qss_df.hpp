@@ -107,6 +107,232 @@ __device__ __forceinline__ int df_wrap(int x, int N) {   // 0 <= x < 4 N
   return x;
 }
 
+// ---- tables of one instance and the rules on them, shared by the one-wave kernel and the W-wave kernel below
+struct DfTab {
+  int N;
+  double *V, *A;
+  unsigned long long *bmE, *bmX;
+  unsigned* WH;
+  unsigned short *OWN, *gE, *idE, *tE, *hX, *sG, *sId, *sRec, *xg, *xid, *xt, *xn, *xw, *WN, *KAP;
+};
+
+// the agent of an exit worldline that steps next: smallest (g, id)
+__device__ __forceinline__ void dfw_summarise(const DfTab& T, int cc) {
+  int bg = (int)kDfNone, bi = (int)kDfNone, br = (int)kDfNone;
+  for (int r2 = T.hX[cc]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
+    const int g2 = T.xg[r2], i2 = T.xid[r2];
+    if (g2 < bg || (g2 == bg && i2 < bi) || br == (int)kDfNone) { bg = g2; bi = i2; br = r2; }
+  }
+  T.sG[cc] = (unsigned short)bg; T.sId[cc] = (unsigned short)bi; T.sRec[cc] = (unsigned short)br;
+}
+// kappa = 2 g - w of an enter agent only grows (a step adds 2, the front it spawns continues at + 2, its end removes it), so a
+// block value computed from whatever a lane happens to read is a valid lower bound: concurrent refreshes need no ordering.
+// Blocks of FOUR worldlines: the ranges asked about end at most three worldlines short of agents that are known not to qualify
+// (the asking agent's own neighbours, already vetted by the rules before), so a block never raises a false alarm by what lies
+// beyond the range's end.
+__device__ __forceinline__ void dfw_kappa_refresh(const DfTab& T, int blk) {
+  int m = 0xFFFF;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int wq = blk * 4 + q;
+    const int gq = wq < T.N ? (int)T.gE[wq] : (int)kDfNone;
+    const int kq = gq == (int)kDfNone ? 0xFFFF : 2 * gq - wq + T.N;
+    m = kq < m ? kq : m;
+  }
+  T.KAP[blk] = (unsigned short)m;
+}
+// may there be an enter agent with 2 g_e - wu < thr among the worldlines wu = start ... start + len - 1 (unwrapped, len <= 64)?
+__device__ __forceinline__ bool dfw_kappa_below(const DfTab& T, int start, int len, int thr) {
+  const int N = T.N;
+  const int s0 = df_wrap(start, N), off = start - s0;
+  const int e = s0 + len - 1, eA = e < N ? e : N - 1;
+  int m = 0x7fffffff;
+  for (int blk = s0 >> 2; blk <= (eA >> 2); ++blk) {
+    const int kv = T.KAP[blk];
+    const int v = kv == 0xFFFF ? 0x7fffffff : kv - N - off;
+    m = v < m ? v : m;
+  }
+  if (e >= N) {
+    for (int blk = 0; blk <= ((e - N) >> 2); ++blk) {
+      const int kv = T.KAP[blk];
+      const int v = kv == 0xFFFF ? 0x7fffffff : kv - 2 * N - off;
+      m = v < m ? v : m;
+    }
+  }
+  return m < thr;
+}
+// may the agent (exit record r / enter worldline w, iteration g, id) take its next step?  -1: yes; else the list it sleeps on
+__device__ __forceinline__ int dfw_exam(const DfTab& T, bool isX, int r, int w, int g, int id, int gmin, int gminE, int gminX) {
+  typedef unsigned long long u64;
+  const int N = T.N;
+  int key = -1;
+  if (g > gmin + kDfR) return 2 * N;                                   // the iteration window
+  if (isX) {
+    const int c = w, p = c + g;   // position, unwrapped
+    const int cm = c == 0 ? N - 1 : c - 1;
+    const int my_min = T.sRec[c];
+    const int fg = T.sG[cm], fi = T.sId[cm];
+    u64 win = df_window(T.bmX, N, df_wrap(c + 1, N)) & df_mask(kDfR + 2);
+    if (my_min != r) key = N + c;                                      // agents of one worldline step in (g, id) order
+    else if (fg <= g) {                                                // the follower of this iteration writes my source
+      if (fi < id) key = N + cm;
+      else if (fg < g) {                                               //   (its next agent is not the one that matters: look at all)
+        for (int r2 = T.hX[cm]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
+          if ((int)T.xid[r2] < id && (int)T.xg[r2] <= g) { key = N + cm; break; }
+        }
+      }
+    }
+    if (key < 0 && win) {                                              // agents ahead of me that lag behind in iterations
+      const int k = __ffsll((long long)win);
+      const int cl = df_wrap(c + k, N);
+      const int lg = T.sG[cl];
+      if (lg <= g - k + 1) {
+        if (k == 1 && lg == g && (int)T.sId[cl] > id) {                  //   it reads my target AFTER I have written it: not a blocker,
+          win &= win - 1ull;                                           //   but the one behind it may be
+          if (win) {
+            const int k2 = __ffsll((long long)win);
+            const int cl2 = df_wrap(c + k2, N);
+            if ((int)T.sG[cl2] <= g - k2 + 1) key = N + cl2;
+          }
+        } else key = N + cl;
+      }
+    }
+    int behind_top = p + gminE;                                        // enter worldlines up to here hold agents at or behind me
+    if (key < 0 && g + 1 >= gminE) {                                   // enter agents coming towards me
+      const int start = p + 1 + gminE, len = g - gminE + 2;
+      u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
+      while (we) {
+        const int bit = 63 - __clzll((long long)we);
+        const int wu = start + bit, ws = df_wrap(wu, N);
+        const int ge = T.gE[ws], pe = wu - ge;
+        if (pe >= p + 2 || (pe == p + 1 && ge <= g)) { key = ws; break; }
+        if (pe <= p) { behind_top = wu; break; }
+        we &= ~(1ull << bit);
+      }
+    }
+    if (key < 0 && g - 2 >= gminE) {                                   // fronts that enter agents behind me may still spawn
+      const int start = c + 2 + 2 * gminE;
+      const int top = behind_top < c + 2 * g - 2 ? behind_top : c + 2 * g - 2;
+      const int len = top - start + 1;
+      if (len > 0 && dfw_kappa_below(T, start, len, -c - 1)) {          //   (no such agent lags that far behind: the usual case)
+        u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
+        while (we) {
+          const int bit = __ffsll((long long)we) - 1;
+          const int wu = start + bit, ws = df_wrap(wu, N);
+          const int ge = T.gE[ws], pe = wu - ge;
+          if (pe <= p && ge + 1 + (p - pe) < g) { key = ws; break; }
+          we &= we - 1ull;
+        }
+      }
+    }
+  } else {
+    const int c = w, p = c + 2 * N - g;   // position, unwrapped and shifted by 2 N
+    const int cu = c + 1 == N ? 0 : c + 1;
+    const int ag = T.gE[cu], ai = T.idE[cu];
+    u64 win = df_window(T.bmE, N, df_wrap(c + N - (kDfR + 2), N)) & df_mask(kDfR + 2);
+    if (ag != (int)kDfNone && ai < id && ag <= g) key = cu;            // the agent one sample ahead writes my source
+    if (key < 0 && win) {                                              // agents behind me that lag behind in iterations
+      const int j = 63 - __clzll((long long)win);
+      const int k = kDfR + 2 - j;
+      const int ws = df_wrap(c + N - k, N);
+      const int gh = T.gE[ws];
+      if (gh <= g - k + 1) {
+        if (k == 1 && gh == g && (int)T.idE[ws] > id) {
+          win &= ~(1ull << j);
+          if (win) {
+            const int j2 = 63 - __clzll((long long)win);
+            const int k2 = kDfR + 2 - j2;
+            const int ws2 = df_wrap(c + N - k2, N);
+            if ((int)T.gE[ws2] <= g - k2 + 1) key = ws2;
+          }
+        } else key = ws;
+      }
+    }
+    if (key < 0 && g >= gminX) {                                       // exit agents coming towards me
+      const int start = p - 1 - g, len = g - gminX + 1;
+      u64 wx = df_window(T.bmX, N, df_wrap(start, N)) & df_mask(len);
+      while (wx) {
+        const int bit = __ffsll((long long)wx) - 1;
+        const int cu2 = start + bit, cs = df_wrap(cu2, N);
+        const int g2 = T.sG[cs], px = cu2 + g2;                          //   its hindmost agent
+        if (px <= p - 2 || (px == p - 1 && g2 < g)) { key = N + cs; break; }
+        if (px >= p) break;
+        wx &= wx - 1ull;
+      }
+    }
+    if (key < 0 && g - 2 >= gminE) {                                   // fronts that enter agents behind me may still spawn
+      const int len = 2 * (g - gminE) - 3;
+      const int start = c + 2 * N - 2 * (g - gminE) + 1;
+      if (len > 0 && dfw_kappa_below(T, start, len, 2 * g - c - 2 * N)) {
+        u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
+        while (we) {
+          const int bit = __ffsll((long long)we) - 1;
+          const int wu = start + bit, ws = df_wrap(wu, N);
+          const int ge = T.gE[ws], pe = wu - ge;
+          if (pe <= p - 1 && ge + (p - pe) < g) { key = ws; break; }
+          we &= we - 1ull;
+        }
+      }
+    }
+  }
+  return key;
+}
+
+struct DfStep { int new_stop, e, spawned, wr, nown; double nv, na; };
+struct DfStepCtx {
+  const QssArgs* a; const DfTab* T; double lat0; bool small_tabs; const Ppoly2 *pa2, *pd2;
+  const double *t_ax, *t_ac, *t_dx, *t_dc;
+};
+// One step of one side of one front (:154-254 enter, :257-348 exit) -- the arithmetic of k_qss_sim, expression for expression.
+__device__ __forceinline__ DfStep dfw_step(const DfStepCtx& C, int side, int li, int ni, double dd, double rn, double gsn, int turn) {
+#pragma clang fp contract(off)
+  const QssArgs& a = *C.a;
+  const DfTab& T = *C.T;
+  DfStep o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
+  const double lv = T.V[li], la = T.A[li];
+  if (lv == 0.0) { o.e = 1; return o; }
+  const double dt = dd / lv;
+  const double max_dacc = dt * a.max_jerk;
+  double max_acc = la + max_dacc, min_acc = la - max_dacc;
+  const double vmax_acc = C.small_tabs ? C.pa2->eval(lv) : ppoly_eval(C.t_ax, C.t_ac, a.acc_m, lv);
+  const double vmax_dcc = C.small_tabs ? C.pd2->eval(lv) : ppoly_eval(C.t_dx, C.t_dc, a.dcc_m, lv);
+  max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
+  min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
+  double min_state, max_state;
+  if (side == 0) {  // v0^2 = v^2 - 2 a x
+    const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
+    min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+  } else {          // v^2 = 2 a x + v0^2
+    const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
+    max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
+  }
+  const double max_curve = sqrt(fabs(fabs(qss_acc_circle_lon(a, la)) - gsn) * rn);  // calc_v, :54-55
+  double greedy = max_state < max_curve ? max_state : max_curve;
+  if (a.max_speed < greedy) greedy = a.max_speed;
+  if (greedy != greedy) { o.e = 1; return o; }
+  if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve && greedy <= a.max_speed) {
+    const double pv = T.V[ni], pa = T.A[ni];
+    if (T.OWN[ni] != 0xFFFF && pv < greedy) {
+      o.new_stop = 1;
+    } else {
+      if (!(min_acc <= pa && pa <= max_acc)) o.new_stop = -1;
+      o.wr = 1; o.nv = greedy; o.nown = turn;
+      o.na = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
+    }
+  } else {
+    o.new_stop = 1;
+    if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
+      o.spawned = 1; o.wr = 1;
+      const double v = sqrt(fabs(fabs(C.lat0) - gsn) * rn);
+      o.nv = v < a.max_speed ? v : a.max_speed;
+      o.na = 0.0; o.nown = ni;
+    }
+  }
+  return o;
+}
+
+
+
 __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
 #pragma clang fp contract(off)  // decisions below compare freshly computed speeds: keep the reference's roundings
   extern __shared__ double qss_lds[];
@@ -197,51 +423,15 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
   pa2.load(t_ax, t_ac, a.acc_m < 2 ? 1 : 2); pd2.load(t_dx, t_dc, a.dcc_m < 2 ? 1 : 2);
 
   int err = 0, bail = 0, maxg = 0;
-  // One step of one side of one front (:154-254 enter, :257-348 exit) -- the arithmetic of k_qss_sim, expression for expression.
-  struct StepOut { int new_stop, e, spawned, wr, nown; double nv, na; };
-  auto step_calc = [&](int side, int li, int ni, double dd, double rn, double gsn, int turn) {
-    StepOut o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
-    const double lv = V[li], la = A[li];
-    if (lv == 0.0) { o.e = 1; return o; }
-    const double dt = dd / lv;
-    const double max_dacc = dt * a.max_jerk;
-    double max_acc = la + max_dacc, min_acc = la - max_dacc;
-    const double vmax_acc = small_tabs ? pa2.eval(lv) : ppoly_eval(t_ax, t_ac, a.acc_m, lv);
-    const double vmax_dcc = small_tabs ? pd2.eval(lv) : ppoly_eval(t_dx, t_dc, a.dcc_m, lv);
-    max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
-    min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
-    double min_state, max_state;
-    if (side == 0) {  // v0^2 = v^2 - 2 a x
-      const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
-      min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-    } else {          // v^2 = 2 a x + v0^2
-      const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
-      max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-    }
-    const double max_curve = sqrt(fabs(fabs(qss_acc_circle_lon(a, la)) - gsn) * rn);  // calc_v, :54-55
-    double greedy = max_state < max_curve ? max_state : max_curve;
-    if (a.max_speed < greedy) greedy = a.max_speed;
-    if (greedy != greedy) { o.e = 1; return o; }
-    if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve && greedy <= a.max_speed) {
-      const double pv = V[ni], pa = A[ni];
-      if (OWN[ni] != 0xFFFF && pv < greedy) {
-        o.new_stop = 1;  // a slower profile already owns this point: stop
-      } else {
-        if (!(min_acc <= pa && pa <= max_acc)) o.new_stop = -1;  // merge mode
-        o.wr = 1; o.nv = greedy; o.nown = turn;
-        o.na = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
-      }
-    } else {
-      o.new_stop = 1;
-      if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
-        o.spawned = 1; o.wr = 1;
-        const double v = sqrt(fabs(fabs(lat0) - gsn) * rn);
-        o.nv = v < a.max_speed ? v : a.max_speed;
-        o.na = 0.0; o.nown = ni;
-      }
-    }
-    return o;
-  };
+  DfTab T;
+  T.N = N; T.V = V; T.A = A; T.bmE = bmE; T.bmX = bmX; T.WH = WH;
+  T.OWN = OWN; T.gE = gE; T.idE = idE; T.tE = tE; T.hX = hX; T.sG = sG; T.sId = sId; T.sRec = sRec;
+  T.xg = xg; T.xid = xid; T.xt = xt; T.xn = xn; T.xw = xw; T.WN = WN; T.KAP = KAP;
+  DfStepCtx C;
+  C.a = &a; C.T = &T; C.lat0 = lat0; C.small_tabs = small_tabs; C.pa2 = &pa2; C.pd2 = &pd2;
+  C.t_ax = t_ax; C.t_ac = t_ac; C.t_dx = t_dx; C.t_dc = t_dc;
+  typedef DfStep StepOut;
+  auto step_calc = [&](int side, int li, int ni, double dd, double rn, double gsn, int turn) { return dfw_step(C, side, li, ni, dd, rn, gsn, turn); };
 
   // ---- Iteration 0 in LIST ORDER.  Under the dataflow rules front f of iteration 0 would have to wait for front f - 1 to have
   // run even where that one turns out to stop without writing -- one chain through all N fronts, which then delays every
@@ -329,15 +519,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
       qn += __popcll(am); nX += __popcll(am);
     }
   }
-  // the agent of an exit worldline that steps next
-  auto summarise = [&](int cc) {
-    int bg = (int)kDfNone, bi = (int)kDfNone, br = (int)kDfNone;
-    for (int r2 = hX[cc]; r2 != (int)kDfNone; r2 = xn[r2]) {
-      const int g2 = xg[r2], i2 = xid[r2];
-      if (g2 < bg || (g2 == bg && i2 < bi) || br == (int)kDfNone) { bg = g2; bi = i2; br = r2; }
-    }
-    sG[cc] = (u16)bg; sId[cc] = (u16)bi; sRec[cc] = (u16)br;
-  };
+  auto summarise = [&](int cc) { dfw_summarise(T, cc); };   // the agent of an exit worldline that steps next
   for (int i = lane; i < N; i += 64) summarise(i);
   if (lane == 0) { cntE[0] = 0; cntX[0] = 0; cntE[1] = nE; cntX[1] = nX; }
   int free_head = N + nsp < HX ? N + nsp : (int)kDfNone;
@@ -360,42 +542,8 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
     if (want) Q2[q2n + __popcll(m & ((1ull << lane) - 1ull))] = (u16)h;
     q2n += __popcll(m);
   };
-  // kappa = 2 g - w of an enter agent only grows (a step adds 2, the front it spawns continues at + 2, its end removes it), so a
-  // block value computed from whatever a lane happens to read is a valid lower bound: concurrent refreshes need no ordering.
-  // Blocks of FOUR worldlines: the ranges asked about below end at most three worldlines short of agents that are known not to
-  // qualify (my own neighbours, already vetted by the rules before), so a block never raises a false alarm by what lies beyond
-  // the range's end.
   const int NK = (N + 3) / 4;
-  auto kappa_refresh = [&](int blk) {
-    int m = 0xFFFF;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int wq = blk * 4 + q;
-      const int gq = wq < N ? (int)gE[wq] : (int)kDfNone;
-      const int kq = gq == (int)kDfNone ? 0xFFFF : 2 * gq - wq + N;
-      m = kq < m ? kq : m;
-    }
-    KAP[blk] = (u16)m;
-  };
-  // may there be an enter agent with 2 g_e - wu < thr among the worldlines wu = start ... start + len - 1 (unwrapped, len <= 64)?
-  auto kappa_below = [&](int start, int len, int thr) {
-    const int s0 = df_wrap(start, N), off = start - s0;   // unwrapped = stored + off, and + N beyond the end of the ring
-    const int e = s0 + len - 1, eA = e < N ? e : N - 1;
-    int m = 0x7fffffff;
-    for (int blk = s0 >> 2; blk <= (eA >> 2); ++blk) {
-      const int kv = KAP[blk];
-      const int v = kv == 0xFFFF ? 0x7fffffff : kv - N - off;
-      m = v < m ? v : m;
-    }
-    if (e >= N) {
-      for (int blk = 0; blk <= ((e - N) >> 2); ++blk) {
-        const int kv = KAP[blk];
-        const int v = kv == 0xFFFF ? 0x7fffffff : kv - 2 * N - off;
-        m = v < m ? v : m;
-      }
-    }
-    return m < thr;
-  };
+  auto kappa_refresh = [&](int blk) { dfw_kappa_refresh(T, blk); };
   for (int blk = lane; blk < NK; blk += 64) kappa_refresh(blk);
   DF_SYNC();
 
@@ -420,118 +568,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
       double dd = 0.0, rn = 0.0, gsn = 0.0;
       if (valid) { dd = SEG[side == 0 ? li : ni]; rn = RAD[ni]; gsn = GS[ni]; }
       // ------------------------------------------------------------------ may this agent take its next step now?
-      int key = -1;   // >= 0: the list it goes to sleep on
-      if (valid) {
-        if (g > gmin + kDfR) key = 2 * N;
-        else if (isX) {
-          const int c = w, p = c + g;   // position, unwrapped
-          const int cm = c == 0 ? N - 1 : c - 1;
-          const int my_min = sRec[c];
-          const int fg = sG[cm], fi = sId[cm];
-          u64 win = df_window(bmX, N, df_wrap(c + 1, N)) & df_mask(kDfR + 2);
-          if (my_min != r) key = N + c;                                      // agents of one worldline step in (g, id) order
-          else if (fg <= g) {                                                // the follower of this iteration writes my source
-            if (fi < id) key = N + cm;
-            else if (fg < g) {                                               //   (its next agent is not the one that matters: look at all)
-              for (int r2 = hX[cm]; r2 != (int)kDfNone; r2 = xn[r2]) {
-                if ((int)xid[r2] < id && (int)xg[r2] <= g) { key = N + cm; break; }
-              }
-            }
-          }
-          if (key < 0 && win) {                                              // agents ahead of me that lag behind in iterations
-            const int k = __ffsll((long long)win);
-            const int cl = df_wrap(c + k, N);
-            const int lg = sG[cl];
-            if (lg <= g - k + 1) {
-              if (k == 1 && lg == g && (int)sId[cl] > id) {                  //   it reads my target AFTER I have written it: not a blocker,
-                win &= win - 1ull;                                           //   but the one behind it may be
-                if (win) {
-                  const int k2 = __ffsll((long long)win);
-                  const int cl2 = df_wrap(c + k2, N);
-                  if ((int)sG[cl2] <= g - k2 + 1) key = N + cl2;
-                }
-              } else key = N + cl;
-            }
-          }
-          int behind_top = p + gminE;                                        // enter worldlines up to here hold agents at or behind me
-          if (key < 0 && g + 1 >= gminE) {                                   // enter agents coming towards me
-            const int start = p + 1 + gminE, len = g - gminE + 2;
-            u64 we = df_window(bmE, N, df_wrap(start, N)) & df_mask(len);
-            while (we) {
-              const int bit = 63 - __clzll((long long)we);
-              const int wu = start + bit, ws = df_wrap(wu, N);
-              const int ge = gE[ws], pe = wu - ge;
-              if (pe >= p + 2 || (pe == p + 1 && ge <= g)) { key = ws; break; }
-              if (pe <= p) { behind_top = wu; break; }
-              we &= ~(1ull << bit);
-            }
-          }
-          if (key < 0 && g - 2 >= gminE) {                                   // fronts that enter agents behind me may still spawn
-            const int start = c + 2 + 2 * gminE;
-            const int top = behind_top < c + 2 * g - 2 ? behind_top : c + 2 * g - 2;
-            const int len = top - start + 1;
-            if (len > 0 && kappa_below(start, len, -c - 1)) {                //   (no such agent lags that far behind: the usual case)
-              u64 we = df_window(bmE, N, df_wrap(start, N)) & df_mask(len);
-              while (we) {
-                const int bit = __ffsll((long long)we) - 1;
-                const int wu = start + bit, ws = df_wrap(wu, N);
-                const int ge = gE[ws], pe = wu - ge;
-                if (pe <= p && ge + 1 + (p - pe) < g) { key = ws; break; }
-                we &= we - 1ull;
-              }
-            }
-          }
-        } else {
-          const int c = w, p = c + 2 * N - g;   // position, unwrapped and shifted by 2 N
-          const int cu = c + 1 == N ? 0 : c + 1;
-          const int ag = gE[cu], ai = idE[cu];
-          u64 win = df_window(bmE, N, df_wrap(c + N - (kDfR + 2), N)) & df_mask(kDfR + 2);
-          if (ag != (int)kDfNone && ai < id && ag <= g) key = cu;            // the agent one sample ahead writes my source
-          if (key < 0 && win) {                                              // agents behind me that lag behind in iterations
-            const int j = 63 - __clzll((long long)win);
-            const int k = kDfR + 2 - j;
-            const int ws = df_wrap(c + N - k, N);
-            const int gh = gE[ws];
-            if (gh <= g - k + 1) {
-              if (k == 1 && gh == g && (int)idE[ws] > id) {
-                win &= ~(1ull << j);
-                if (win) {
-                  const int j2 = 63 - __clzll((long long)win);
-                  const int k2 = kDfR + 2 - j2;
-                  const int ws2 = df_wrap(c + N - k2, N);
-                  if ((int)gE[ws2] <= g - k2 + 1) key = ws2;
-                }
-              } else key = ws;
-            }
-          }
-          if (key < 0 && g >= gminX) {                                       // exit agents coming towards me
-            const int start = p - 1 - g, len = g - gminX + 1;
-            u64 wx = df_window(bmX, N, df_wrap(start, N)) & df_mask(len);
-            while (wx) {
-              const int bit = __ffsll((long long)wx) - 1;
-              const int cu2 = start + bit, cs = df_wrap(cu2, N);
-              const int g2 = sG[cs], px = cu2 + g2;                          //   its hindmost agent
-              if (px <= p - 2 || (px == p - 1 && g2 < g)) { key = N + cs; break; }
-              if (px >= p) break;
-              wx &= wx - 1ull;
-            }
-          }
-          if (key < 0 && g - 2 >= gminE) {                                   // fronts that enter agents behind me may still spawn
-            const int len = 2 * (g - gminE) - 3;
-            const int start = c + 2 * N - 2 * (g - gminE) + 1;
-            if (len > 0 && kappa_below(start, len, 2 * g - c - 2 * N)) {
-              u64 we = df_window(bmE, N, df_wrap(start, N)) & df_mask(len);
-              while (we) {
-                const int bit = __ffsll((long long)we) - 1;
-                const int wu = start + bit, ws = df_wrap(wu, N);
-                const int ge = gE[ws], pe = wu - ge;
-                if (pe <= p - 1 && ge + (p - pe) < g) { key = ws; break; }
-                we &= we - 1ull;
-              }
-            }
-          }
-        }
-      }
+      const int key = valid ? dfw_exam(T, isX, r, w, g, id, gmin, gminE, gminX) : -1;   // >= 0: the list it goes to sleep on
       const bool ready = valid && key < 0;
       d_exam += __popcll(__ballot(valid)); d_step += __popcll(__ballot(ready));
       if (valid && key >= 0) {
@@ -772,223 +809,6 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
 // lists (one lane, the few agents that die or are born) | next agents | wake-ups -- separated by workgroup barriers.
 // Rules, tables and results are those of k_qss_df above; what changes is who keeps the counters (LDS scalars and
 // atomics instead of wave-uniform registers) and that list surgery is queued for one lane instead of done in place.
-struct DfTab {
-  int N;
-  double *V, *A;
-  unsigned long long *bmE, *bmX;
-  unsigned* WH;
-  unsigned short *OWN, *gE, *idE, *tE, *hX, *sG, *sId, *sRec, *xg, *xid, *xt, *xn, *xw, *WN, *KAP;
-};
-
-__device__ __forceinline__ void dfw_summarise(const DfTab& T, int cc) {
-  int bg = (int)kDfNone, bi = (int)kDfNone, br = (int)kDfNone;
-  for (int r2 = T.hX[cc]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
-    const int g2 = T.xg[r2], i2 = T.xid[r2];
-    if (g2 < bg || (g2 == bg && i2 < bi) || br == (int)kDfNone) { bg = g2; bi = i2; br = r2; }
-  }
-  T.sG[cc] = (unsigned short)bg; T.sId[cc] = (unsigned short)bi; T.sRec[cc] = (unsigned short)br;
-}
-__device__ __forceinline__ void dfw_kappa_refresh(const DfTab& T, int blk) {
-  int m = 0xFFFF;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int wq = blk * 4 + q;
-    const int gq = wq < T.N ? (int)T.gE[wq] : (int)kDfNone;
-    const int kq = gq == (int)kDfNone ? 0xFFFF : 2 * gq - wq + T.N;
-    m = kq < m ? kq : m;
-  }
-  T.KAP[blk] = (unsigned short)m;
-}
-__device__ __forceinline__ bool dfw_kappa_below(const DfTab& T, int start, int len, int thr) {
-  const int N = T.N;
-  const int s0 = df_wrap(start, N), off = start - s0;
-  const int e = s0 + len - 1, eA = e < N ? e : N - 1;
-  int m = 0x7fffffff;
-  for (int blk = s0 >> 2; blk <= (eA >> 2); ++blk) {
-    const int kv = T.KAP[blk];
-    const int v = kv == 0xFFFF ? 0x7fffffff : kv - N - off;
-    m = v < m ? v : m;
-  }
-  if (e >= N) {
-    for (int blk = 0; blk <= ((e - N) >> 2); ++blk) {
-      const int kv = T.KAP[blk];
-      const int v = kv == 0xFFFF ? 0x7fffffff : kv - 2 * N - off;
-      m = v < m ? v : m;
-    }
-  }
-  return m < thr;
-}
-// may the agent (exit record r / enter worldline w, iteration g, id) take its next step?  -1: yes; else the list it sleeps on
-__device__ __forceinline__ int dfw_exam(const DfTab& T, bool isX, int r, int w, int g, int id, int gmin, int gminE, int gminX) {
-  typedef unsigned long long u64;
-  const int N = T.N;
-  int key = -1;
-  if (g > gmin + kDfR) return 2 * N;
-  if (isX) {
-    const int c = w, p = c + g;
-    const int cm = c == 0 ? N - 1 : c - 1;
-    const int my_min = T.sRec[c];
-    const int fg = T.sG[cm], fi = T.sId[cm];
-    u64 win = df_window(T.bmX, N, df_wrap(c + 1, N)) & df_mask(kDfR + 2);
-    if (my_min != r) key = N + c;
-    else if (fg <= g) {
-      if (fi < id) key = N + cm;
-      else if (fg < g) {
-        for (int r2 = T.hX[cm]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
-          if ((int)T.xid[r2] < id && (int)T.xg[r2] <= g) { key = N + cm; break; }
-        }
-      }
-    }
-    if (key < 0 && win) {
-      const int k = __ffsll((long long)win);
-      const int cl = df_wrap(c + k, N);
-      const int lg = T.sG[cl];
-      if (lg <= g - k + 1) {
-        if (k == 1 && lg == g && (int)T.sId[cl] > id) {
-          win &= win - 1ull;
-          if (win) {
-            const int k2 = __ffsll((long long)win);
-            const int cl2 = df_wrap(c + k2, N);
-            if ((int)T.sG[cl2] <= g - k2 + 1) key = N + cl2;
-          }
-        } else key = N + cl;
-      }
-    }
-    int behind_top = p + gminE;
-    if (key < 0 && g + 1 >= gminE) {
-      const int start = p + 1 + gminE, len = g - gminE + 2;
-      u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
-      while (we) {
-        const int bit = 63 - __clzll((long long)we);
-        const int wu = start + bit, ws = df_wrap(wu, N);
-        const int ge = T.gE[ws], pe = wu - ge;
-        if (pe >= p + 2 || (pe == p + 1 && ge <= g)) { key = ws; break; }
-        if (pe <= p) { behind_top = wu; break; }
-        we &= ~(1ull << bit);
-      }
-    }
-    if (key < 0 && g - 2 >= gminE) {
-      const int start = c + 2 + 2 * gminE;
-      const int top = behind_top < c + 2 * g - 2 ? behind_top : c + 2 * g - 2;
-      const int len = top - start + 1;
-      if (len > 0 && dfw_kappa_below(T, start, len, -c - 1)) {
-        u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
-        while (we) {
-          const int bit = __ffsll((long long)we) - 1;
-          const int wu = start + bit, ws = df_wrap(wu, N);
-          const int ge = T.gE[ws], pe = wu - ge;
-          if (pe <= p && ge + 1 + (p - pe) < g) { key = ws; break; }
-          we &= we - 1ull;
-        }
-      }
-    }
-  } else {
-    const int c = w, p = c + 2 * N - g;
-    const int cu = c + 1 == N ? 0 : c + 1;
-    const int ag = T.gE[cu], ai = T.idE[cu];
-    u64 win = df_window(T.bmE, N, df_wrap(c + N - (kDfR + 2), N)) & df_mask(kDfR + 2);
-    if (ag != (int)kDfNone && ai < id && ag <= g) key = cu;
-    if (key < 0 && win) {
-      const int j = 63 - __clzll((long long)win);
-      const int k = kDfR + 2 - j;
-      const int ws = df_wrap(c + N - k, N);
-      const int gh = T.gE[ws];
-      if (gh <= g - k + 1) {
-        if (k == 1 && gh == g && (int)T.idE[ws] > id) {
-          win &= ~(1ull << j);
-          if (win) {
-            const int j2 = 63 - __clzll((long long)win);
-            const int k2 = kDfR + 2 - j2;
-            const int ws2 = df_wrap(c + N - k2, N);
-            if ((int)T.gE[ws2] <= g - k2 + 1) key = ws2;
-          }
-        } else key = ws;
-      }
-    }
-    if (key < 0 && g >= gminX) {
-      const int start = p - 1 - g, len = g - gminX + 1;
-      u64 wx = df_window(T.bmX, N, df_wrap(start, N)) & df_mask(len);
-      while (wx) {
-        const int bit = __ffsll((long long)wx) - 1;
-        const int cu2 = start + bit, cs = df_wrap(cu2, N);
-        const int g2 = T.sG[cs], px = cu2 + g2;
-        if (px <= p - 2 || (px == p - 1 && g2 < g)) { key = N + cs; break; }
-        if (px >= p) break;
-        wx &= wx - 1ull;
-      }
-    }
-    if (key < 0 && g - 2 >= gminE) {
-      const int len = 2 * (g - gminE) - 3;
-      const int start = c + 2 * N - 2 * (g - gminE) + 1;
-      if (len > 0 && dfw_kappa_below(T, start, len, 2 * g - c - 2 * N)) {
-        u64 we = df_window(T.bmE, N, df_wrap(start, N)) & df_mask(len);
-        while (we) {
-          const int bit = __ffsll((long long)we) - 1;
-          const int wu = start + bit, ws = df_wrap(wu, N);
-          const int ge = T.gE[ws], pe = wu - ge;
-          if (pe <= p - 1 && ge + (p - pe) < g) { key = ws; break; }
-          we &= we - 1ull;
-        }
-      }
-    }
-  }
-  return key;
-}
-
-struct DfStep { int new_stop, e, spawned, wr, nown; double nv, na; };
-struct DfStepCtx {
-  const QssArgs* a; const DfTab* T; double lat0; bool small_tabs; const Ppoly2 *pa2, *pd2;
-  const double *t_ax, *t_ac, *t_dx, *t_dc;
-};
-// One step of one side of one front (:154-254 enter, :257-348 exit) -- the arithmetic of k_qss_sim, expression for expression.
-__device__ __forceinline__ DfStep dfw_step(const DfStepCtx& C, int side, int li, int ni, double dd, double rn, double gsn, int turn) {
-#pragma clang fp contract(off)
-  const QssArgs& a = *C.a;
-  const DfTab& T = *C.T;
-  DfStep o; o.new_stop = 0; o.e = 0; o.spawned = 0; o.wr = 0; o.nown = 0; o.nv = 0.0; o.na = 0.0;
-  const double lv = T.V[li], la = T.A[li];
-  if (lv == 0.0) { o.e = 1; return o; }
-  const double dt = dd / lv;
-  const double max_dacc = dt * a.max_jerk;
-  double max_acc = la + max_dacc, min_acc = la - max_dacc;
-  const double vmax_acc = C.small_tabs ? C.pa2->eval(lv) : ppoly_eval(C.t_ax, C.t_ac, a.acc_m, lv);
-  const double vmax_dcc = C.small_tabs ? C.pd2->eval(lv) : ppoly_eval(C.t_dx, C.t_dc, a.dcc_m, lv);
-  max_acc = max_acc < vmax_dcc ? vmax_dcc : (max_acc > vmax_acc ? vmax_acc : max_acc);
-  min_acc = min_acc < vmax_dcc ? vmax_dcc : (min_acc > vmax_acc ? vmax_acc : min_acc);
-  double min_state, max_state;
-  if (side == 0) {  // v0^2 = v^2 - 2 a x
-    const double a1 = lv * lv - 2 * max_acc * dd, a2 = lv * lv - 2 * min_acc * dd;
-    min_state = sqrt(a1 > 0.0 ? a1 : 0.0); max_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-  } else {          // v^2 = 2 a x + v0^2
-    const double a1 = 2 * max_acc * dd + lv * lv, a2 = 2 * min_acc * dd + lv * lv;
-    max_state = sqrt(a1 > 0.0 ? a1 : 0.0); min_state = sqrt(a2 > 0.0 ? a2 : 0.0);
-  }
-  const double max_curve = sqrt(fabs(fabs(qss_acc_circle_lon(a, la)) - gsn) * rn);  // calc_v, :54-55
-  double greedy = max_state < max_curve ? max_state : max_curve;
-  if (a.max_speed < greedy) greedy = a.max_speed;
-  if (greedy != greedy) { o.e = 1; return o; }
-  if (min_state <= greedy && greedy <= max_state && 0.0 <= greedy && greedy <= max_curve && greedy <= a.max_speed) {
-    const double pv = T.V[ni], pa = T.A[ni];
-    if (T.OWN[ni] != 0xFFFF && pv < greedy) {
-      o.new_stop = 1;
-    } else {
-      if (!(min_acc <= pa && pa <= max_acc)) o.new_stop = -1;
-      o.wr = 1; o.nv = greedy; o.nown = turn;
-      o.na = side == 0 ? (lv * lv - greedy * greedy) / (2 * dd) : (greedy * greedy - lv * lv) / (2 * dd);
-    }
-  } else {
-    o.new_stop = 1;
-    if (side == 0 && (greedy > max_curve || greedy < min_state)) {  // :239-254: spawn a new turn
-      o.spawned = 1; o.wr = 1;
-      const double v = sqrt(fabs(fabs(C.lat0) - gsn) * rn);
-      o.nv = v < a.max_speed ? v : a.max_speed;
-      o.na = 0.0; o.nown = ni;
-    }
-  }
-  return o;
-}
-
-
 enum { DFS_Q2N = 0, DFS_NWIN, DFS_ERR, DFS_BAIL, DFS_NFREE, DFS_NSPQ, DFS_GMINE, DFS_GMINX, DFS_GMIN, DFS_CHG, DFS_NE, DFS_NX, DFS_MAXG,
        DFS_QN, DFS_NU, DFS_DEXAM, DFS_DSTEP, DFS_COUNT };
 static_assert(DFS_COUNT <= 32, "scalars");
