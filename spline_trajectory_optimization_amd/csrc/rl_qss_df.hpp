@@ -116,14 +116,41 @@ struct DfTab {
   unsigned short *OWN, *gE, *idE, *tE, *hX, *sG, *sId, *sRec, *xg, *xid, *xt, *xn, *xw, *WN, *KAP;
 };
 
-// the agent of an exit worldline that steps next: smallest (g, id)
+// ---- The agents of one exit worldline: a CIRCULAR list sorted by (g, id) -- the order they step in -- entered at its TAIL
+// (hX[c], kDfNone when empty); the head xn[tail] is the agent that steps next, and (sG, sId, sRec)[c] caches it for the
+// examinations.  Only the head ever steps or dies, so the usual updates are O(1): a step in a group that moves in lock step
+// (all at g; the head goes to g + 1, which is now the largest key) ROTATES the list -- the head becomes the tail --, a death
+// unlinks the head behind the tail, a front born now has the largest g and is appended.  Everything else (a head that must go
+// somewhere in the middle, a front born out of order) walks to the agent's place.
+__device__ __forceinline__ unsigned dfw_key(const DfTab& T, int r) { return ((unsigned)T.xg[r] << 16) | (unsigned)T.xid[r]; }
 __device__ __forceinline__ void dfw_summarise(const DfTab& T, int cc) {
-  int bg = (int)kDfNone, bi = (int)kDfNone, br = (int)kDfNone;
-  for (int r2 = T.hX[cc]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
-    const int g2 = T.xg[r2], i2 = T.xid[r2];
-    if (g2 < bg || (g2 == bg && i2 < bi) || br == (int)kDfNone) { bg = g2; bi = i2; br = r2; }
-  }
-  T.sG[cc] = (unsigned short)bg; T.sId[cc] = (unsigned short)bi; T.sRec[cc] = (unsigned short)br;
+  const int tail = T.hX[cc];
+  if (tail == (int)kDfNone) { T.sG[cc] = (unsigned short)kDfNone; T.sId[cc] = (unsigned short)kDfNone; T.sRec[cc] = (unsigned short)kDfNone; return; }
+  const int head = T.xn[tail];
+  T.sG[cc] = T.xg[head]; T.sId[cc] = T.xid[head]; T.sRec[cc] = (unsigned short)head;
+}
+__device__ __forceinline__ void dfw_insert(const DfTab& T, int cc, int rec) {   // rec's g and id are set
+  const int tail = T.hX[cc];
+  if (tail == (int)kDfNone) { T.xn[rec] = (unsigned short)rec; T.hX[cc] = (unsigned short)rec; return; }
+  const unsigned k = dfw_key(T, rec);
+  if (k >= dfw_key(T, tail)) { T.xn[rec] = T.xn[tail]; T.xn[tail] = (unsigned short)rec; T.hX[cc] = (unsigned short)rec; return; }
+  int prev = tail, cur = T.xn[tail];
+  for (int guard = 0; dfw_key(T, cur) <= k && guard < 8192; ++guard) { prev = cur; cur = T.xn[cur]; }   // ends at the tail at the latest: its key is larger (the count: no hang on a corrupted list)
+  T.xn[rec] = (unsigned short)cur; T.xn[prev] = (unsigned short)rec;
+}
+__device__ __forceinline__ void dfw_pop_head(const DfTab& T, int cc) {   // the head has died
+  const int tail = T.hX[cc], head = T.xn[tail];
+  if (head == tail) T.hX[cc] = (unsigned short)kDfNone; else T.xn[tail] = T.xn[head];
+}
+__device__ __forceinline__ void dfw_head_stepped(const DfTab& T, int cc) {   // the head's g has just been raised in its record
+  const int tail = T.hX[cc], head = T.xn[tail];
+  if (head == tail) return;
+  const unsigned k = dfw_key(T, head);
+  const int nxt = T.xn[head];
+  if (k <= dfw_key(T, nxt)) return;                                         // still the next to step
+  if (k >= dfw_key(T, tail)) { T.hX[cc] = (unsigned short)head; return; }   // lock step: rotate
+  T.xn[tail] = (unsigned short)nxt;                                         // out, and to its place
+  dfw_insert(T, cc, head);
 }
 // kappa = 2 g - w of an enter agent only grows (a step adds 2, the front it spawns continues at + 2, its end removes it), so a
 // block value computed from whatever a lane happens to read is a valid lower bound: concurrent refreshes need no ordering.
@@ -177,8 +204,12 @@ __device__ __forceinline__ int dfw_exam(const DfTab& T, bool isX, int r, int w, 
     else if (fg <= g) {                                                // the follower of this iteration writes my source
       if (fi < id) key = N + cm;
       else if (fg < g) {                                               //   (its next agent is not the one that matters: look at all)
-        for (int r2 = T.hX[cm]; r2 != (int)kDfNone; r2 = T.xn[r2]) {
+        const int tl = T.hX[cm];
+        int r2 = T.xn[tl];
+        for (int guard = 0; guard < 8192; ++guard) {
           if ((int)T.xid[r2] < id && (int)T.xg[r2] <= g) { key = N + cm; break; }
+          if (r2 == tl) break;
+          r2 = T.xn[r2];
         }
       }
     }
@@ -491,11 +522,11 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
   // ---- the tables at the start of iteration 1
   int nE = 0, nX = 0, qn = 0;
   if (!err && !bail) {
-    for (int i = lane; i < N; i += 64) { hX[i] = xg[i] == 1 ? (u16)i : (u16)kDfNone; xn[i] = (u16)kDfNone; }
+    for (int i = lane; i < N; i += 64) { hX[i] = xg[i] == 1 ? (u16)i : (u16)kDfNone; xn[i] = (u16)i; }   // circular lists of one
     DF_SYNC();
     for (int k = lane; k < nsp; k += 64) {   // a new front's exit side: born at f - 1, so on worldline f - 2 (one per worldline)
       const int rec = N + k, cxw = xw[rec];
-      xn[rec] = hX[cxw]; hX[cxw] = (u16)rec;
+      dfw_insert(T, cxw, rec);   // (behind the original front of that worldline, whose id is smaller)
       WN[N + rec] = (u16)kDfNone;
     }
     DF_SYNC();
@@ -613,9 +644,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
         if (m != 0ull) {
           nX -= __popcll(m);
           if (dx) {
-            int prev = (int)kDfNone, cur = hX[w];
-            while (cur != r) { prev = cur; cur = xn[cur]; }
-            if (prev == (int)kDfNone) hX[w] = xn[r]; else xn[prev] = xn[r];
+            dfw_pop_head(T, w);
             if (hX[w] == (u16)kDfNone) atomicAnd(&bmX[w >> 6], ~(1ull << (w & 63)));
           }
           const u64 lower = m & ((1ull << lane) - 1ull);
@@ -625,6 +654,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
           free_head = __builtin_amdgcn_readlane(r, 63 - __clzll((long long)m));
         }
       }
+      if (ready && isX && !die) dfw_head_stepped(T, w);   // (other worldlines than the ones that have just lost their head)
       DF_SYNC();
       int cx = 0;
       {
@@ -642,7 +672,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
             if (lane == j) {
               nxt = xn[rec];
               xg[rec] = (u16)(g + 1); xid[rec] = (u16)kDfNone; xt[rec] = (u16)ni; xw[rec] = (u16)cx;
-              xn[rec] = hX[cx]; hX[cx] = (u16)rec;
+              dfw_insert(T, cx, rec);
               bmX[cx >> 6] |= 1ull << (cx & 63);
               myrec = rec;
             }
@@ -659,10 +689,7 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
         }
       }
       // the next agent of every exit worldline whose list or iteration counters have changed
-      if (ready && isX) {
-        if (!die && (int)hX[w] == r && xn[r] == (u16)kDfNone) sG[w] = (u16)(g + 1);   // alone on its worldline: the usual case
-        else summarise(w);
-      }
+      if (ready && isX) summarise(w);
       if (ready && spawned) summarise(cx);
       DF_SYNC();
       // ------------------------------------------------------------------ wake whoever sleeps on my worldline; queue myself --
@@ -750,7 +777,9 @@ __global__ __launch_bounds__(64) void k_qss_df(QssArgs a) {
         const int i = base + lane;
         u16* u = U + (size_t)4 * (i < nU ? i : Ulo);
         const bool sel = i < nU && u[0] == (u16)bth;
-        if (sel) summarise(xw[u[3]]);   // (the same worldline by several lanes: the same result)
+        // (The id does not move the agent within its worldline's list: the members that share its g are older fronts, whose ids
+        // are smaller, and at most one front is born per worldline and iteration -- it sat behind them as (g, unnumbered) already.)
+        if (sel) summarise(xw[u[3]]);
         push_next(sel, u[2]);
         push_next(sel, N + u[3]);
         if (sel) u[0] = (u16)kDfNone;
@@ -953,11 +982,11 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
     }
     int nE = 0, nX = 0, qn0 = 0;
     if (!err0 && !bail0) {
-      for (int i = lane; i < N; i += 64) { hX[i] = xg[i] == 1 ? (u16)i : (u16)kDfNone; xn[i] = (u16)kDfNone; }
+      for (int i = lane; i < N; i += 64) { hX[i] = xg[i] == 1 ? (u16)i : (u16)kDfNone; xn[i] = (u16)i; }   // circular lists of one
       DF_SYNC();
       for (int k = lane; k < nsp; k += 64) {
         const int rec = N + k, cxw = xw[rec];
-        xn[rec] = hX[cxw]; hX[cxw] = (u16)rec;
+        dfw_insert(T, cxw, rec);   // (behind the original front of that worldline, whose id is smaller)
       }
       DF_SYNC();
       for (int i = lane; i < L.NW; i += 64) { bmE[i] = 0ull; bmX[i] = 0ull; }
@@ -1086,11 +1115,9 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
       }
       if (ready && isX) {
         atomicSub(&cntX[g & (kDfCnt - 1)], 1);
-        if (!die) { xg[r] = (u16)(g + 1); atomicAdd(&cntX[(g + 1) & (kDfCnt - 1)], 1); }
+        if (!die) { xg[r] = (u16)(g + 1); atomicAdd(&cntX[(g + 1) & (kDfCnt - 1)], 1); dfw_head_stepped(T, w); }
         else {   // leaves its worldline's list (only the next agent of a worldline can have stepped: the lists differ)
-          int prev = (int)kDfNone, cur = hX[w];
-          while (cur != r) { prev = cur; cur = xn[cur]; }
-          if (prev == (int)kDfNone) hX[w] = xn[r]; else xn[prev] = xn[r];
+          dfw_pop_head(T, w);
           if (hX[w] == (u16)kDfNone) atomicAnd(&bmX[w >> 6], ~(1ull << (w & 63)));
           const int slot = atomicAdd(&scal[DFS_NFREE], 1);
           FREEQ[slot] = (u16)r;
@@ -1117,7 +1144,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
               free_head = xn[rec];
               const int cxx = df_wrap(sni + 2 * N - (sg + 1), N);
               xg[rec] = (u16)(sg + 1); xid[rec] = (u16)kDfNone; xt[rec] = (u16)sni; xw[rec] = (u16)cxx;
-              xn[rec] = hX[cxx]; hX[cxx] = (u16)rec;
+              dfw_insert(T, cxx, rec);
               bmX[cxx >> 6] |= 1ull << (cxx & 63);
               atomicAdd(&cntX[(sg + 1) & (kDfCnt - 1)], 1);
               u16* u = U + (size_t)4 * nU;
@@ -1135,10 +1162,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
       }
       DFW_TICK(4);
       // ---- the next agent of every exit worldline whose list or iteration counters have changed
-      if (ready && isX) {
-        if (!die && (int)hX[w] == r && xn[r] == (u16)kDfNone) sG[w] = (u16)(g + 1);
-        else dfw_summarise(T, w);
-      }
+      if (ready && isX) dfw_summarise(T, w);
       if (ready && spawned) dfw_summarise(T, cx);
       __syncthreads();
       if (tid == 0) { scal[DFS_NFREE] = 0; scal[DFS_NSPQ] = 0; }
@@ -1224,7 +1248,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
           const int i = base + lane;
           u16* u = U + (size_t)4 * (i < nU ? i : Ulo);
           const bool sel = i < nU && u[0] == (u16)bth;
-          if (sel) dfw_summarise(T, xw[u[3]]);
+          if (sel) dfw_summarise(T, xw[u[3]]);   // (its place in the list does not change with the id: see k_qss_df)
           push_next(sel, u[2]);
           push_next(sel, N + u[3]);
           if (sel) u[0] = (u16)kDfNone;
