@@ -330,7 +330,7 @@ def qss_leg(B, with_cpu):
                          "global_iterations_mean": float(its.mean()), "raised": int((its < 0).sum())}
             if name == "batch":
                 out, its_batch = w.cpu().numpy(), its
-        leg["kernel"] = "k_qss_df (the reference's steps as a dataflow) up to the batch size rl_qss_sim_dev gives it, else k_qss_sim (list order)"
+        leg["kernel"] = "k_qss_dfw<4> (the reference's steps as a dataflow, four waves per instance) for every size its LDS tables hold, else k_qss_sim (list order)"
         if with_cpu:
             from oracle import oracle as orc
             k = min(3, B)

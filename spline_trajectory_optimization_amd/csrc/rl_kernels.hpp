@@ -1150,8 +1150,8 @@ struct QssArgs {
   // launch then reads no host memory after the call returns.  tab_n = 0: the four pointers above are device arrays.
   int tab_n;
   int* dbg;              // optional [B][12]: passes, chunks, examinations, steps, wake pushes, numbering events, spawned fronts, bail reason
-  int df_bail_at;        // k_qss_df only, tests: hand the instance back once a step of this iteration has run (0: never)
-  int redo;              // k_qss_sim only: 1 = run just the instances k_qss_df handed back (iters[b] == -2)
+  int df_bail_at;        // k_qss_dfw only, tests: hand the instance back once a step of this iteration has run (0: never)
+  int redo;              // k_qss_sim only: 1 = run just the instances k_qss_dfw handed back (iters[b] == -2)
   double tab[kQssTabMax];
 };
 

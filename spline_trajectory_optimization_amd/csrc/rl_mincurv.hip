@@ -1043,29 +1043,28 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     per_cu_list = per_cu_list > 8 ? 8 : per_cu_list;
     const long long cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
     const long long rounds_df = (B + per_cu_df * cus - 1) / (per_cu_df * cus), rounds_list = (B + per_cu_list * cus - 1) / (per_cu_list * cus);
-    use_df = rounds_df <= (N >= 1024 ? 4 : 2) * rounds_list;   // (a round of the dataflow kernel: ~1/4.3 of a list-order round with four waves, ~1/2.2 with one)
+    use_df = rounds_df <= 4 * rounds_list;   // (a round of the dataflow kernel takes 1/5 (N = 2000) ... 1/2 (N = 500) of a list-order round)
   }
   if (fdf && (fdf[0] == '0' || fdf[0] == '1')) use_df = fdf[0] == '1' && rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
   if (v1 && v1[0] == '1') use_df = false;
   if (use_df) {
     const size_t lds_df = rl::df_layout(N, acc_m, dcc_m).bytes;
-    RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_df), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
     const char* dbg = getenv("RL_QSS_DEBUG");
     int* ddbg = nullptr;
     if (dbg && dbg[0] == '1') { RL_HIP(hipMalloc(&ddbg, (size_t)B * 12 * sizeof(int))); a.dbg = ddbg; }
-    // RL_QSS_DF_WAVES = 1: the one-wave kernel k_qss_df; 2 / 4: k_qss_dfw, the same scheduler with the agents of a pass spread over
-    // that many waves of the (one) workgroup an instance's tables leave room for.
-    // Measured: four waves 37 against 46 ms at N = 2000, one wave 4.7 against 5.2 ms at N = 500.
-    int df_waves = N >= 1024 ? 4 : 1;
+    // RL_QSS_DF_WAVES = 1 / 2 / 4: waves of the (one) workgroup an instance's tables leave room for; four is the fastest at every
+    // size measured, the others exist for the tests.
+    int df_waves = 4;
     if (const char* dw = getenv("RL_QSS_DF_WAVES")) df_waves = atoi(dw);
-    if (df_waves == 4) {
-      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
-      hipLaunchKernelGGL(rl::k_qss_dfw<4>, dim3(B), dim3(256), lds_df, ctx->stream, a);
+    if (df_waves == 1) {
+      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+      hipLaunchKernelGGL(rl::k_qss_dfw<1>, dim3(B), dim3(64), lds_df, ctx->stream, a);
     } else if (df_waves == 2) {
       RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
       hipLaunchKernelGGL(rl::k_qss_dfw<2>, dim3(B), dim3(128), lds_df, ctx->stream, a);
-    } else {   // (k_qss_dfw<1> measures 20 % behind k_qss_df: barriers, shared counters and the list lane cost a lone wave more than they give)
-      hipLaunchKernelGGL(rl::k_qss_df, dim3(B), dim3(64), lds_df, ctx->stream, a);
+    } else {
+      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+      hipLaunchKernelGGL(rl::k_qss_dfw<4>, dim3(B), dim3(256), lds_df, ctx->stream, a);
     }
     RL_HIP(hipGetLastError());
     if (ddbg) {   // diagnostics only: synchronous
@@ -1075,9 +1074,9 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
       RL_HIP(hipFree(ddbg));
       long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int handed = 0;
       for (int i = 0; i < B; ++i) { for (int q = 0; q < 8; ++q) tot[q] += hd[(size_t)i * 12 + q]; handed += hd[(size_t)i * 12 + 7] != 0; }
-      fprintf(stderr, "k_qss_df: B=%d N=%d lds=%zu  per instance: passes %.0f chunks %.0f examinations %.0f steps %.0f longest queue %.0f numberings %.0f spawned %.0f; handed back %d (reason of instance 0: %d)\n",
+      fprintf(stderr, "k_qss_dfw: B=%d N=%d lds=%zu  per instance: passes %.0f chunks %.0f examinations %.0f steps %.0f longest queue %.0f numberings %.0f spawned %.0f; handed back %d (reason of instance 0: %d)\n",
               B, N, lds_df, (double)tot[0] / B, (double)tot[1] / B, (double)tot[2] / B, (double)tot[3] / B, (double)tot[4] / B, (double)tot[5] / B, (double)tot[6] / B, handed, hd[7]);
-      fprintf(stderr, "k_qss_df: instance 0, thousands of clock64 ticks: examination %d, step %d, records + wake %d, end of pass %d\n", hd[8], hd[9], hd[10], hd[11]);
+      fprintf(stderr, "k_qss_dfw: thread 0 of instance 0, thousands of clock64 ticks: examination + step %d, records (+ waits) %d, list lane + next agents + wake-ups %d, end of pass %d\n", hd[8], hd[9], hd[10], hd[11]);
       a.dbg = nullptr;
     }
     a.redo = 1;

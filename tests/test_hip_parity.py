@@ -627,11 +627,11 @@ def test_qss_sizes_around_the_dataflow_tables(rl, fits, monkeypatch):
         np.testing.assert_allclose(out[:, [4, 14, 15, 16]], ref[:, [4, 14, 15, 16]], rtol=0, atol=1e-10)
 
 
-@pytest.mark.parametrize("kernel", ["dataflow, one wave", "dataflow, four waves", "list-order"])
+@pytest.mark.parametrize("kernel", ["dataflow, one wave", "dataflow, four waves", "list-order"])  # k_qss_dfw<1>, <4>; k_qss_sim
 def test_qss_randomised_vs_oracle(rl, kernel):
     """The simulator kernels beside the oracle's list-order loop on random trajectories (tools/validate_qss.py: N = 257 ... 2000,
     with and without bank, 2- and 3/4-piece vehicle tables, three speed / jerk limits): owner flags and iteration counts equal,
-    profiles to 1e-10.  k_qss_df / k_qss_dfw (round 4) execute the reference's steps OUT of list order, k_qss_sim in it."""
+    profiles to 1e-10.  k_qss_dfw<W> (round 4) executes the reference's steps OUT of list order, k_qss_sim in it."""
     import os
     import subprocess
     import sys
@@ -645,7 +645,7 @@ def test_qss_randomised_vs_oracle(rl, kernel):
 
 
 def test_qss_kernels_bitwise_equal_and_hand_back(rl, monkeypatch):
-    """The dataflow kernels (one wave per instance: k_qss_df; two and four: k_qss_dfw) and the list-order kernel return the same bits
+    """The dataflow kernel with one, two and four waves per instance (k_qss_dfw<W>) and the list-order kernel return the same bits
     (G6 input, single and as a batch of 5), also when a dataflow kernel gives an instance back half way (RL_QSS_DF_BAIL_AT: the path
     taken when its tables overflow)."""
     g, pts, veh = _sim_inputs()

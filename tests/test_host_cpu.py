@@ -317,7 +317,7 @@ def test_set_up_double_track_problem_returns_the_reference_contract():
 
 
 def test_qss_dataflow_schedule_model():
-    """tests/qss_schedule_model.py: the readiness rules of k_qss_df replayed on step logs of the sequential oracle -- every step
+    """tests/qss_schedule_model.py: the readiness rules of k_qss_dfw replayed on step logs of the sequential oracle -- every step
     released only after all its true dependencies, progress in every pass, spawned fronts numbered in list order (the small
     cases here; 24 trajectories up to N = 2000 when the kernel was written)."""
     import os
