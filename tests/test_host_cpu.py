@@ -327,3 +327,7 @@ def test_qss_dataflow_schedule_model():
     out = subprocess.run([sys.executable, os.path.join(here, "qss_schedule_model.py"), "4", "24", "small"], capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0 and "no violation" in out.stdout and out.stdout.count("case ") >= 2, out.stdout[-1500:] + out.stderr[-1500:]
+    # the rules alone, iteration 0 included (the kernel runs that one in list order: start = 1 above)
+    out = subprocess.run([sys.executable, os.path.join(here, "qss_schedule_model.py"), "1", "24", "small", "0"], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "no violation" in out.stdout and out.stdout.count("case ") >= 1, out.stdout[-1500:] + out.stderr[-1500:]
