@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
       if (__any(in && o.e)) { err0 = 1; break; }
       if (in && o.wr) { V[ni] = o.nv; A[ni] = o.na; OWN[ni] = (u16)o.nown; }
       const u64 sm = __ballot(in && o.spawned);
-      if (nsp + __popcll(sm) > HX - N) { bail0 = 4; break; }
+      if (nsp + (int)__popcll(sm) > HX - N) { bail0 = 4; break; }
       if (in) {
         if (o.new_stop != 1) gE[f] = 1;
         else if (o.spawned) {
