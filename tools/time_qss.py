@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wall time of Simulator.run_simulation on the GPU (rl_qss_sim, host call incl. copies): Monza trajectories at N = 2000 and
 N = 500, one at a time and in batches, with the kernel rl_qss_sim_dev picks and with each of the two forced (RL_QSS_DF = 1: the
-dataflow kernel k_qss_df, 0: the list-order kernel k_qss_sim).   python tools/time_qss.py [B ...]"""
+dataflow kernel k_qss_dfw, 0: the list-order kernel k_qss_sim).   python tools/time_qss.py [B ...]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
