@@ -40,7 +40,7 @@
 // fronts numbered as in the reference's list).  Monza N = 2000: 213 k steps after iteration 0 in 3 790 passes (the list order:
 // 130 k rounds); one trajectory 167 -> 32 ms on the GPU, 1024 of them 183 -> 130 ms (profiles/r04_qss_*).
 //
-// Everything a step or a test touches lives in LDS (163 KB at N = 2000: one workgroup = one instance per CU, four waves).
+// Everything a step or a test touches lives in LDS (156 KB at N = 2000; N <= 2110: one workgroup = one instance per CU, four waves).
 // Instances whose size or front count exceeds the tables report iters = -2 and are re-run by k_qss_sim (launched right behind,
 // a no-op for every other instance).
 #pragma once
@@ -69,7 +69,7 @@ __host__ __device__ inline DfLayout df_layout(int N, int acc_m, int dcc_m) {
   auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 7) & ~(size_t)7; return at; };
   L.o_V = take((size_t)N * 8); L.o_A = take((size_t)N * 8); L.o_tab = take((size_t)L.n_tab * 8);
   L.o_bmE = take((size_t)L.NW * 8); L.o_bmX = take((size_t)L.NW * 8); L.o_idbm = take((size_t)(kDfIdMax / 64) * 8);
-  L.o_WH = take((size_t)(2 * N + 1) * 4);
+  L.o_WH = take((size_t)(2 * N + 2) * 2);   // 16-bit heads, updated with 32-bit compare-and-swap on the pair that holds them
   L.o_cntE = take(kDfCnt * 4); L.o_cntX = take(kDfCnt * 4); L.o_bcnt = take(kDfCnt * 4); L.o_scal = take(32 * 4);
   L.o_OWN = take((size_t)N * 2); L.o_gE = take((size_t)N * 2); L.o_idE = take((size_t)N * 2); L.o_tE = take((size_t)N * 2);
   L.o_hX = take((size_t)N * 2); L.o_sG = take((size_t)N * 2); L.o_sId = take((size_t)N * 2); L.o_sRec = take((size_t)N * 2);
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
     for (int i = tid; i <= a.dcc_m; i += TT) t_dx[i] = a.dcc_x[i];
     for (int i = tid; i < 4 * a.dcc_m; i += TT) t_dc[i] = a.dcc_c[i];
   }
-  for (int i = tid; i < 2 * N + 1; i += TT) WH[i] = kDfNone;
+  for (int i = tid; i < N + 1; i += TT) WH[i] = 0xFFFFFFFFu;   // two heads per word, all empty
   for (int i = tid; i < N; i += TT) {  // simulator.py:133-147
     const double* p = P + (size_t)i * 19;
     const double* q = P + (size_t)(i == 0 ? N - 1 : i - 1) * 19;
@@ -581,16 +581,31 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
   const bool timing = a.dbg != nullptr;
 #define DFW_TICK(k) do { if (timing) { const long long tn = clock64(); tp[k] += tn - tq; tq = tn; } } while (0)
   const int g_cap = N - 1;
-  // A sleeper is linked in with a compare-and-swap, its link written first: a wake-up of another wave that empties the list at
-  // the same moment either sees it complete or not at all.
+  // Wait-list heads are 16 bits, two to a word, and change by 32-bit compare-and-swap on that word (a retry also when the OTHER
+  // head of the word has changed meanwhile).  A sleeper is linked in with its link written first: a wake-up of another wave
+  // that empties the list at the same moment either sees it complete or not at all.
   auto sleep_on = [&](int key, int h) {
-    unsigned old = WH[key];
+    unsigned* word = WH + (key >> 1);
+    const int sh = (key & 1) * 16;
+    unsigned oldw = *word;
     while (true) {
-      WN[h] = (u16)old;
+      WN[h] = (u16)((oldw >> sh) & 0xFFFFu);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      const unsigned seen = atomicCAS(&WH[key], old, (unsigned)h);
-      if (seen == old) break;
-      old = seen;
+      const unsigned neww = (oldw & ~(0xFFFFu << sh)) | ((unsigned)h << sh);
+      const unsigned seen = atomicCAS(word, oldw, neww);
+      if (seen == oldw) break;
+      oldw = seen;
+    }
+  };
+  auto take_sleepers = [&](int key) {   // empties the list, returns its head
+    unsigned* word = WH + (key >> 1);
+    const int sh = (key & 1) * 16;
+    unsigned oldw = *word;
+    while (true) {
+      if (((oldw >> sh) & 0xFFFFu) == kDfNone) return kDfNone;
+      const unsigned seen = atomicCAS(word, oldw, oldw | (0xFFFFu << sh));
+      if (seen == oldw) return (oldw >> sh) & 0xFFFFu;
+      oldw = seen;
     }
   };
   // The next pass's queue -- exit agents from the front, enter agents from the back, so that a wave examines one kind only (the two
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
       // ---- wake whoever sleeps on my worldline ...
       {
         unsigned cur = kDfNone;
-        if (ready) cur = atomicExch(&WH[isX ? N + w : w], kDfNone);
+        if (ready) cur = take_sleepers(isX ? N + w : w);
         while (__any(cur != kDfNone)) {
           push_next(cur != kDfNone, (int)cur);
           if (cur != kDfNone) cur = WN[cur];

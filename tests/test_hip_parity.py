@@ -612,13 +612,13 @@ def test_qss_simulator_batch_and_bank(rl, fits):
 
 
 def test_qss_sizes_around_the_dataflow_tables(rl, fits, monkeypatch):
-    """Trajectories the dataflow kernel's LDS tables do not hold (N > 2004: rl_qss_sim_dev runs the list-order kernel), the largest
-    they do (N = 2004) and the smallest (N = 256; below it the list order again), each against the oracle."""
+    """Trajectories the dataflow kernel's LDS tables do not hold (N > 2110: rl_qss_sim_dev runs the list-order kernel), the largest
+    they do (N = 2110; and 2048) and the smallest (N = 256; below it the list order again), each against the oracle."""
     g, pts, veh = _sim_inputs()
     t, cx, cy, k, length = spline(fits, "c100")
     for k_ in ("RL_QSS_DF", "RL_QSS_DF_WAVES", "RL_QSS_DF_BAIL_AT"):
         monkeypatch.delenv(k_, raising=False)
-    for N in (200, 256, 2004, 2100):
+    for N in (200, 256, 2048, 2110, 2200):
         p = orc.sample_along(t, cx, cy, k, length, np.linspace(0, 1, N, endpoint=False))
         out, it = rl.ops.qss_sim(p, *veh)
         ref, oit = orc.qss_sim(p, *veh)
