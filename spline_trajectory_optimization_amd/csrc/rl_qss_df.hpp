@@ -52,6 +52,7 @@ constexpr int kDfR = 24;                 // iteration window: agents run at most
 constexpr int kDfCnt = 64;               // circular per-iteration counters (> kDfR + 2)
 constexpr int kDfIdMax = 8192;           // front ids below this (bitmap used when spawned fronts are numbered)
 constexpr unsigned kDfNone = 0xFFFFu;
+constexpr unsigned kDfParked = 0xFFFEu;   // in an agent's wait link: not on any list -- it is woken when it becomes the head of its exit worldline
 
 struct DfLayout {
   int n_tab, NW, NB, HX, QC;
@@ -77,7 +78,7 @@ __host__ __device__ inline DfLayout df_layout(int N, int acc_m, int dcc_m) {
   L.o_xn = take((size_t)L.HX * 2); L.o_xw = take((size_t)L.HX * 2);
   L.o_WN = take((size_t)L.QC * 2); L.o_pfx = take((size_t)(kDfIdMax / 64) * 2); L.o_blk = take((size_t)((N + 3) / 4 + 8) * 2);
   L.o_Q = take((size_t)L.QC * 2); L.o_Q2 = take((size_t)L.QC * 2);
-  L.o_req = take((size_t)5 * 256 * 2);   // k_qss_dfw: records released / fronts born in the current batch of agents (<= 256 each)
+  L.o_req = take((size_t)4 * 256 * 2);   // fronts born in the current batch of agents (<= 256): g, parent id, enter worldline, target sample
   L.bytes = o;
   return L;
 }
@@ -377,7 +378,7 @@ __device__ __forceinline__ DfStep dfw_step(const DfStepCtx& C, int side, int li,
 // or not at all; every thread derives the iteration window from the same counters, so nothing is broadcast.
 // (The first version, one wave per instance with these counters in wave-uniform registers, took 44 ms per N = 2000
 // trajectory against 32 ms: git history)
-enum { DFS_Q2N = 0, DFS_Q2NE, DFS_NWIN, DFS_ERR, DFS_BAIL, DFS_NFREE, DFS_NSPQ, DFS_GMINE, DFS_GMINX, DFS_GMIN, DFS_CHG, DFS_NE, DFS_NX, DFS_MAXG,
+enum { DFS_Q2N = 0, DFS_Q2NE, DFS_NWIN, DFS_ERR, DFS_BAIL, DFS_FREE, DFS_NSPQ, DFS_GMINE, DFS_GMINX, DFS_GMIN, DFS_CHG, DFS_NE, DFS_NX, DFS_MAXG,
        DFS_QN, DFS_QNE, DFS_NU, DFS_DEXAM, DFS_DSTEP, DFS_COUNT };
 static_assert(DFS_COUNT <= 32, "scalars");
 
@@ -428,8 +429,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
   double* GS = RAD + N;
   u16* U = reinterpret_cast<u16*>(a.flags + (size_t)b * 5 * a.cap);   // spawned fronts awaiting their number: birth, parent id, enter worldline, exit record
   const int Ucap = (5 * a.cap * 4) / 8;
-  u16* FREEQ = reinterpret_cast<u16*>(lds + L.o_req);                  // exit records released in the current batch of agents
-  u16* SPQ = FREEQ + TT;                                               // fronts born in it: g, parent id, enter worldline, target sample
+  u16* SPQ = reinterpret_cast<u16*>(lds + L.o_req);                    // fronts born in the current batch of agents: g, parent id, enter worldline, target sample
   u16* WINQ = reinterpret_cast<u16*>(a.fresh + (size_t)b * a.cap);     // agents asleep on the iteration window: a ring of 2^k <= 2 cap entries
   const int win_mask = (1 << (31 - __clz(2 * a.cap))) - 1;             //   (>= cap = 4 N + 16 > every agent there can be)
   const double lat0 = qss_acc_circle_lon(a, 0.0);
@@ -443,6 +443,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
     for (int i = tid; i < 4 * a.dcc_m; i += TT) t_dc[i] = a.dcc_c[i];
   }
   for (int i = tid; i < N + 1; i += TT) WH[i] = 0xFFFFFFFFu;   // two heads per word, all empty
+  for (int i = tid; i < L.QC; i += TT) WN[i] = (u16)kDfNone;      // (no agent parked)
   for (int i = tid; i < N; i += TT) {  // simulator.py:133-147
     const double* p = P + (size_t)i * 19;
     const double* q = P + (size_t)(i == 0 ? N - 1 : i - 1) * 19;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
   // fronts write.  A chunk at a time; per round every pending front computes, and a front's result holds iff no pending front
   // of the unbroken run before it writes (its source is then what it has read): the first writer of each run and the stoppers
   // before it commit.
-  int free_head = (int)kDfNone, next_id = N, Ulo = 0, numbered_upto = 0;   // kept by wave 0
+  int next_id = N, Ulo = 0, numbered_upto = 0;   // kept by wave 0
   if (wave == 0) {
     int err0 = 0, bail0 = 0, nsp = 0;
     for (int base = 0; base < N && !err0 && !bail0; base += 64) {
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
         qnx0 += __popcll(am); nX += __popcll(am);
       }
     }
-    free_head = N + nsp < HX ? N + nsp : (int)kDfNone;
+    if (lane == 0) scal[DFS_FREE] = N + nsp < HX ? N + nsp : (int)kDfNone;   // exit records not in use: a stack threaded through xn
     next_id = N + nsp;
     if (lane == 0) {
       scal[DFS_ERR] = err0; scal[DFS_BAIL] = bail0; scal[DFS_QN] = qnx0; scal[DFS_QNE] = qne0; scal[DFS_NE] = nE; scal[DFS_NX] = nX;
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
       my_exam += valid ? 1 : 0; my_step += ready ? 1 : 0;
       if (valid && key >= 0) {
         if (key == 2 * N) { const int slot = atomicAdd(&scal[DFS_NWIN], 1) & win_mask; WINQ[slot] = (u16)h; }
+        else if (isX && key == N + w) WN[h] = (u16)kDfParked;   // not the next of its own worldline: whoever makes it the next wakes it, and only it
         else sleep_on(key, h);
       }
       DFW_TICK(0);
@@ -668,6 +670,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
       __syncthreads();   // every examination and every step of the batch has read what it needs
       DFW_TICK(2);
       // ---- profile, own records, deaths and births queued for the one lane that edits the shared lists
+      int wake_head = -1;   // the agent this step / death / birth has made the next of an exit worldline, if it was parked
       if (ready && o.e) atomicOr(&scal[DFS_ERR], 1);
       if (ready && o.wr) { V[ni] = o.nv; A[ni] = o.na; OWN[ni] = (u16)o.nown; }
       if (ready && !die && g + 1 > g_cap) atomicMax(&scal[DFS_BAIL], 2);
@@ -692,10 +695,19 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
         else {   // leaves its worldline's list (only the next agent of a worldline can have stepped: the lists differ)
           dfw_pop_head(T, w);
           if (hX[w] == (u16)kDfNone) atomicAnd(&bmX[w >> 6], ~(1ull << (w & 63)));
-          const int slot = atomicAdd(&scal[DFS_NFREE], 1);
-          FREEQ[slot] = (u16)r;
+          int old = scal[DFS_FREE];   // its record back on the free stack (pushes only in this phase, pops only in the list lane's)
+          while (true) {
+            xn[r] = (u16)old;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const int seen = atomicCAS(&scal[DFS_FREE], old, r);
+            if (seen == old) break;
+            old = seen;
+          }
           atomicSub(&scal[DFS_NX], 1);
         }
+        dfw_summarise(T, w);   // the next agent of this worldline (a front born into it in this batch: again below)
+        const int hr = sRec[w];
+        if (hr != (int)kDfNone && WN[N + hr] == (u16)kDfParked) { WN[N + hr] = (u16)kDfNone; wake_head = N + hr; }
       }
       DFW_TICK(3);
       __syncthreads();
@@ -703,11 +715,10 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
       if (err || bail) break;
       const int cx = df_wrap(ni + 2 * N - (g + 1), N);   // (of a front born here: its exit worldline)
       {
-        const int nfree = scal[DFS_NFREE], nspq = scal[DFS_NSPQ];
-        if (nfree != 0 || nspq != 0) {
+        const int nspq = scal[DFS_NSPQ];
+        if (nspq != 0) {   // fronts were born in this batch: one lane gives each its exit record and links it into its worldline's list
           if (tid == 0) {
-            int nU = scal[DFS_NU], bl = 0;
-            for (int q = 0; q < nfree; ++q) { const int rr = FREEQ[q]; xn[rr] = (u16)free_head; free_head = rr; }
+            int nU = scal[DFS_NU], bl = 0, free_head = scal[DFS_FREE];
             for (int q = 0; q < nspq && !bl; ++q) {
               const u16* sp = SPQ + 4 * q;
               const int sg = sp[0], sid = sp[1], sw = sp[2], sni = sp[3];
@@ -717,6 +728,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
               free_head = xn[rec];
               const int cxx = df_wrap(sni + 2 * N - (sg + 1), N);
               xg[rec] = (u16)(sg + 1); xid[rec] = (u16)kDfNone; xt[rec] = (u16)sni; xw[rec] = (u16)cxx;
+              WN[N + rec] = (u16)kDfNone;
               dfw_insert(T, cxx, rec);
               bmX[cxx >> 6] |= 1ull << (cxx & 63);
               atomicAdd(&cntX[(sg + 1) & (kDfCnt - 1)], 1);
@@ -725,20 +737,22 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
               ++nU;
               atomicAdd(&scal[DFS_NX], 1);
             }
-            scal[DFS_NU] = nU;   // (the two request counters are cleared further down, once every thread has read them)
+            scal[DFS_NU] = nU; scal[DFS_FREE] = free_head;
             if (bl) atomicMax(&scal[DFS_BAIL], bl);
           }
           __syncthreads();
           bail = scal[DFS_BAIL];
           if (bail) break;
+          if (tid == 0) scal[DFS_NSPQ] = 0;   // (every thread has read it before the barrier above)
+          if (ready && spawned) {
+            dfw_summarise(T, cx);
+            const int hr = sRec[cx];
+            if (hr != (int)kDfNone && WN[N + hr] == (u16)kDfParked) { WN[N + hr] = (u16)kDfNone; wake_head = N + hr; }
+          }
+          __syncthreads();
         }
       }
       DFW_TICK(4);
-      // ---- the next agent of every exit worldline whose list or iteration counters have changed
-      if (ready && isX) dfw_summarise(T, w);
-      if (ready && spawned) dfw_summarise(T, cx);
-      __syncthreads();
-      if (tid == 0) { scal[DFS_NFREE] = 0; scal[DFS_NSPQ] = 0; }
       DFW_TICK(5);
       // ---- wake whoever sleeps on my worldline ...
       {
@@ -748,6 +762,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
           push_next(cur != kDfNone, (int)cur);
           if (cur != kDfNone) cur = WN[cur];
         }
+        push_next(wake_head >= 0, wake_head);
       }
       // ---- ... and queue myself, or go to sleep at once on the neighbour that blocks the next step
       int skey = -1;
@@ -755,7 +770,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
         const int g1 = g + 1;
         if (isX) {
           const int cm = w == 0 ? N - 1 : w - 1;
-          if ((int)sRec[w] != r) skey = N + w;
+          if ((int)sRec[w] != r) { skey = N + w; WN[h] = (u16)kDfParked; }   // (its turn comes round when the others of its worldline have stepped)
           else if ((int)sG[cm] <= g1 && (int)sId[cm] < id) skey = N + cm;
         } else {
           const int cu = w + 1 == N ? 0 : w + 1, cd = w == 0 ? N - 1 : w - 1;
@@ -763,7 +778,7 @@ __global__ __launch_bounds__(64 * W) void k_qss_dfw(QssArgs a) {
           if (ag != (int)kDfNone && (int)idE[cu] < id && ag <= g1) skey = cu;
           else if (bg != (int)kDfNone && bg <= g1 && !(bg == g1 && (int)idE[cd] > id)) skey = cd;
         }
-        if (skey >= 0) sleep_on(skey, h);
+        if (skey >= 0 && skey != N + w) sleep_on(skey, h);
       }
       push_next(ready && !die && skey < 0, h);
       __syncthreads();
