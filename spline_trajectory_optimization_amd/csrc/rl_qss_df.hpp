@@ -21,7 +21,8 @@
 //     blocked, so there is always progress; steps that are ready at the same time never conflict with each other.
 //   * blocked agents sleep on the worldline (or the window) that blocks them and are re-examined when that worldline's agent
 //     steps or dies; an agent that has just stepped goes to sleep at once on the neighbour that blocks its next step (the usual
-//     case in a train): 1.5 examinations per step instead of one per agent per round.
+//     case in a train); an exit agent that is merely not the next of its own worldline is parked and woken, alone, by whoever
+//     makes it the next: 1.3 examinations per step instead of one per agent per round.
 //   * iteration 0 runs in list order first (its enter sub-pass is conflict-free, its exit sub-pass is taken a chunk at a time):
 //     under the dataflow rules a front would have to wait for the front before it even where that one turns out to stop
 //     without writing -- one chain through all N fronts, which delays every later iteration too.
@@ -38,7 +39,7 @@
 // oracle under this scheduler and checks every released step against the TRUE read/write dependencies of the sequential order
 // (24 random trajectories, N = 257 ... 2000, banked and not, two vehicles: no violation, no pass without progress, spawned
 // fronts numbered as in the reference's list).  Monza N = 2000: 213 k steps after iteration 0 in 3 790 passes (the list order:
-// 130 k rounds); one trajectory 167 -> 32 ms on the GPU, 1024 of them 183 -> 130 ms (profiles/r04_qss_*).
+// 130 k rounds); one trajectory 167 -> 29 ms on the GPU, 1024 of them 184 -> 116 ms (profiles/r04_qss_*).
 //
 // Everything a step or a test touches lives in LDS (156 KB at N = 2000; N <= 2110: one workgroup = one instance per CU, four waves).
 // Instances whose size or front count exceeds the tables report iters = -2 and are re-run by k_qss_sim (launched right behind,
@@ -377,7 +378,7 @@ __device__ __forceinline__ DfStep dfw_step(const DfStepCtx& C, int side, int li,
 // compare-and-swap after its link is written, so that a wake-up by another wave that empties the same list sees it complete
 // or not at all; every thread derives the iteration window from the same counters, so nothing is broadcast.
 // (The first version, one wave per instance with these counters in wave-uniform registers, took 44 ms per N = 2000
-// trajectory against 32 ms: git history)
+// trajectory against 29 ms: git history)
 enum { DFS_Q2N = 0, DFS_Q2NE, DFS_NWIN, DFS_ERR, DFS_BAIL, DFS_FREE, DFS_NSPQ, DFS_GMINE, DFS_GMINX, DFS_GMIN, DFS_CHG, DFS_NE, DFS_NX, DFS_MAXG,
        DFS_QN, DFS_QNE, DFS_NU, DFS_DEXAM, DFS_DSTEP, DFS_COUNT };
 static_assert(DFS_COUNT <= 32, "scalars");
