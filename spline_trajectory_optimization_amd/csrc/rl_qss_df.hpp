@@ -372,8 +372,9 @@ __device__ __forceinline__ DfStep dfw_step(const DfStepCtx& C, int side, int li,
 // The kernel: W waves per instance (k_qss_dfw<W>; W = 4 in production, 1 and 2 in the tests).  The LDS tables of one instance
 // fill a CU at N = 2000, so one workgroup per CU is all there is; a pass is taken 64 W agents at a time, each phase once for
 // all of them, separated by workgroup barriers: examination + step arithmetic | profile, own records, heads of the worldline
-// lists | (one lane: records released and fronts born in this batch -- the free list and the lists a front is born into are
-// shared) | next agents | wake-ups, sleep or queue | end of pass.  Counters live in LDS (live agents per direction and
+// lists and their next agents, released records (pushed on the free stack by compare-and-swap) | (only when fronts were born
+// in this batch: one lane gives each its exit record and links it into its worldline's list) | wake-ups, sleep or queue | end
+// of pass.  Counters live in LDS (live agents per direction and
 // iteration, queue lengths as counters that are never reset, the window sleepers as a ring); a sleeper is linked in with a
 // compare-and-swap after its link is written, so that a wake-up by another wave that empties the same list sees it complete
 // or not at all; every thread derives the iteration window from the same counters, so nothing is broadcast.
