@@ -611,6 +611,23 @@ def test_qss_simulator_batch_and_bank(rl, fits):
         np.testing.assert_allclose(out[b][:, [4, 14, 15, 16]], ref[:, [4, 14, 15, 16]], rtol=0, atol=1e-10)
 
 
+def test_qss_dataflow_same_bits_whatever_the_timing(rl, monkeypatch):
+    """The dataflow kernel's waves race for queue slots and wait-list heads; the ORDER steps run in may differ from run to run and
+    from instance to instance, the RESULT may not: 96 copies of one trajectory in one launch (different CUs, different timing) and
+    three launches return the same bits."""
+    g, pts, veh = _sim_inputs()
+    monkeypatch.setenv("RL_QSS_DF", "1")
+    monkeypatch.delenv("RL_QSS_DF_WAVES", raising=False)
+    first = None
+    for rep in range(3):
+        out, it = rl.ops.qss_sim(np.repeat(pts[None], 96, axis=0), *veh)
+        if first is None:
+            first = (out[0].copy(), int(it[0]))
+        assert (np.asarray(it) == first[1]).all()
+        for b in range(out.shape[0]):
+            np.testing.assert_array_equal(out[b], first[0])
+
+
 def test_qss_sizes_around_the_dataflow_tables(rl, fits, monkeypatch):
     """Trajectories the dataflow kernel's LDS tables do not hold (N > 2110: rl_qss_sim_dev runs the list-order kernel), the largest
     they do (N = 2110; and 2048) and the smallest (N = 256; below it the list order again), each against the oracle."""
