@@ -23,6 +23,29 @@
 
 #define ORC_MAXK 7
 
+/* ---------------------------------------------------------------- elementary functions of the sampled heading
+ * The reference takes the heading and the normal through numpy: yaw = np.arctan2(y', x') (trajectory.py:250),
+ * max_dist * np.cos / np.sin(yaw +- pi/2) (trajectory.py:87-92).  What numpy calls there is the platform's libm
+ * (glibc 2.35 in this image: atan2 / sin / cos with errors up to 0.55 ulp, i.e. NOT always the correctly rounded
+ * value: measured 0.09 % / 0.14 % / 0.14 % of random arguments differ from it by one ulp).  Two builds of this file:
+ *   default        the platform libm, like the reference run on this image;
+ *   -DORC_LIBM_CR  the CORRECTLY ROUNDED values (libquadmath at 113 bits, then one rounding to double): the
+ *                  platform-independent definition of the same three functions, which is what the HIP kernel's
+ *                  reference-order mode computes (its own double-double code, rl_crmath.hpp) -- so that the two can be
+ *                  compared bit for bit.  libmincurv_oracle_cr.so; checked against the same fixtures as the default. */
+#ifdef ORC_LIBM_CR
+#include <quadmath.h>
+static double o_atan2(double y, double x) { return (double)atan2q((__float128)y, (__float128)x); }
+static double o_cos(double x) { return (double)cosq((__float128)x); }
+static double o_sin(double x) { return (double)sinq((__float128)x); }
+int orc_libm_is_correctly_rounded(void) { return 1; }
+#else
+static double o_atan2(double y, double x) { return atan2(y, x); }
+static double o_cos(double x) { return cos(x); }
+static double o_sin(double x) { return sin(x); }
+int orc_libm_is_correctly_rounded(void) { return 0; }
+#endif
+
 /* ---------------------------------------------------------------- re-rounding (test diagnostics)
  * Monte-Carlo arithmetic in miniature: with a non-zero seed the sampled positions, headings and bound
  * points -- the quantities whose last bits the reference's constraint rows amplify by 1/b (DESIGN.md
@@ -214,7 +237,7 @@ static void sample_geometry(const double* t, int nt, const double* cx, const dou
     double* p = points + (size_t)i * ORC_NCOL;
     p[ORC_X] = rr(x[i]);
     p[ORC_Y] = rr(y[i]);
-    p[ORC_YAW] = rr(atan2(dy[i], dx[i]));
+    p[ORC_YAW] = rr(o_atan2(dy[i], dx[i]));
     /* __get_turn_radius, trajectory.py:253-260 */
     double s2 = dx[i] * dx[i] + dy[i] * dy[i];
     double curvature = fabs(dx[i] * d2y[i] - dy[i] * d2x[i]) / sqrt(s2 * s2 * s2);
@@ -247,7 +270,7 @@ void orc_sample_along(const double* t, int nt, const double* cx, const double* c
  * Ties keep the lowest edge index. */
 static void closest_hit(double px, double py, double yaw_norm, double max_dist,
                         const double* ring, int nr, double* bx, double* by) {
-  double dx = max_dist * cos(yaw_norm), dy = max_dist * sin(yaw_norm);
+  double dx = max_dist * o_cos(yaw_norm), dy = max_dist * o_sin(yaw_norm);
   double best = INFINITY, best_s = 0.0;
   int found = 0;
   for (int j = 0; j < nr; ++j) {
@@ -548,10 +571,10 @@ void orc_solve_width_batch_seeded(const double* t, int nt, const double* cx0, co
     for (int i = 0; i < N; ++i) {
       const double* p = base + (size_t)i * ORC_NCOL;
       double wl = widths[((size_t)b * N + i) * 2], wr = widths[((size_t)b * N + i) * 2 + 1];
-      ringL[2 * i] = p[ORC_X] + wl * cos(p[ORC_YAW] + M_PI / 2.0);
-      ringL[2 * i + 1] = p[ORC_Y] + wl * sin(p[ORC_YAW] + M_PI / 2.0);
-      ringR[2 * i] = p[ORC_X] + wr * cos(p[ORC_YAW] + (-M_PI / 2.0));
-      ringR[2 * i + 1] = p[ORC_Y] + wr * sin(p[ORC_YAW] + (-M_PI / 2.0));
+      ringL[2 * i] = p[ORC_X] + wl * o_cos(p[ORC_YAW] + M_PI / 2.0);
+      ringL[2 * i + 1] = p[ORC_Y] + wl * o_sin(p[ORC_YAW] + M_PI / 2.0);
+      ringR[2 * i] = p[ORC_X] + wr * o_cos(p[ORC_YAW] + (-M_PI / 2.0));
+      ringR[2 * i + 1] = p[ORC_Y] + wr * o_sin(p[ORC_YAW] + (-M_PI / 2.0));
     }
     double* pts = (double*)malloc((size_t)N * ORC_NCOL * sizeof(double));
     orc_trajectory_init(pts, N);
@@ -608,10 +631,10 @@ void orc_width_rings(const double* t, int nt, const double* cx0, const double* c
   for (int i = 0; i < N; ++i) {
     const double* p = base + (size_t)i * ORC_NCOL;
     double wl = widths[(size_t)i * 2], wr = widths[(size_t)i * 2 + 1];
-    ringL[2 * i] = p[ORC_X] + wl * cos(p[ORC_YAW] + M_PI / 2.0);
-    ringL[2 * i + 1] = p[ORC_Y] + wl * sin(p[ORC_YAW] + M_PI / 2.0);
-    ringR[2 * i] = p[ORC_X] + wr * cos(p[ORC_YAW] + (-M_PI / 2.0));
-    ringR[2 * i + 1] = p[ORC_Y] + wr * sin(p[ORC_YAW] + (-M_PI / 2.0));
+    ringL[2 * i] = p[ORC_X] + wl * o_cos(p[ORC_YAW] + M_PI / 2.0);
+    ringL[2 * i + 1] = p[ORC_Y] + wl * o_sin(p[ORC_YAW] + M_PI / 2.0);
+    ringR[2 * i] = p[ORC_X] + wr * o_cos(p[ORC_YAW] + (-M_PI / 2.0));
+    ringR[2 * i + 1] = p[ORC_Y] + wr * o_sin(p[ORC_YAW] + (-M_PI / 2.0));
   }
   free(u);
   free(base);

@@ -21,9 +21,8 @@ _ip = ctypes.POINTER(ctypes.c_int)
 def build(force=False):
     src = os.path.join(_HERE, "mincurv_oracle.c")
     so = os.path.join(_HERE, "libmincurv_oracle.so")
-    so2 = os.path.join(_HERE, "libmincurv_oracle_fma.so")
-    if force or not os.path.exists(so) or not os.path.exists(so2) or os.path.getmtime(so) < os.path.getmtime(src) \
-            or os.path.getmtime(so2) < os.path.getmtime(src):
+    others = [os.path.join(_HERE, "libmincurv_oracle_fma.so"), os.path.join(_HERE, "libmincurv_oracle_cr.so")]
+    if force or any(not os.path.exists(f) or os.path.getmtime(f) < os.path.getmtime(src) for f in [so] + others):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -32,8 +31,12 @@ _lib = None
 
 
 class _Variant:
-    """Context manager: route the wrappers of this module to the FMA-contracted build of the same
-    oracle source (noise-sensitivity diagnostics in the tests)."""
+    """Context manager: route the wrappers of this module to another build of the same oracle source:
+    the FMA-contracted one (noise-sensitivity diagnostics in the tests) or the one with the correctly
+    rounded atan2 / cos / sin (oracle/Makefile)."""
+
+    def __init__(self, so_name="libmincurv_oracle_fma.so"):
+        self.so_name = so_name
 
     def __enter__(self):
         global _lib
@@ -41,7 +44,7 @@ class _Variant:
         self.saved = _lib
         _lib = None
         self.saved_so = globals()["_SO"]
-        globals()["_SO"] = os.path.join(_HERE, "libmincurv_oracle_fma.so")
+        globals()["_SO"] = os.path.join(_HERE, self.so_name)
         return self
 
     def __exit__(self, *exc):
@@ -53,6 +56,12 @@ class _Variant:
 
 def fma_variant():
     return _Variant()
+
+
+def cr_variant():
+    """The strict build whose heading / normal functions are the correctly rounded ones: what the HIP
+    kernel's reference-order mode (RL_ARITH_REFERENCE) must reproduce bit for bit."""
+    return _Variant("libmincurv_oracle_cr.so")
 
 
 def lib():

@@ -429,7 +429,11 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
       if (base >= 0) {
         int off = lo - base;
         if (off < 0) off += nr;
-        if (todo && off + kWinEdges + 1 <= kStage) {
+        // (off & 7): a window is served from the stretch only when it starts on a chunk boundary OF THE STRETCH -- the
+        // padded slot of its vertex k is then stage_slot(off) + k + (k >> 3) (StagedWindow).  Window starts and stretch
+        // bases are multiples of kChunk, so this only fails behind the seam of a ring whose length is not a multiple of
+        // kChunk (off = lo - base + nr); such a lane is re-staged from its own window start (off = 0) below.
+        if (todo && (off & (kChunk - 1)) == 0 && off + kWinEdges + 1 <= kStage) {
           scan_window<kStageBatch>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h);
           todo = false;
         }

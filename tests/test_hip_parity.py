@@ -347,6 +347,33 @@ def test_ring_residency_variants_agree(rl, fits, rings, monkeypatch):
         np.testing.assert_array_equal(res["0"][2], res[v][2])
 
 
+@pytest.mark.parametrize("N", [498, 499, 501, 503])
+def test_ring_residency_ring_length_not_a_multiple_of_the_chunk(rl, fits, rings, monkeypatch, N):
+    """Rings in global memory are scanned from a staged LDS stretch whose padded slot map assumes that a window starts
+    on a chunk boundary of the stretch.  Behind the seam of a ring whose length is not a multiple of 8 that is false
+    (round-4 advisor finding: 3-18 of a window's 25 vertices were read one slot off); such lanes must be re-staged.
+    N % 8 in {2, 3, 5, 7} on width-form rings (ring length = N), and the shared Monza rings (2913 / 2879 vertices:
+    residues 1 and 7) forced into global memory: every residency returns the same bits."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    B = 4
+    widths = monza_like_widths(rl, fits, rings, "c100", N, B, seed=5)
+    i_start = rl.batch.default_i_start(len(cx), k, 2, seed=N)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    trk.set_rings(rings[0], rings[1])
+    res, shared = {}, {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("RL_FORCE_RESIDENCY", v)
+        res[v] = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
+        shared[v] = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_SHARED_RINGS, None, i_start, B=2)
+        assert res[v][4].rings_in_lds == int(v)
+    for a, b in ((res["0"], res["1"]), (shared["0"], shared["1"])):
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+    monkeypatch.setenv("RL_FORCE_RESIDENCY", "0")
+    brute = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=0)
+    np.testing.assert_array_equal(brute[0], res["0"][0]); np.testing.assert_array_equal(brute[2], res["0"][2])
+
+
 def test_bound_points_form_matches_widths_form(rl, fits):
     t, cx, cy, k, length = spline(fits, "c100")
     N, B = 300, 4
