@@ -23,7 +23,7 @@
  *     changed between calls (rl_ctx_set_stream): the *_dev calls that use the arena order themselves behind the
  *     previous user of the arena with an event when the stream has changed, so two such calls enqueued on different
  *     streams without a host synchronisation in between run one after the other, never on the same scratch at once;
- *   - the only environment variables the product library reads are RL_GLOBAL_V1, RL_MT_HES_SWEEP, RL_MT_UNFUSED, RL_MT_KKT4, RL_MT_GROUPS (test
+ *   - the only environment variables the product library reads are RL_ARITH (default arithmetic of new contexts), RL_GLOBAL_V1, RL_MT_HES_SWEEP, RL_MT_UNFUSED, RL_MT_KKT4, RL_MT_GROUPS (test
  *     hooks selecting a second implementation, read once in rl_ctx_create) and RL_FORCE_RESIDENCY / RL_FORCE_GLOBAL_RINGS
  *     (residency of the sweep's per-instance state; all variants are bit-identical): INTEGRATION.md lists them.  Solver
  *     strategy constants are compile-time; RL_MT_* / RL_DEBUG_FLAGS overrides exist only in a -DRL_ABLATION diagnostic build;
@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 100          /* 0.1.0 */
+#define RL_VERSION 101          /* 0.1.1: rl_ctx_set_arith */
 #define RL_NCOL 19              /* Trajectory columns, models/trajectory.py:26-44 */
 #define RL_MAX_ITER 32          /* max outer iterations per sweep call */
 #define RL_MAX_DEGREE 5
@@ -59,12 +59,23 @@ enum {
  * chunk-circle guard (the fast one) */
 enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1, RL_SEARCH_WINDOWED = 2 };
 
+/* Arithmetic of the sweep (rl_mincurv_sweep, rl_mincurv_solve_batch_*), per context (rl_ctx_set_arith; RL_ARITH=reference
+ * in the environment sets the default of new contexts):
+ *   RL_ARITH_FAST       fma throughout, normal from a reciprocal square root, tree sums -- a legal rounding of the
+ *                       reference's arithmetic, within the nearest-branch rule of DESIGN.md section 5;
+ *   RL_ARITH_REFERENCE  the reference's operations in the reference's order (numpy / scipy: unfused de Boor
+ *                       recurrences and sums, splder derivative splines in the cost, sequential cost sums, unfused
+ *                       cross products, yaw = atan2 and the normals cos / sin(yaw +- pi/2) CORRECTLY ROUNDED): returns
+ *                       the bits of oracle/mincurv_oracle.c built with -DORC_LIBM_CR.  run_min_curvature_qp on
+ *                       degree-5 splines (the reference's wrap, optimizer.py:281-285, is written for k = 5). */
+enum { RL_ARITH_FAST = 0, RL_ARITH_REFERENCE = 1 };
+
 typedef struct rl_stats {
   float kernel_ms;       /* duration of the sweep kernel of the last *_host call (hipEvent)  */
   int lds_bytes;         /* dynamic LDS per workgroup                                          */
   int block_threads;     /* workgroup size                                                     */
   int rings_in_lds;      /* 1 = ring vertices LDS-resident, 0 = global scratch                 */
-  int reserved[4];
+  int reserved[4];       /* [0] = the arithmetic the sweep ran with (RL_ARITH_*)               */
 } rl_stats;
 
 int rl_version(void);
@@ -85,6 +96,12 @@ void rl_ctx_destroy(rl_ctx* ctx);
 /* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
 int rl_ctx_set_stream(rl_ctx* ctx, void* hip_stream);
 int rl_ctx_synchronize(rl_ctx* ctx);
+/* arithmetic of the sweep entry points of this context: RL_ARITH_FAST (default) or RL_ARITH_REFERENCE */
+int rl_ctx_set_arith(rl_ctx* ctx, int arith);
+int rl_ctx_get_arith(const rl_ctx* ctx);
+/* test aid: out[n,5] = yaw, cos / sin(yaw + pi/2), cos / sin(yaw - pi/2) of the tangents (dx, dy), as the
+ * reference-order mode computes them (csrc/rl_crmath.hpp: correctly rounded; trajectory.py:87-92, 250) */
+int rl_debug_cr_heading(rl_ctx* ctx, const double* dx, const double* dy, int n, double* out);
 
 /* ---- a3: BSplineTrajectory.eval / interpolate.splev  (models/trajectory.py:247-251)
  * out is [(der_max+1)*2, N]: x, y, x', y', x'', y'' rows. */

@@ -260,6 +260,20 @@ void orc_sample_along(const double* t, int nt, const double* cx, const double* c
     points[(size_t)i * ORC_NCOL + ORC_DIST_FWD] = length - points[(size_t)i * ORC_NCOL + ORC_DIST_BWD];
 }
 
+/* the heading of a tangent and the two normal directions exactly as sample_geometry / closest_hit take them:
+ * out[5] = yaw, cos / sin(yaw + pi/2), cos / sin(yaw - pi/2).  Test aid: in the -DORC_LIBM_CR build these are the
+ * correctly rounded values the HIP kernel's reference-order mode must return. */
+void orc_heading(const double* dx, const double* dy, int n, double* out) {
+  for (int i = 0; i < n; ++i) {
+    double yaw = o_atan2(dy[i], dx[i]);
+    out[5 * i] = yaw;
+    out[5 * i + 1] = o_cos(yaw + M_PI / 2.0);
+    out[5 * i + 2] = o_sin(yaw + M_PI / 2.0);
+    out[5 * i + 3] = o_cos(yaw + (-M_PI / 2.0));
+    out[5 * i + 4] = o_sin(yaw + (-M_PI / 2.0));
+  }
+}
+
 /* ---------------------------------------------------------------- fill_bounds */
 
 /* Closest intersection of the normal segment  p + s*d, s in [-1,1]  (d = max_dist*(cos,sin)(yaw+norm))

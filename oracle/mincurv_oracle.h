@@ -163,6 +163,11 @@ void orc_replay_steps(const double* t, int nt, int k, int N, const double* ringL
                       const double* ringR, int nR, int n_steps, const int* idx,
                       const double* cxs, const double* cys, double* out, int nthreads);
 
+/* heading of a tangent + the two normal directions as the sampling / boundary code takes them (test aid);
+ * orc_libm_is_correctly_rounded() = 1 in the -DORC_LIBM_CR build (libmincurv_oracle_cr.so) */
+void orc_heading(const double* dx, const double* dy, int n, double* out /*[n,5]*/);
+int orc_libm_is_correctly_rounded(void);
+
 #ifdef __cplusplus
 }
 #endif

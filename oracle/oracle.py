@@ -96,6 +96,15 @@ def _i(a):
     return a, a.ctypes.data_as(_ip)
 
 
+def heading(dx, dy):
+    """[n,5] = yaw, cos / sin(yaw + pi/2), cos / sin(yaw - pi/2) as sample_along / fill_bounds take them
+    (inside cr_variant(): the correctly rounded values)."""
+    dx, xp = _d(dx); dy, yp = _d(dy)
+    out = np.empty((len(dx), 5))
+    lib().orc_heading(xp, yp, len(dx), out.ctypes.data_as(_dp))
+    return out
+
+
 def bspline_eval(t, c, k, x, der=0):
     t, tp = _d(t); c, cp = _d(c); x, xp = _d(np.atleast_1d(x))
     out = np.empty_like(x)

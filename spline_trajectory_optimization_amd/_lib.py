@@ -16,6 +16,7 @@ NCOL = 19
 MAX_ITER = 32
 BOUNDS_SHARED_RINGS, BOUNDS_WIDTHS, BOUNDS_POINTS = 0, 1, 2
 SEARCH_BRUTE, SEARCH_CULLED, SEARCH_WINDOWED = 0, 1, 2
+ARITH_FAST, ARITH_REFERENCE = 0, 1   # include/rl_mincurv.h: RL_ARITH_*
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -42,6 +43,9 @@ _SIGNATURES = {
     "rl_ctx_destroy": (None, [_vp]),
     "rl_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
     "rl_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "rl_ctx_set_arith": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rl_ctx_get_arith": (ctypes.c_int, [_vp]),
+    "rl_debug_cr_heading": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, _dp]),
     "rl_spline_eval": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp,
                                       ctypes.c_int, ctypes.c_int, _dp]),
     "rl_sample_along": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int,
@@ -166,6 +170,27 @@ class Context:
 
     def synchronize(self):
         check(self.lib.rl_ctx_synchronize(self.h))
+
+    def set_arith(self, arith):
+        """ARITH_FAST (default) or ARITH_REFERENCE: the reference's operations in the reference's order
+        (include/rl_mincurv.h).  Returns the previous setting."""
+        old = self.lib.rl_ctx_get_arith(self.h)
+        check(self.lib.rl_ctx_set_arith(self.h, int(arith)))
+        return old
+
+    def arith(self, arith):
+        """with ctx.arith(ARITH_REFERENCE): ...  -- the sweep calls inside run in that arithmetic."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = ctx.set_arith(arith)
+                return ctx
+
+            def __exit__(self_, *exc):
+                ctx.set_arith(self_.old)
+                return False
+        return _Scope()
 
 
 class Track:

@@ -24,6 +24,9 @@ struct TrackDev {
   const int* sup;      // [n][2] sample range [s0,s1) with t[j] <= u_i < t[j+k+1]
                        //        (the mask of optimizer.py:27-29 / 225-227)
   const double* base;  // [4][N] initial line p0x, p0y and unit left normal n0x, n0y
+  // reference-order mode only (rl_kernels.hpp: StrictRows), built on first use:
+  const double* Ds;      // [5k+2][N] unfused de Boor values D0 | D1 | D2 | E1 | E2
+  const double* base_s;  // [6][N] p0x, p0y, cos / sin(yaw0 + pi/2), cos / sin(yaw0 - pi/2)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -127,10 +130,20 @@ constexpr int kNoEdge = 0x7fffffff;
 // the sign of this value decides on which edge a crossing through a ring vertex is found, and the
 // window scan evaluates it twice (candidate pass, exact pass).  Left to the compiler, the
 // contraction of a*b - c*d differs between call sites.
+// ST (the reference-order mode, RL_ARITH_REFERENCE): two rounded products and a subtraction, like numpy and like
+// oracle/mincurv_oracle.c: closest_hit -- with one product exact (fma) a crossing through a sample that sits ON a ring
+// leaves another residual than the reference's.
+__device__ __forceinline__ double cross_unfused(double a, double b, double c, double d) {
+#pragma clang fp contract(off)
+  return a * b - c * d;
+}
+template <bool ST = false>
 __device__ __forceinline__ double edge_side(double vx, double vy, double dx, double dy) {
-  return fma(vx, dy, -(vy * dx));
+  if constexpr (ST) return cross_unfused(vx, dy, vy, dx);
+  else return fma(vx, dy, -(vy * dx));
 }
 
+template <bool ST = false>
 __device__ __forceinline__ void edge_hit(double ax, double ay, double ea, double bx, double by,
                                          double eb, double dx, double dy, int edge, Hit& h) {
   // edge strictly on one side of the line <=> ea, eb non-zero with equal signs.  One multiply
@@ -139,28 +152,28 @@ __device__ __forceinline__ void edge_hit(double ax, double ay, double ea, double
   if (prod > 0.0) return;
   if (prod == 0.0 && ea != 0.0 && eb != 0.0 && ((ea > 0.0) == (eb > 0.0))) return;
   const double sx = bx - ax, sy = by - ay;
-  const double den = fma(dx, sy, -(dy * sx));
+  const double den = ST ? cross_unfused(dx, sy, dy, sx) : fma(dx, sy, -(dy * sx));
   if (den == 0.0) return;  // parallel / collinear: not a Point intersection
-  const double s = fma(ax, sy, -(ay * sx)) / den;
+  const double s = (ST ? cross_unfused(ax, sy, ay, sx) : fma(ax, sy, -(ay * sx))) / den;
   const double as = fabs(s);
   if (as > 1.0) return;  // beyond +-max_dist
   if (as < h.best || (as == h.best && edge < h.edge)) { h.best = as; h.best_s = s; h.edge = edge; }
 }
 
 // scan edges j0 .. j0+count-1 (indices modulo nr); addresses are lane-uniform when j0 is
-template <typename RingPtr>
+template <bool ST = false, typename RingPtr>
 __device__ __forceinline__ void scan_edges(RingPtr ring, int nr, int j0, int count, double px,
                                            double py, double dx, double dy, Hit& h) {
   int j = j0;
   double2 v = ring[j];
   double ax = v.x - px, ay = v.y - py;
-  double ea = edge_side(ax, ay, dx, dy);
+  double ea = edge_side<ST>(ax, ay, dx, dy);
   for (int q = 0; q < count; ++q) {
     const int j1 = (j + 1 == nr) ? 0 : j + 1;
     v = ring[j1];
     const double bx = v.x - px, by = v.y - py;
-    const double eb = edge_side(bx, by, dx, dy);
-    edge_hit(ax, ay, ea, bx, by, eb, dx, dy, j, h);
+    const double eb = edge_side<ST>(bx, by, dx, dy);
+    edge_hit<ST>(ax, ay, ea, bx, by, eb, dx, dy, j, h);
     ax = bx; ay = by; ea = eb;
     j = j1;
   }
@@ -168,13 +181,13 @@ __device__ __forceinline__ void scan_edges(RingPtr ring, int nr, int j0, int cou
 
 // Same scan with the vertex loads issued BATCH at a time ahead of the arithmetic: with one wave per
 // SIMD nothing else hides the LDS latency, so the loads of a batch share one wait.
-template <int BATCH, typename RingPtr>
+template <int BATCH, bool ST = false, typename RingPtr>
 __device__ __forceinline__ void scan_edges_batched(RingPtr ring, int nr, int j0, int count, double px,
                                                    double py, double dx, double dy, Hit& h) {
   int j = j0;
   double2 v = ring[j];
   double ax = v.x - px, ay = v.y - py;
-  double ea = edge_side(ax, ay, dx, dy);
+  double ea = edge_side<ST>(ax, ay, dx, dy);
   int q = 0;
   for (; q + BATCH <= count; q += BATCH) {
     double2 w[BATCH];
@@ -189,8 +202,8 @@ __device__ __forceinline__ void scan_edges_batched(RingPtr ring, int nr, int j0,
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
       const double bx = w[u].x - px, by = w[u].y - py;
-      const double eb = edge_side(bx, by, dx, dy);
-      edge_hit(ax, ay, ea, bx, by, eb, dx, dy, u == 0 ? j : jj[u - 1], h);
+      const double eb = edge_side<ST>(bx, by, dx, dy);
+      edge_hit<ST>(ax, ay, ea, bx, by, eb, dx, dy, u == 0 ? j : jj[u - 1], h);
       ax = bx; ay = by; ea = eb;
     }
     j = jj[BATCH - 1];
@@ -201,8 +214,8 @@ __device__ __forceinline__ void scan_edges_batched(RingPtr ring, int nr, int j0,
       const int j1 = (j + 1 == nr) ? 0 : j + 1;
       v = ring[j1];
       const double bx = v.x - px, by = v.y - py;
-      const double eb = edge_side(bx, by, dx, dy);
-      edge_hit(ax, ay, ea, bx, by, eb, dx, dy, j, h);
+      const double eb = edge_side<ST>(bx, by, dx, dy);
+      edge_hit<ST>(ax, ay, ea, bx, by, eb, dx, dy, j, h);
       ax = bx; ay = by; ea = eb;
       j = j1;
     }
@@ -229,13 +242,13 @@ constexpr int kWinBatch = 8;
 // `lo` addresses the vertices (ring[lo .. lo + kWinEdges]); `lo_edge` numbers the edges (edge q of the window is edge
 // lo_edge + q of the ring, modulo nr).  Scanning the ring itself: lo == lo_edge; scanning a staged stretch: lo = offset
 // of the window inside the stretch.
-template <int BATCH = kWinBatch, typename RingPtr>
+template <int BATCH = kWinBatch, bool ST = false, typename RingPtr>
 __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo_edge, double px, double py,
                                             double dx, double dy, Hit& h) {
   unsigned cand = 0u;
   {
     double2 v = ring[lo];
-    double ea = edge_side(v.x - px, v.y - py, dx, dy);
+    double ea = edge_side<ST>(v.x - px, v.y - py, dx, dy);
 #pragma unroll
     for (int q0 = 0; q0 < kWinEdges; q0 += BATCH) {
       double2 w[BATCH];
@@ -243,7 +256,7 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
       for (int u = 0; u < BATCH; ++u) w[u] = ring[lo + q0 + u + 1];
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const double eb = edge_side(w[u].x - px, w[u].y - py, dx, dy);
+        const double eb = edge_side<ST>(w[u].x - px, w[u].y - py, dx, dy);
         if (!(ea * eb > 0.0)) cand |= 1u << (q0 + u);
         ea = eb;
       }
@@ -258,7 +271,7 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
       const int j = lo + q, je = lo_edge + q;
       const double2 va = ring[j], vb = ring[j + 1];
       const double ax = va.x - px, ay = va.y - py, bx = vb.x - px, by = vb.y - py;
-      edge_hit(ax, ay, edge_side(ax, ay, dx, dy), bx, by, edge_side(bx, by, dx, dy), dx, dy,
+      edge_hit<ST>(ax, ay, edge_side<ST>(ax, ay, dx, dy), bx, by, edge_side<ST>(bx, by, dx, dy), dx, dy,
                je >= nr ? je - nr : je, h);
     }
   }
@@ -317,11 +330,11 @@ __device__ __forceinline__ int window_start(int hint, int nchunk) {
 }
 
 // brute force over all edges; ring vertices as double2 (x,y), any address space
-template <typename RingPtr>
+template <bool ST = false, typename RingPtr>
 __device__ __forceinline__ Hit search_ring_brute(RingPtr ring, int nr, double px, double py,
                                                  double dx, double dy) {
   Hit h{INFINITY, 0.0, kNoEdge};
-  scan_edges(ring, nr, 0, nr, px, py, dx, dy, h);
+  scan_edges<ST>(ring, nr, 0, nr, px, py, dx, dy, h);
   return h;
 }
 
@@ -331,7 +344,7 @@ __device__ __forceinline__ Hit search_ring_brute(RingPtr ring, int nr, double px
 // passes is scanned exactly like the brute-force loop, so the result (including tie-breaking) is
 // identical to search_ring_brute.
 
-template <typename RingPtr, typename CirclePtr>
+template <bool ST = false, typename RingPtr, typename CirclePtr>
 __device__ __forceinline__ Hit search_ring_culled(RingPtr ring, int nr, CirclePtr circ, int nchunk,
                                                   double px, double py, double dx, double dy,
                                                   double dlen) {
@@ -342,7 +355,7 @@ __device__ __forceinline__ Hit search_ring_culled(RingPtr ring, int nr, CirclePt
     if (fabs(mx * dy - my * dx) > rr) continue;
     if (fabs(mx * dx + my * dy) > (dlen + r) * dlen * (1.0 + 1e-9) + 1e-9) continue;
     const int j0 = c * kChunk;
-    scan_edges(ring, nr, j0, min(kChunk, nr - j0), px, py, dx, dy, h);
+    scan_edges<ST>(ring, nr, j0, min(kChunk, nr - j0), px, py, dx, dy, h);
   }
   return h;
 }
@@ -405,7 +418,7 @@ __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>
 // contains every edge with a crossing not farther than the best one == search_ring_brute, bit for bit.
 // STAGED: the window is scanned from the wave's LDS stretch `stg` (staged_base = first vertex of what it holds now, -1 =
 // nothing yet); `ring` is then the global ring (slow path and re-staging).
-template <bool STAGED = false, typename RingPtr, typename CirclePtr>
+template <bool STAGED = false, bool ST = false, typename RingPtr, typename CirclePtr>
 __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, CirclePtr circ,
                                                     CirclePtr sep, int nchunk, bool active, int hint,
                                                     double px, double py, double dx, double dy,
@@ -421,7 +434,7 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0) :: "memory");
 #endif
   if constexpr (!STAGED) {
-    if (windowed) scan_window(ring, nr, lo, lo, px, py, dx, dy, h);
+    if (windowed) scan_window<kWinBatch, ST>(ring, nr, lo, lo, px, py, dx, dy, h);
   } else {
     bool todo = windowed;
     int base = staged_base;
@@ -434,7 +447,7 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
         // bases are multiples of kChunk, so this only fails behind the seam of a ring whose length is not a multiple of
         // kChunk (off = lo - base + nr); such a lane is re-staged from its own window start (off = 0) below.
         if (todo && (off & (kChunk - 1)) == 0 && off + kWinEdges + 1 <= kStage) {
-          scan_window<kStageBatch>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h);
+          scan_window<kStageBatch, ST>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h);
           todo = false;
         }
       }
@@ -516,7 +529,7 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
       }
       if (__any(need)) {
         Hit h2 = h;
-        scan_edges_batched<kChunk>(ring, nr, e0, cnt, px, py, dx, dy, h2);
+        scan_edges_batched<kChunk, ST>(ring, nr, e0, cnt, px, py, dx, dy, h2);
         if (slow) h = h2;
       }
     }

@@ -12,6 +12,7 @@
 //                          Gauss-Seidel sweep (a7+a8+a11+a4+local a3+a5) resident in LDS
 #pragma once
 #include "rl_device.hpp"
+#include "rl_crmath.hpp"
 
 
 namespace rl {
@@ -44,6 +45,117 @@ __global__ void k_build_tables(const double* __restrict__ t, int nt, const doubl
   base[(size_t)N + i] = y;
   base[(size_t)2 * N + i] = -dy * inv;  // unit left normal = (cos, sin)(yaw + pi/2)
   base[(size_t)3 * N + i] = dx * inv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// REFERENCE-ORDER ARITHMETIC (RL_ARITH_REFERENCE).  The fast kernels evaluate the curve with
+// fma from tables that were themselves built with fma, take the normal from a reciprocal square root and add the cost
+// sums in a tree: every one of these is a legal rounding of the reference's arithmetic, but not the reference's.  On
+// ill-conditioned instances that is enough to end on another of the discrete lines the reference's own formulation
+// allows.  The reference-order mode restates, operation by operation and in numpy's order, what
+// the reference computes -- which is what oracle/mincurv_oracle.c restates too, so the two can be compared bit for bit:
+//   * basis values by scipy's de Boor recurrences, unfused (the strict table set below);
+//   * x, y, x', y' as sequential unfused sums  s += c[l-k+a] * B_a(u)  (BSpline.__call__);
+//   * the cost's x', y', x'', y'' through the DERIVATIVE SPLINES the reference builds (optimizer.py:33-36:
+//     splder coefficients (c[j+1]-c[j]) * k / (t[j+k+1]-t[j+1]), evaluated at degree k-1 / k-2);
+//   * yaw = atan2(y', x'), the normals max_dist * (cos, sin)(yaw +- pi/2): correctly rounded (rl_crmath.hpp);
+//   * ring crossings with unfused cross products, bound points L = p + s d stored (not re-derived);
+//   * the six cost sums accumulated sample by sample in index order; rows, quotients and the clamp unfused.
+// Strict table rows, [kStrictRows<K>][N]:  D0 (K+1 basis values) | D1 (first derivatives) | D2 (second derivatives) |
+// E1 (the K values of degree K-1: the basis of the first-derivative spline) | E2 (K-1 values of degree K-2).
+template <int K> struct StrictRows {
+  static constexpr int D0 = 0, D1 = K + 1, D2 = 2 * (K + 1), E1 = 3 * (K + 1), E2 = 3 * (K + 1) + K, total = 5 * K + 2;
+};
+
+// s = 0; s += c[a] * tab[a][i], a = 0 .. CNT-1: BSpline evaluation order, no contraction
+template <int CNT, typename CPtr>
+__device__ __forceinline__ double seq_dot(CPtr c, const double* __restrict__ tab, int N, int i) {
+#pragma clang fp contract(off)
+  double s = 0.0;
+#pragma unroll
+  for (int a = 0; a < CNT; ++a) s += c[a] * tab[(size_t)a * N + i];
+  return s;
+}
+__device__ __forceinline__ double uf_madd(double p, double w, double c) {   // p + w * c, two roundings
+#pragma clang fp contract(off)
+  return p + w * c;
+}
+__device__ __forceinline__ double uf_msub(double p, double w, double c) {   // p - w * c, two roundings
+#pragma clang fp contract(off)
+  return p - w * c;
+}
+
+template <int K>
+__global__ void k_build_tables_strict(const double* __restrict__ t, int nt, const double* __restrict__ c0, int N,
+                                      double* __restrict__ Ds, double* __restrict__ base_s) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  using R = StrictRows<K>;
+  const int n = nt - K - 1;
+  const double u = (double)i * (1.0 / (double)N);
+  const int l = find_interval(t, K, n, u);
+  double h[K + 1], hh[K + 1], snap1[K + 1], snap2[K + 1];
+  auto value_step = [&](int j) {      // scipy _deBoor_D, value recurrence (oracle: deboor_d)
+    for (int q = 0; q < j; ++q) hh[q] = h[q];
+    h[0] = 0.0;
+    for (int m = 1; m <= j; ++m) {
+      const double xb = t[l + m], xa = t[l + m - j];
+      if (xb == xa) { h[m] = 0.0; continue; }
+      const double w = hh[m - 1] / (xb - xa);
+      h[m - 1] += w * (xb - u);
+      h[m] = w * (u - xa);
+    }
+  };
+  auto deriv_step = [&](int j, int mder) {   // derivative recurrence
+    for (int q = 0; q < j; ++q) hh[q] = h[q];
+    h[0] = 0.0;
+    for (int m = 1; m <= j; ++m) {
+      const double xb = t[l + m], xa = t[l + m - j];
+      if (xb == xa) { h[mder] = 0.0; continue; }
+      const double w = (double)j * hh[m - 1] / (xb - xa);
+      h[m - 1] -= w;
+      h[m] = w;
+    }
+  };
+  h[0] = 1.0;
+  for (int j = 1; j <= K; ++j) {
+    if (j == K - 1) for (int q = 0; q < K - 1; ++q) snap2[q] = h[q];   // after K-2 steps: degree K-2
+    if (j == K) for (int q = 0; q < K; ++q) snap1[q] = h[q];           // after K-1 steps: degree K-1
+    value_step(j);
+  }
+  if (K == 1) snap2[0] = 1.0;
+  for (int a = 0; a <= K; ++a) Ds[(size_t)(R::D0 + a) * N + i] = h[a];
+  for (int a = 0; a < K; ++a) Ds[(size_t)(R::E1 + a) * N + i] = snap1[a];
+  for (int a = 0; a < K - 1; ++a) Ds[(size_t)(R::E2 + a) * N + i] = snap2[a];
+  double p0x = 0.0, p0y = 0.0;
+  for (int a = 0; a <= K; ++a) { p0x += c0[l - K + a] * h[a]; p0y += c0[n + l - K + a] * h[a]; }
+  // first derivative: K-1 value steps, one derivative step
+  for (int q = 0; q < K; ++q) h[q] = snap1[q];
+  deriv_step(K, 1);
+  for (int a = 0; a <= K; ++a) Ds[(size_t)(R::D1 + a) * N + i] = h[a];
+  double dx = 0.0, dy = 0.0;
+  for (int a = 0; a <= K; ++a) { dx += c0[l - K + a] * h[a]; dy += c0[n + l - K + a] * h[a]; }
+  // second derivative: K-2 value steps, two derivative steps
+  for (int q = 0; q < K - 1; ++q) h[q] = snap2[q];
+  deriv_step(K - 1, 2);
+  deriv_step(K, 2);
+  for (int a = 0; a <= K; ++a) Ds[(size_t)(R::D2 + a) * N + i] = h[a];
+  // initial line and its two normal directions: the width-form rings are p0 + w (cos, sin)(yaw0 +- pi/2)
+  const cr::Heading hd = cr::heading(dx, dy);
+  base_s[i] = p0x; base_s[(size_t)N + i] = p0y;
+  base_s[(size_t)2 * N + i] = hd.cl; base_s[(size_t)3 * N + i] = hd.sl;
+  base_s[(size_t)4 * N + i] = hd.cr; base_s[(size_t)5 * N + i] = hd.sr;
+}
+
+// test aid: the five outputs of cr::heading for n tangent vectors (tests compare with the oracle's libquadmath build)
+__global__ void k_debug_cr_heading(const double* __restrict__ dx, const double* __restrict__ dy, int n,
+                                   double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const cr::Heading h = cr::heading(dx[i], dy[i]);
+  out[5 * (size_t)i] = h.yaw; out[5 * (size_t)i + 1] = h.cl; out[5 * (size_t)i + 2] = h.sl;
+  out[5 * (size_t)i + 3] = h.cr; out[5 * (size_t)i + 4] = h.sr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,15 +440,23 @@ struct SweepArgs {
 // LDS carve (doubles).  cpad = n rounded up to even so every later array is 16-byte aligned.
 struct SweepLds {
   int cpad, nLp, nRp, ncL, ncR;
-  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, off_joint, off_stage, total;
+  size_t off_cx, off_cy, off_red, off_sL, off_sR, off_rL, off_rR, off_cL, off_cR, off_pL, off_pR, off_hint, off_joint, off_stage,
+         off_c12, off_terms, total;
 };
 constexpr int kSweepWaves = 4;   // waves of the 256-thread sweep workgroup (the staged stretches are per wave)
+// reference-order mode: the six cost terms of up to kTermChunk samples wait in LDS for their sequential summation
+// (6 x 256 doubles = 12 KB: inside the staged stretches' 13.8 KB, which are idle between two refreshes), and the
+// window of derivative-spline coefficients the next step needs (2 coordinates x (2k + 2k-1) values)
+constexpr int kTermChunk = 256;
+constexpr int kC12Doubles = 4 * (2 * kMaxK) + 8;
 
 // joint: the sliding-window instantiation (its QP scratch and per-sample flags are carved only then).  With the rings in
 // global memory every wave gets two staged stretches (left / right ring, rl_device.hpp: kStage vertices each): at N = 2000
 // the workgroup then takes 39.5 KB -- four of them still fit a CU's 160 KB, which is what the batch size asks for.
+// strict: the reference-order mode keeps the bound POINTS (double2 per sample and side) where the fast mode keeps the
+// crossing parameters (one double each).
 __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int nR, bool rings_in_lds, bool sigma_in_lds,
-                                                     bool joint = false) {
+                                                     bool joint = false, bool strict = false) {
   SweepLds L;
   L.cpad = (n + 1) & ~1;
   L.nLp = nL; L.nRp = nR;
@@ -352,17 +472,23 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   L.off_pR = o; o += (size_t)((L.ncR + 1) & ~1);
   L.off_joint = o; o += joint ? 128 + (size_t)((N + 15) / 16) * 2 : 0;  // joint variant: QP scratch + 1 byte per sample
   L.off_hint = o; o += (size_t)(((size_t)2 * ((N + 3) & ~3) * sizeof(unsigned short) + 15) / 16) * 2;  // u16 [2][Npad]
+  L.off_c12 = o; o += strict ? kC12Doubles : 0;
   L.off_sL = L.off_sR = L.off_rL = L.off_rR = 0;
   if (sigma_in_lds) {
-    L.off_sL = o; o += (size_t)((N + 1) & ~1);
-    L.off_sR = o; o += (size_t)((N + 1) & ~1);
+    const size_t per = (size_t)((N + 1) & ~1) * (strict ? 2 : 1);
+    L.off_sL = o; o += per;
+    L.off_sR = o; o += per;
   }
   L.off_stage = 0;
+  L.off_terms = 0;
   if (rings_in_lds) {
     L.off_rL = o; o += (size_t)2 * (nL + kRingPad);
     L.off_rR = o; o += (size_t)2 * (nR + kRingPad);
+    if (strict) { L.off_terms = o; o += (size_t)6 * kTermChunk; }
   } else {
     L.off_stage = o; o += (size_t)kSweepWaves * 2 * kStageSlots * 2;   // [wave][ring][kStageSlots] double2
+    L.off_terms = L.off_stage;                                         // strict: the terms use the idle stretches
+    static_assert((size_t)kSweepWaves * 2 * kStageSlots * 2 >= (size_t)6 * kTermChunk, "the cost terms fit the staged stretches");
   }
   L.total = o;
   return L;
@@ -374,8 +500,9 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
 //   11,12 the new control point (when accepted)
 constexpr int kSweepDumpHead = 16;
 
-template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false, bool SIGMA_LDS = RINGS_LDS>
+template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false, bool SIGMA_LDS = RINGS_LDS, bool STRICT = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS && !JOINT)) ? 4 : 1) void k_sweep(SweepArgs a) {
+  static_assert(!STRICT || (!JOINT && !DUMP && BLOCK == 256 && SIGMA_LDS == RINGS_LDS), "reference-order mode: the 256-thread sweep, all-LDS or all-global residency");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
   const TrackDev& tr = a.tr;
@@ -384,7 +511,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   const int tid = threadIdx.x;
   const int lane = tid % kWave, wave = tid / kWave;
   constexpr int NW = BLOCK / kWave;
-  const SweepLds L = sweep_lds_layout(n, N, a.nL, a.nR, RINGS_LDS, SIGMA_LDS, JOINT);
+  const SweepLds L = sweep_lds_layout(n, N, a.nL, a.nR, RINGS_LDS, SIGMA_LDS, JOINT, STRICT);
   // staged windows: rings in global memory, four waves (the eight-wave ablation variant keeps the direct loads)
   constexpr bool STAGED = !RINGS_LDS && BLOCK == 64 * kSweepWaves;
   double2* stgL = reinterpret_cast<double2*>(smem + L.off_stage) + (STAGED ? wave * 2 * kStageSlots : 0);
@@ -403,18 +530,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
     // three residencies of the per-instance state: crossings sL/sR and ring vertices each either in LDS or
     // in the instance's global scratch (rl_mincurv.hip: plan_sweep)
     double* g = a.gscratch + (size_t)b * a.gscratch_stride;
+    const size_t per_side = (size_t)((N + 1) & ~1) * (STRICT ? 2 : 1);   // reference-order mode: bound POINTS (double2)
     if (SIGMA_LDS) { sL = smem + L.off_sL; sR = smem + L.off_sR; }
-    else { sL = g; sR = sL + ((N + 1) & ~1); g = sR + ((N + 1) & ~1); }
+    else { sL = g; sR = sL + per_side; g = sR + per_side; }
     if (RINGS_LDS) {
       rL = reinterpret_cast<double2*>(smem + L.off_rL);
       rR = reinterpret_cast<double2*>(smem + L.off_rR);
     } else {
-      if (RL_ABLATE(a, 8)) g = a.gscratch + (SIGMA_LDS ? 0 : (size_t)2 * ((N + 1) & ~1));   // timing only: every instance reads instance 0's rings (L2-hot)
+      if (RL_ABLATE(a, 8)) g = a.gscratch + (SIGMA_LDS ? 0 : 2 * per_side);   // timing only: every instance reads instance 0's rings (L2-hot)
       rL = reinterpret_cast<double2*>(g);
       rR = rL + a.nL + kRingPad;
     }
   }
   const int nL = a.nL, nR = a.nR;
+  double2* bL = reinterpret_cast<double2*>(sL);   // reference-order mode: the bound points themselves (LBX, LBY), (RBX, RBY)
+  double2* bR = reinterpret_cast<double2*>(sR);
+  const double* __restrict__ Ds = tr.Ds;
+  using SR = StrictRows<K>;
 
   // ---- prologue: control points, ring vertices, chunk circles
   for (int j = tid; j < n; j += BLOCK) { cx[j] = tr.c0[j]; cy[j] = tr.c0[n + j]; }
@@ -422,10 +554,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
     const double2* w = reinterpret_cast<const double2*>(a.in) + (size_t)b * N;
     for (int i = tid; i < N; i += BLOCK) {
       const double2 wi = w[i];
-      const double px = tr.base[i], py = tr.base[(size_t)N + i];
-      const double nx = tr.base[(size_t)2 * N + i], ny = tr.base[(size_t)3 * N + i];
-      rL[i] = make_double2(px + wi.x * nx, py + wi.x * ny);
-      rR[i] = make_double2(px - wi.y * nx, py - wi.y * ny);
+      if constexpr (STRICT) {   // oracle: orc_width_rings -- p0 + w cos / sin(yaw0 +- pi/2), each normal on its own
+        const double* bs = tr.base_s;
+        const double px = bs[i], py = bs[(size_t)N + i];
+        rL[i] = make_double2(uf_madd(px, wi.x, bs[(size_t)2 * N + i]), uf_madd(py, wi.x, bs[(size_t)3 * N + i]));
+        rR[i] = make_double2(uf_madd(px, wi.y, bs[(size_t)4 * N + i]), uf_madd(py, wi.y, bs[(size_t)5 * N + i]));
+      } else {
+        const double px = tr.base[i], py = tr.base[(size_t)N + i];
+        const double nx = tr.base[(size_t)2 * N + i], ny = tr.base[(size_t)3 * N + i];
+        rL[i] = make_double2(px + wi.x * nx, py + wi.x * ny);
+        rR[i] = make_double2(px - wi.y * nx, py - wi.y * ny);
+      }
     }
   } else if (a.form == 2) {  // bound points
     const double4* w = reinterpret_cast<const double4*>(a.in) + (size_t)b * N;
@@ -519,6 +658,59 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   // l_first: the knot interval of sample i0 + tid if the caller has it already (the cost pass of the same step), else -1
   auto refresh = [&](int i0, int i1, int j0, int j1, int mode, int l_first = -1) {
     const int m0 = i1 - i0, m1 = j1 - j0, m = m0 + m1;
+    if constexpr (STRICT) {
+      // reference-order mode: sample_along (trajectory.py:278-280) + fill_bounds (:83-141) of the samples that moved,
+      // operation by operation (oracle: sample_geometry, closest_hit)
+      auto point = [&](int i, double& px, double& py, cr::Heading& hd) {
+        const int l = tr.ell[i];
+        px = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+        py = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+        const double tx = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D1 * N, N, i);
+        const double ty = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D1 * N, N, i);
+        hd = cr::heading(tx, ty);
+      };
+      if (mode == 2) {
+        const int nwt = (m + kWave - 1) / kWave;
+        for (int wt = wave; wt < nwt; wt += NW) {
+          const int r = wt * kWave + lane;
+          const bool active = r < m;
+          const int i = active ? (r < m0 ? i0 + r : j0 + (r - m0)) : (m0 > 0 ? i0 : j0);
+          double px, py; cr::Heading hd;
+          point(i, px, py, hd);
+          const double dLx = a.max_dist * hd.cl, dLy = a.max_dist * hd.sl;   // trajectory.py:87-88, norm = +pi/2
+          const double dRx = a.max_dist * hd.cr, dRy = a.max_dist * hd.sr;   //                      norm = -pi/2
+          const Hit hl = search_ring_windowed<STAGED, true>(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], px, py,
+                                                            dLx, dLy, a.max_dist, false, nullptr, stgL);
+          const Hit hr = search_ring_windowed<STAGED, true>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], px, py,
+                                                            dRx, dRy, a.max_dist, false, nullptr, stgR);
+          if (active) {   // no crossing: best_s = 0, the waypoint itself (trajectory.py:127)
+            bL[i] = make_double2(uf_madd(px, hl.best_s, dLx), uf_madd(py, hl.best_s, dLy));
+            bR[i] = make_double2(uf_madd(px, hr.best_s, dRx), uf_madd(py, hr.best_s, dRy));
+            hints[i] = (unsigned short)(hl.edge == kNoEdge ? 0xFFFF : hl.edge);
+            hints[Npad + i] = (unsigned short)(hr.edge == kNoEdge ? 0xFFFF : hr.edge);
+          }
+        }
+        return;
+      }
+      for (int task = tid; task < 2 * m; task += BLOCK) {
+        const int side = task >= m;
+        const int r = side ? task - m : task;
+        const int i = r < m0 ? i0 + r : j0 + (r - m0);
+        double px, py; cr::Heading hd;
+        point(i, px, py, hd);
+        const double dx = a.max_dist * (side ? hd.cr : hd.cl), dy = a.max_dist * (side ? hd.sr : hd.sl);
+        Hit h;
+        if (mode == 1) {
+          h = side ? search_ring_culled<true>(rR, nR, circR, L.ncR, px, py, dx, dy, a.max_dist)
+                   : search_ring_culled<true>(rL, nL, circL, L.ncL, px, py, dx, dy, a.max_dist);
+        } else {
+          h = side ? search_ring_brute<true>(rR, nR, px, py, dx, dy) : search_ring_brute<true>(rL, nL, px, py, dx, dy);
+        }
+        (side ? bR : bL)[i] = make_double2(uf_madd(px, h.best_s, dx), uf_madd(py, h.best_s, dy));
+        hints[side * Npad + i] = (unsigned short)(h.edge == kNoEdge ? 0xFFFF : h.edge);
+      }
+      return;
+    }
     if (mode == 2) {
       // windowed, wave-cooperative search: a wave takes 64 consecutive samples and intersects
       // their normals with the left ring, then with the right ring (one curve evaluation for both)
@@ -649,6 +841,172 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   const double* __restrict__ D2 = tr.D + (size_t)2 * (K + 1) * N;
   int n_skipped = 0;
 
+  if constexpr (STRICT) {
+    // ---- reference-order mode of run_min_curvature_qp (optimizer.py:256-341): the same three phases per step, with the
+    // reference's operations in the reference's order (see the note above StrictRows)
+    double* c12 = smem + L.off_c12;      // derivative-spline coefficients around the NEXT control point: c1x | c1y | c2x | c2y, 2K each
+    double* terms = smem + L.off_terms;  // [6][kTermChunk] cost terms of the current chunk of support samples
+    const int steps = i_max - i_min;
+    const int total_steps = a.max_iter * 2 * steps;
+    auto step_index = [&](int q) {       // optimizer.py:303-324
+      const int it = q / (2 * steps), pass = (q / steps) & 1, stp = q % steps;
+      const int i_loop = pass == 0 ? stp : steps - stp;
+      int idx = i_loop + a.i_start[it];
+      if (idx >= i_max) idx = idx - i_max + i_min;
+      return idx;
+    };
+    // splder (scipy BSpline.derivative; oracle: orc_bspline_derivative): c1[j] = (c[j+1] - c[j]) * k / (t[j+k+1] - t[j+1]),
+    // c2[j] = (c1[j+1] - c1[j]) * (k-1) / (t[j+k+1] - t[j+2]), for j = idx-K .. idx+K-1: what the support of idx reads
+    auto deriv_window = [&](int idx) {   // wave 0
+      const int q = lane & 31;
+      const double* cc = lane < 32 ? cx : cy;
+      const int j = idx - K + q;
+      double c1 = 0.0, c2 = 0.0;
+      if (q < 2 * K && j >= 0 && j + 1 <= n - 1) {
+#pragma clang fp contract(off)
+        c1 = (cc[j + 1] - cc[j]) * (double)K / (tr.t[j + K + 1] - tr.t[j + 1]);
+      }
+      const double c1n = __shfl_down(c1, 1, kWave);
+      if (q < 2 * K - 1 && j >= 0 && j + 2 <= n - 1) {
+#pragma clang fp contract(off)
+        c2 = (c1n - c1) * (double)(K - 1) / (tr.t[j + K + 1] - tr.t[j + 2]);
+      }
+      if (q < 2 * K) { c12[(lane < 32 ? 0 : 2 * K) + q] = c1; c12[4 * K + (lane < 32 ? 0 : 2 * K) + q] = c2; }
+    };
+    if (wave == 0 && total_steps > 0) deriv_window(step_index(0));
+    __syncthreads();
+    int ok_count = 0;
+    for (int q = 0; q < total_steps; ++q) {
+      const int it = q / (2 * steps), pass = (q / steps) & 1;
+      const int idx = step_index(q);
+      const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+      const int M = s1 - s0;
+      const double zx = cx[idx], zy = cy[idx];
+      // ---- phase 1: per support sample the six cost terms (optimizer.py:66-85) and the clamp interval of its rows (:231-253)
+      double lox = -INFINITY, hix = INFINITY, loy = -INFINITY, hiy = INFINITY;
+      bool bad = false;
+      double sacc = 0.0;   // lanes 0..5 of wave 0: the running sums, in sample order
+      const int nchunks = (M + kTermChunk - 1) / kTermChunk;
+      for (int ch = 0; ch < nchunks; ++ch) {
+        const int i = s0 + ch * kTermChunk + tid;
+        if (i < s1) {
+#pragma clang fp contract(off)
+          const int l = tr.ell[i];
+          const double x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+          const double y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+          const int wofs = l - idx;       // c1[l-K+a] sits at window offset (l-K+a) - (idx-K)
+          const double dTx = seq_dot<K>(c12 + wofs, Ds + (size_t)SR::E1 * N, N, i);
+          const double dTy = seq_dot<K>(c12 + 2 * K + wofs, Ds + (size_t)SR::E1 * N, N, i);
+          const double d2Tx = seq_dot<K - 1>(c12 + 4 * K + wofs, Ds + (size_t)SR::E2 * N, N, i);
+          const double d2Ty = seq_dot<K - 1>(c12 + 6 * K + wofs, Ds + (size_t)SR::E2 * N, N, i);
+          const int aa = idx - l + K;
+          const double B2 = Ds[(size_t)(SR::D2 + aa) * N + i];
+          const double B0 = Ds[(size_t)(SR::D0 + aa) * N + i];
+          const double Fx = d2Tx - B2 * zx, Fy = d2Ty - B2 * zy;
+          const double s2 = dTx * dTx + dTy * dTy;
+          const double denom = s2 * s2 * s2;
+          const double Pxx = (dTy * dTy) / denom;
+          const double Pxy = (-2.0 * dTx * dTy) / denom;
+          const double Pyy = (dTx * dTx) / denom;
+          double* tp = terms + tid;
+          tp[0] = B2 * Pxx * B2;
+          tp[kTermChunk] = B2 * Pyy * B2;
+          tp[2 * kTermChunk] = Fx * Pxx * B2;
+          tp[3 * kTermChunk] = Fy * Pxy * B2;
+          tp[4 * kTermChunk] = Fy * Pyy * B2;
+          tp[5 * kTermChunk] = B2 * Pxy * Fx;
+          // rows (optimizer.py:235-248): non_z = p - b z_old, lba = min(L, R) - non_z, uba = max(L, R) - non_z
+          const double2 Lp = bL[i], Rp = bR[i];
+          const double nzx = x - B0 * zx, nzy = y - B0 * zy;
+          const double lbx = fmin(Lp.x, Rp.x) - nzx, ubx = fmax(Lp.x, Rp.x) - nzx;
+          const double lby = fmin(Lp.y, Rp.y) - nzy, uby = fmax(Lp.y, Rp.y) - nzy;
+          if (B0 > 0.0) {
+            lox = fmax(lox, lbx / B0); hix = fmin(hix, ubx / B0);
+            loy = fmax(loy, lby / B0); hiy = fmin(hiy, uby / B0);
+          } else {
+            if (lbx > 0.0 || ubx < 0.0 || lby > 0.0 || uby < 0.0) bad = true;
+          }
+          if (!(lbx == lbx) || !(ubx == ubx) || !(lby == lby) || !(uby == uby)) bad = true;
+        }
+        if (ch == nchunks - 1) {
+          const double v4 = wave_max(lox), v5 = wave_min(hix), v6 = wave_max(loy), v7 = wave_min(hiy);
+          const bool wbad = __any(bad);
+          if (lane == 0) { double* r = red + wave * 12; r[4] = v4; r[5] = v5; r[6] = v6; r[7] = v7; r[8] = wbad ? 1.0 : 0.0; }
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 6) {      // hxx += ..., in index order (oracle: orc_min_curvature_cost)
+          const int cnt = min(kTermChunk, M - ch * kTermChunk);
+          const double* tp = terms + lane * kTermChunk;
+          int j = 0;
+          for (; j + 8 <= cnt; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = tp[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc += v[u];
+          }
+          for (; j < cnt; ++j) sacc += tp[j];
+        }
+        if (ch + 1 < nchunks) __syncthreads();
+      }
+      // ---- phase 2 (wave 0): the 2-variable QP in closed form (oracle: orc_qp_solve_separable), control point + wrap,
+      // then the derivative-spline window of the next step
+      if (wave == 0) {
+        auto lane_val = [&](int src) {
+          return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), src),
+                                  __builtin_amdgcn_readlane(__double2loint(sacc), src));
+        };
+        const double t0 = lane_val(0), t1 = lane_val(1), t2 = lane_val(2), t3 = lane_val(3), t4 = lane_val(4), t5 = lane_val(5);
+        double s4 = red[4], s5 = red[5], s6 = red[6], s7 = red[7], s8 = red[8];
+        for (int w = 1; w < NW; ++w) {
+          s4 = fmax(s4, red[w * 12 + 4]); s5 = fmin(s5, red[w * 12 + 5]);
+          s6 = fmax(s6, red[w * 12 + 6]); s7 = fmin(s7, red[w * 12 + 7]);
+          s8 = fmax(s8, red[w * 12 + 8]);
+        }
+        const double H0 = 2.0 * t0, H1 = 2.0 * t1;                 // optimizer.py:83
+        const double g0 = t2 + t2, g1 = (t3 + t4) + (t5 + t4);     // optimizer.py:85
+        const bool okw = (s8 == 0.0) && (H0 > 0.0) && (H1 > 0.0) && isfinite(H0) && isfinite(H1) &&
+                         isfinite(g0) && isfinite(g1) && (s4 <= s5) && (s6 <= s7);
+        if (tid == 0) {
+          if (okw) {
+            double nzx = -g0 / H0, nzy = -g1 / H1;
+            nzx = fmin(fmax(nzx, s4), s5);
+            nzy = fmin(fmax(nzy, s6), s7);
+            cx[idx] = nzx;         cy[idx] = nzy;          // optimizer.py:280-285
+            cx[0] = cx[n - 5];     cy[0] = cy[n - 5];
+            cx[1] = cx[n - 4];     cy[1] = cy[n - 4];
+            cx[n - 3] = cx[2];     cy[n - 3] = cy[2];
+            cx[n - 2] = cx[3];     cy[n - 2] = cy[3];
+            cx[n - 1] = cx[4];     cy[n - 1] = cy[4];
+          }
+          red[NW * 12] = okw ? 1.0 : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (q + 1 < total_steps) deriv_window(step_index(q + 1));
+      }
+      __syncthreads();
+      const bool ok = red[NW * 12] != 0.0;
+      if (ok) {
+        // ---- phase 3: re-sample and re-intersect what moved (the supports of idx and of its periodic alias)
+        int alias = -1;
+        if (idx <= 4 && idx >= 2) alias = idx + (n - 5);
+        else if (idx >= n - 5 && idx <= n - 4) alias = idx - (n - 5);
+        int j0 = 0, j1 = 0;
+        if (alias >= 0) { j0 = tr.sup[2 * alias]; j1 = tr.sup[2 * alias + 1]; }
+        if (K != 5) refresh(0, N, 0, 0, mode); else refresh(s0, s1, j0, j1, mode);
+        __syncthreads();
+        ++ok_count;
+      } else {
+        ++n_skipped;
+      }
+      if ((q + 1) % steps == 0) {
+        if (tid == 0 && a.n_success) a.n_success[(size_t)b * 2 * a.max_iter + 2 * it + pass] = ok_count;
+        ok_count = 0;
+      }
+    }
+  } else
   if (JOINT) {
     // ---- TrajectoryOptimizer.run_joint_min_curvature_qp (optimizer.py:163-220), span 5
     constexpr int SP = 5;
@@ -1101,6 +1459,28 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   for (int j = tid; j < n; j += BLOCK) {
     reinterpret_cast<double2*>(a.out_ctrl)[(size_t)b * n + j] = make_double2(cx[j], cy[j]);
   }
+  if constexpr (STRICT) {
+    for (int i = tid; i < N; i += BLOCK) {
+#pragma clang fp contract(off)
+      const int l = tr.ell[i];
+      const double x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+      const double y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+      if (a.out_xy) reinterpret_cast<double2*>(a.out_xy)[(size_t)b * N + i] = make_double2(x, y);
+      if (a.out_points) {   // trajectory.py:278-281 (oracle: sample_geometry) + the bound columns
+        const double dx = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D1 * N, N, i);
+        const double dy = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D1 * N, N, i);
+        const double d2x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D2 * N, N, i);
+        const double d2y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D2 * N, N, i);
+        double* p = a.out_points + ((size_t)b * N + i) * 19;
+        p[0] = x; p[1] = y; p[3] = cr::heading(dx, dy).yaw;
+        const double s2 = dx * dx + dy * dy;
+        const double curvature = fabs(dx * d2y - dy * d2x) / sqrt(s2 * s2 * s2);
+        p[5] = 1.0 / fabs(curvature);
+        const double2 Lp = bL[i], Rp = bR[i];
+        p[9] = Lp.x; p[10] = Lp.y; p[11] = Rp.x; p[12] = Rp.y;
+      }
+    }
+  } else
   for (int i = tid; i < N; i += BLOCK) {
     const int l = tr.ell[i];
     if (a.out_points) {

@@ -72,6 +72,7 @@ struct rl_ctx {
   int max_lds = 65536;
   int num_cu = 0;
   bool force_global_v1 = false;  // test hook: RL_GLOBAL_V1=1 keeps the generic kernel
+  int arith = RL_ARITH_FAST;     // rl_ctx_set_arith: arithmetic of the sweep (RL_ARITH_FAST / RL_ARITH_REFERENCE)
   // Device scratch owned by the context (grow-only): the *_dev entry points of the QSS simulator and the
   // min-time solve carve their work arrays out of it, so that steady-state calls allocate nothing.
   void* arena = nullptr;
@@ -206,6 +207,10 @@ struct rl_track {
   std::vector<double> t_host;
   DevBuf<double> t, c0, D, base;
   DevBuf<int> ell, sup;
+  // reference-order mode (RL_ARITH_REFERENCE): unfused de Boor tables and the initial line with its two normal
+  // directions, built by the first solve that asks for them, rebuilt when the control points change
+  mutable DevBuf<double> Ds, base_s;
+  mutable bool strict_valid = false;
   DevBuf<double> ringL, ringR;  // shared rings as (x,y) pairs
   int nL = 0, nR = 0;
   double length = 0.0;          // BSplineTrajectory._length of the INITIAL spline (rl_track_set_length); 0 = not given
@@ -223,6 +228,7 @@ struct rl_track {
     rl::TrackDev d;
     d.k = k; d.n = n; d.nt = nt; d.N = N;
     d.t = t.p; d.c0 = c0.p; d.ell = ell.p; d.D = D.p; d.sup = sup.p; d.base = base.p;
+    d.Ds = Ds.p; d.base_s = base_s.p;
     return d;
   }
 };
@@ -254,7 +260,7 @@ struct SweepPlan {
   int block;
 };
 
-SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, bool joint = false) {
+SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, bool joint = false, bool strict = false) {
   SweepPlan p;
   p.block = 256;
   // Residency of the per-instance state (ring vertices 16 B x (nL + nR), crossings 8 B x 2N):
@@ -269,7 +275,8 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, boo
   int want = B >= 2 * ctx->num_cu ? 0 : 1;    // 0 all global, 1 all LDS, 2 crossings in LDS
   if (force && (force[0] == '0' || force[0] == '1')) want = force[0] == '1' ? 0 : 1;
   if (const char* r = getenv("RL_FORCE_RESIDENCY")) if (r[0] >= '0' && r[0] <= '2') want = r[0] - '0';
-  rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true, true, joint);
+  if (strict && want == 2) want = 0;   // the reference-order mode exists all-LDS and all-global
+  rl::SweepLds in = rl::sweep_lds_layout(n, N, nL, nR, true, true, joint, strict);
   if (want == 1 && in.total * sizeof(double) > (size_t)ctx->max_lds) want = 0;
   if (want == 2) {
     rl::SweepLds mid = rl::sweep_lds_layout(n, N, nL, nR, false, true, joint);
@@ -277,16 +284,17 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, boo
   }
   p.rings_in_lds = want == 1;
   p.sigma_in_lds = want != 0;
-  rl::SweepLds L = rl::sweep_lds_layout(n, N, nL, nR, p.rings_in_lds, p.sigma_in_lds, joint);
+  rl::SweepLds L = rl::sweep_lds_layout(n, N, nL, nR, p.rings_in_lds, p.sigma_in_lds, joint, strict);
   p.lds_bytes = L.total * sizeof(double);
-  p.gscratch_doubles = (p.sigma_in_lds ? 0 : (size_t)2 * ((N + 1) & ~1)) +
+  // crossings (fast mode: one double per sample and side) or bound points (reference-order mode: two)
+  p.gscratch_doubles = (p.sigma_in_lds ? 0 : (size_t)2 * ((N + 1) & ~1) * (strict ? 2 : 1)) +
                        (p.rings_in_lds ? 0 : (size_t)2 * (nL + rl::kRingPad) + (size_t)2 * (nR + rl::kRingPad));
   return p;
 }
 
-template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL>
+template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL, bool STRICT = false>
 int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
-  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL>;
+  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL, STRICT>;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
@@ -294,7 +302,12 @@ int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
   return RL_OK;
 }
 
-int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false) {
+int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false, bool strict = false) {
+  if (strict) {   // RL_ARITH_REFERENCE: the degree-5 sweep (the reference's wrap is written for k = 5, optimizer.py:281-285)
+    if (joint || k != 5 || a.dbg) return fail(RL_ERR_UNSUPPORTED, "reference-order arithmetic: run_min_curvature_qp on a degree-5 spline, no step dump");
+    return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, false, true, true>(ctx, a, p.lds_bytes)
+                          : launch_sweep_t<5, 256, false, false, false, false, true>(ctx, a, p.lds_bytes);
+  }
   if (joint) {
     if (k != 5) return fail(RL_ERR_UNSUPPORTED, "the sliding-window variant is built for degree 5 (span 5)");
     return p.rings_in_lds ? launch_sweep_t<5, 256, true, true>(ctx, a, p.lds_bytes)
@@ -322,6 +335,21 @@ int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepAr
                           : launch_sweep_t<3, 256, false>(ctx, a, p.lds_bytes);
   }
   return fail(RL_ERR_UNSUPPORTED, "spline degree must be 3 or 5");
+}
+
+// tables of the reference-order mode (rl_kernels.hpp: k_build_tables_strict), built on first use
+int ensure_strict_tables(const rl_ctx* ctx, const rl_track* trk) {
+  if (trk->strict_valid) return RL_OK;
+  const int k = trk->k, N = trk->N;
+  if (k != 5) return fail(RL_ERR_UNSUPPORTED, "reference-order arithmetic: degree-5 splines");
+  if (!trk->Ds.p) RL_HIP(trk->Ds.alloc((size_t)rl::StrictRows<5>::total * N));
+  if (!trk->base_s.p) RL_HIP(trk->base_s.alloc((size_t)6 * N));
+  const dim3 grid((N + 127) / 128), block(128);
+  hipLaunchKernelGGL(rl::k_build_tables_strict<5>, grid, block, 0, ctx->stream, trk->t.p, trk->nt, trk->c0.p, N,
+                     trk->Ds.p, trk->base_s.p);
+  RL_HIP(hipGetLastError());
+  trk->strict_valid = true;
+  return RL_OK;
 }
 
 }  // namespace
@@ -368,6 +396,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
   }
   c->num_cu = prop.multiProcessorCount;
   if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
+  if (const char* v = getenv("RL_ARITH")) c->arith = (v[0] == 'r' || v[0] == '1') ? RL_ARITH_REFERENCE : RL_ARITH_FAST;
   if (const char* v = getenv("RL_MT_HES_SWEEP")) c->mt_hes_sweep = v[0] == '1';
   if (const char* v = getenv("RL_MT_UNFUSED")) c->mt_unfused = v[0] == '1';
   if (const char* v = getenv("RL_MT_KKT4")) c->mt_kkt4 = v[0] == '1';
@@ -403,6 +432,29 @@ void rl_ctx_destroy(rl_ctx* ctx) {
 int rl_ctx_set_stream(rl_ctx* ctx, void* hip_stream) {
   if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
   ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return RL_OK;
+}
+
+int rl_ctx_set_arith(rl_ctx* ctx, int arith) {
+  if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
+  if (arith != RL_ARITH_FAST && arith != RL_ARITH_REFERENCE) return fail(RL_ERR_ARG, "arith must be RL_ARITH_FAST or RL_ARITH_REFERENCE");
+  ctx->arith = arith;
+  return RL_OK;
+}
+
+int rl_ctx_get_arith(const rl_ctx* ctx) { return ctx ? ctx->arith : RL_ERR_ARG; }
+
+int rl_debug_cr_heading(rl_ctx* ctx, const double* dx, const double* dy, int n, double* out) {
+  if (!ctx || !dx || !dy || !out || n <= 0) return fail(RL_ERR_ARG, "bad argument");
+  RL_HIP(hipSetDevice(ctx->device));
+  PoolBuf<double> ddx(ctx), ddy(ctx), dout(ctx);
+  RL_HIP(ddx.alloc(n)); RL_HIP(ddy.alloc(n)); RL_HIP(dout.alloc((size_t)5 * n));
+  RL_HIP(hipMemcpyAsync(ddx.p, dx, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(ddy.p, dy, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(rl::k_debug_cr_heading, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ddx.p, ddy.p, n, dout.p);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipMemcpyAsync(out, dout.p, (size_t)5 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
   return RL_OK;
 }
 
@@ -576,6 +628,7 @@ int rl_track_set_control_points(rl_track* trk, const double* cx0, const double* 
   RL_HIP(hipGetLastError());
   RL_HIP(hipStreamSynchronize(ctx->stream));
   trk->gq_valid = false;
+  trk->strict_valid = false;
   return RL_OK;
 }
 
@@ -677,6 +730,12 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     if (widest > rl::kJointRowsPerThread * 256)
       return fail(RL_ERR_UNSUPPORTED, "sliding-window variant: a window spans more than 768 samples");
   }
+  const bool strict = ctx->arith == RL_ARITH_REFERENCE;
+  if (strict) {
+    if (joint) return fail(RL_ERR_UNSUPPORTED, "reference-order arithmetic (rl_ctx_set_arith) covers run_min_curvature_qp, not the sliding-window driver");
+    RL_HIP(hipSetDevice(ctx->device));
+    if (int rc = ensure_strict_tables(ctx, trk)) return rc;
+  }
   rl::SweepArgs a;
   std::memset(&a, 0, sizeof(a));
   a.tr = trk->dev();
@@ -701,7 +760,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
 #ifdef RL_ABLATION
   if (const char* dbg = getenv("RL_DEBUG_FLAGS")) a.debug = atoi(dbg);
 #endif
-  if (g_dbg_instances > 0 && (joint || k == 5)) {
+  if (g_dbg_instances > 0 && (joint || k == 5) && !strict) {
     const int ninst = std::min(g_dbg_instances, B);
     size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256 + 2 * n)
                         : (size_t)ninst * max_iter * 2 * (size_t)(i_max - i_min) * (rl::kSweepDumpHead + 2 * n);
@@ -720,7 +779,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_points = out_points;
   a.n_success = n_success; a.status = status;
   RL_HIP(hipSetDevice(ctx->device));
-  SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR, B, joint);
+  SweepPlan p = plan_sweep(ctx, n, N, a.nL, a.nR, B, joint, strict);
   if (p.lds_bytes > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "problem does not fit LDS");
   if (p.sigma_in_lds && !p.rings_in_lds && (joint || k != 5 || a.dbg)) {   // the mixed residency exists for the k = 5 sweep only
     p.sigma_in_lds = false;
@@ -737,9 +796,10 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     stats->lds_bytes = (int)p.lds_bytes;
     stats->block_threads = p.block;
     stats->rings_in_lds = p.rings_in_lds ? 1 : (p.sigma_in_lds ? 2 : 0);
+    stats->reserved[0] = strict ? RL_ARITH_REFERENCE : RL_ARITH_FAST;
   }
   if (plan_out) *plan_out = p;
-  return launch_sweep(ctx, k, p, a, joint);
+  return launch_sweep(ctx, k, p, a, joint, strict);
 }
 
 int rl_mincurv_solve_batch_dev(rl_ctx* ctx, const rl_track* trk, int bounds_form, const double* in,

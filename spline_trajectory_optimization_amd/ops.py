@@ -3,6 +3,7 @@
 All arithmetic happens in the HIP kernels of librl_mincurv.so; these functions only marshal
 pointers.  Each wrapper names the reference function it stands in for.
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -80,7 +81,22 @@ def track_constraint(track, points, idx):
     return A, lba[:2 * m].copy(), uba[:2 * m].copy()
 
 
-def mincurv_sweep(track, cx, cy, i_start, want_points=True):
+def _arith_scope(ctx, arith):
+    """arith = None: whatever the context is set to; else _lib.ARITH_FAST / _lib.ARITH_REFERENCE for this call."""
+    return contextlib.nullcontext() if arith is None else ctx.arith(arith)
+
+
+def cr_heading(dx, dy, device=None):
+    """Test aid: [n,5] = yaw, cos / sin(yaw + pi/2), cos / sin(yaw - pi/2) of the tangents (dx, dy) as the
+    reference-order mode computes them on the device (correctly rounded; csrc/rl_crmath.hpp)."""
+    ctx = Context.get(device)
+    dx, xp = as_d(dx); dy, yp = as_d(dy)
+    out = np.zeros((len(dx), 5))
+    check(ctx.lib.rl_debug_cr_heading(ctx.h, xp, yp, len(dx), out.ctypes.data_as(_dp)))
+    return out
+
+
+def mincurv_sweep(track, cx, cy, i_start, want_points=True, arith=None):
     """TrajectoryOptimizer.run_min_curvature_qp for one instance bounded by the track's shared
     rings (optimization/optimizer.py:256-341).  Returns (cx, cy, points|None, n_success, stats)."""
     ctx = track.ctx
@@ -90,10 +106,11 @@ def mincurv_sweep(track, cx, cy, i_start, want_points=True):
     pts = np.zeros((track.N, _lib.NCOL)) if want_points else None
     ns = np.zeros(2 * max_iter, dtype=np.int32)
     st = Stats()
-    check(ctx.lib.rl_mincurv_sweep(ctx.h, track.h, ip, max_iter, cx.ctypes.data_as(_dp),
-                                   cy.ctypes.data_as(_dp),
-                                   pts.ctypes.data_as(_dp) if want_points else None,
-                                   ns.ctypes.data_as(_ip), ctypes.byref(st)))
+    with _arith_scope(ctx, arith):
+        check(ctx.lib.rl_mincurv_sweep(ctx.h, track.h, ip, max_iter, cx.ctypes.data_as(_dp),
+                                       cy.ctypes.data_as(_dp),
+                                       pts.ctypes.data_as(_dp) if want_points else None,
+                                       ns.ctypes.data_as(_ip), ctypes.byref(st)))
     return cx, cy, pts, ns.reshape(max_iter, 2), st
 
 
@@ -114,7 +131,7 @@ def mincurv_sweep_joint(track, cx, cy, i_start, want_points=True):
     return cx, cy, pts, ns, st
 
 
-def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WINDOWED, B=None):
+def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WINDOWED, B=None, arith=None):
     """Batched sweep with host (numpy) buffers.  bounds: widths [B,N,2] / points [B,N,4] / None.
     Returns (ctrl [B,n,2], xy [B,N,2], n_success [B,max_iter,2], status [B], stats)."""
     ctx = track.ctx
@@ -131,14 +148,15 @@ def solve_batch_host(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WIN
     ctrl = np.zeros((B, track.n, 2)); xy = np.zeros((B, track.N, 2))
     ns = np.zeros((B, max_iter, 2), dtype=np.int32); status = np.zeros(B, dtype=np.int32)
     st = Stats()
-    check(ctx.lib.rl_mincurv_solve_batch_host(ctx.h, track.h, int(bounds_form), bp, int(B), ip,
-                                              max_iter, int(search), ctrl.ctypes.data_as(_dp),
-                                              xy.ctypes.data_as(_dp), ns.ctypes.data_as(_ip),
-                                              status.ctypes.data_as(_ip), ctypes.byref(st)))
+    with _arith_scope(ctx, arith):
+        check(ctx.lib.rl_mincurv_solve_batch_host(ctx.h, track.h, int(bounds_form), bp, int(B), ip,
+                                                  max_iter, int(search), ctrl.ctypes.data_as(_dp),
+                                                  xy.ctypes.data_as(_dp), ns.ctypes.data_as(_ip),
+                                                  status.ctypes.data_as(_ip), ctypes.byref(st)))
     return ctrl, xy, ns, status, st
 
 
-def solve_batch_torch(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WINDOWED, out=None):
+def solve_batch_torch(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WINDOWED, out=None, arith=None):
     """Batched sweep on DEVICE tensors (torch is plumbing for memory and streams only).
     bounds: float64 cuda tensor [B,N,2|4].  Enqueues on torch's current stream, no sync.
     Returns dict(ctrl, xy, n_success, status) of cuda tensors."""
@@ -160,11 +178,12 @@ def solve_batch_torch(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WI
         }
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     st = Stats()
-    check(ctx.lib.rl_mincurv_solve_batch_dev(
-        ctx.h, track.h, int(bounds_form), ctypes.c_void_p(bounds.data_ptr()), int(B), ip, max_iter,
-        int(search), ctypes.c_void_p(out["ctrl"].data_ptr()), ctypes.c_void_p(out["xy"].data_ptr()),
-        ctypes.c_void_p(out["n_success"].data_ptr()), ctypes.c_void_p(out["status"].data_ptr()),
-        ctypes.byref(st)))
+    with _arith_scope(ctx, arith):
+        check(ctx.lib.rl_mincurv_solve_batch_dev(
+            ctx.h, track.h, int(bounds_form), ctypes.c_void_p(bounds.data_ptr()), int(B), ip, max_iter,
+            int(search), ctypes.c_void_p(out["ctrl"].data_ptr()), ctypes.c_void_p(out["xy"].data_ptr()),
+            ctypes.c_void_p(out["n_success"].data_ptr()), ctypes.c_void_p(out["status"].data_ptr()),
+            ctypes.byref(st)))
     out["stats"] = st
     return out
 
