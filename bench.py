@@ -112,13 +112,14 @@ def cpu_legs(groups, i_starts, xy_gpu, ninst_total):
     import parity_rule
     per = max(1, ninst_total // len(groups))
     cores = max(1, min(os.cpu_count() or 1, per))
-    t_wall, done, cls = 0.0, 0, []
+    t_wall, done, cls, pos = 0.0, 0, [], []
     for g, ist, xy in zip(groups, i_starts, xy_gpu):
         po = parity_rule.ParityOracle(g["t"], g["cx"], g["cy"], g["k"], g["length"], N_WAYPOINTS, g["widths"][:per], ist,
                                       n_seeds=2, nthreads=cores)
         t_wall += po.t_strict          # the timed leg: the strict oracle only
         done += per
         cls.append(parity_rule.classify(xy[:per], po))
+        pos.append(po)
     c = {k_: np.concatenate([x[k_] for x in cls]) for k_ in cls[0]}
     probe = {}
     for mod in ("casadi", "shapely"):
@@ -142,7 +143,59 @@ def cpu_legs(groups, i_starts, xy_gpu, ninst_total):
     ref_loop = reference_loop_time()
     if ref_loop:
         cb["reference_loop"] = ref_loop
-    return cb
+    return cb, pos
+
+
+def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref_run):
+    """The same batch through the sweep's REFERENCE-ORDER arithmetic (RL_ARITH_REFERENCE, include/rl_mincurv.h): the
+    reference's operations in the reference's order, which returns the oracle's bits.  Timed like the headline (events on
+    the launch stream around each of `steps` launches after a warm-up); compared, on the cpu_baseline sample, with the
+    oracle's build whose atan2 / cos / sin are the correctly rounded ones (bit for bit), with the strict oracle on the
+    platform libm (the headline leg's comparison) and with the reference's own runs of instances 0 and 3 (fixture G7b)."""
+    from oracle import oracle as orc
+    from spline_trajectory_optimization_amd import _lib, ops
+    out = ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search, arith=_lib.ARITH_REFERENCE)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search, out=out,
+                              arith=_lib.ARITH_REFERENCE)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    B = g["widths"].shape[0]
+    xy = out["xy"].cpu().numpy(); ctrl = out["ctrl"].cpu().numpy(); ns = out["n_success"].cpu().numpy()
+    leg = {"what": "the headline batch in RL_ARITH_REFERENCE: unfused de Boor recurrences and sums, splder derivative splines in the "
+                   "cost, sequential cost sums, unfused cross products, correctly rounded atan2 / cos / sin (csrc/rl_crmath.hpp)",
+           "kernel": "k_sweep<..., STRICT>", "kernel_ms": ms, "solves_per_s": B / ms * 1e3, "steps": args.steps,
+           "cost_vs_fast": ms / fast_kernel_ms,
+           "default": "fast (the reference-order mode costs more than 10 %): rl_ctx_set_arith(ctx, RL_ARITH_REFERENCE) / RL_ARITH=reference / "
+                      "bench.py --arith reference select it",
+           "lds_bytes_per_workgroup": int(out["stats"].lds_bytes)}
+    if po is not None:
+        m = po.xy0.shape[0]
+        dev = np.abs(xy[:m] - po.xy0).reshape(m, -1).max(axis=1)
+        with orc.cr_variant():
+            t0 = time.perf_counter()
+            octrl, oxy, ons = orc.solve_width_batch(*po.args, po.widths, po.i_start, nthreads=po.nthreads)
+            dt = time.perf_counter() - t0
+        bit = [bool(np.array_equal(ctrl[b], octrl[b]) and np.array_equal(xy[b], oxy[b]) and np.array_equal(ns[b].ravel(), ons[b].ravel()))
+               for b in range(m)]
+        leg["gpu_vs_oracle"] = {
+            "sample": m, "dev_m_median": float(np.median(dev)), "dev_m_max": float(dev.max()),
+            "vs": "the strict oracle on the platform libm (the same lines the headline's gpu_vs_oracle uses)",
+            "bit_identical_to_the_correctly_rounded_oracle": int(sum(bit)),
+            "correctly_rounded_oracle": f"oracle/libmincurv_oracle_cr.so (atan2 / cos / sin through libquadmath), {dt:.1f} s for the sample; "
+                                        "control points, sampled line and success counts compared as bit patterns",
+            "cr_oracle_vs_libm_oracle_dev_m_max": float(np.abs(oxy - po.xy0).max()),
+            "fast_arithmetic_dev_m_median": float(np.median(np.abs(fast_xy[:m] - po.xy0).reshape(m, -1).max(axis=1)))}
+    if ref_run:
+        d = {bi: float(np.hypot(ctrl[bi, :, 0] - rc[0], ctrl[bi, :, 1] - rc[1]).max()) for bi, rc in ref_run.items()}
+        leg["gpu_vs_reference_run"] = {"instances": sorted(d), "dev_m": [d[b_] for b_ in sorted(d)],
+                                       "within_1e-4": int(sum(v <= 1e-4 for v in d.values())),
+                                       "fixture": "tests/golden/G7b_benchmarked_config.npz (the reference's own loop, numpy on glibc)"}
+    return leg
 
 
 def reference_loop_time():
@@ -383,6 +436,7 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    exit_code = 0
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
@@ -440,6 +494,7 @@ def run_rank(args):
         groups.append({"name": "oval", "t": ot, "cx": ocx, "cy": ocy, "k": ok_, "length": oval.get_length(),
                        "widths": batch.width_batch(owl, owr, B // 2, seed=5678 + rank)})
     search = {"windowed": _lib.SEARCH_WINDOWED, "culled": _lib.SEARCH_CULLED, "brute": _lib.SEARCH_BRUTE}[args.search]
+    ctx.set_arith(_lib.ARITH_REFERENCE if args.arith == "reference" else _lib.ARITH_FAST)   # of the headline's launches
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in groups[1:]]
     for g in groups:
         g["n"] = len(g["cx"])
@@ -564,7 +619,7 @@ def run_rank(args):
         qp_per_solve = [2 * MAX_ITER * (g["n"] - g["k"]) for g in groups]
         qps_per_step = sum(q * g["widths"].shape[0] for q, g in zip(qp_per_solve, groups))
         achieved = (BYTES_PER_SOLVE * B) / (kernel_ms * 1e-3) / 1e9
-        prof = profile_block("k_sweep") if args.workload == "monza" else None
+        prof = profile_block("k_sweep") if args.workload == "monza" and args.arith == "fast" else None
         wl_text = (f"Monza N={N_WAYPOINTS}, batch={B} width-perturbed instances per GPU (BASELINE configs[1])"
                    if args.workload == "monza" else
                    f"mixed: {groups[0]['widths'].shape[0]} Monza + {groups[1]['widths'].shape[0]} rotated-oval "
@@ -583,6 +638,9 @@ def run_rank(args):
                             f"banded QP is the separate `global_qp` leg",
                 "spline": f"s={SPLINE_S:g} k={SPLINE_K} n={[g['n'] for g in groups]}", "batch_per_gpu": B,
                 "control_point_qps_per_s": qps_per_step * world * args.steps / elapsed, "search": args.search,
+                "arith": args.arith + (" (fma, rsqrt normal, tree sums: a legal rounding of the reference's arithmetic; the reference-order "
+                                       "mode is the `reference_order` leg)" if args.arith == "fast" else
+                                       " (RL_ARITH_REFERENCE: the reference's operations in the reference's order)"),
                 "parallelism": f"{world} rank(s) x independent instances"
                                + (f", 1 gather to rank 0 per step and group over torch.distributed backend "
                                   f"'{dist.get_backend()}' ({'gloo: --share-gpu test hook' if args.share_gpu else 'nccl = RCCL over xGMI'})"
@@ -593,7 +651,7 @@ def run_rank(args):
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": prof.get("hbm_bytes_fetch_x2") if prof else None,
                          "traffic_source": prof.get("source") if prof else None, "traffic_measured_in_run": False,
-                         "kernel": "k_sweep", "kernel_ms": kernel_ms,
+                         "kernel": "k_sweep" if args.arith == "fast" else "k_sweep<..., STRICT>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
                          "actual_limiter": "latency of one step's dependent chain at the occupancy the batch allows (4 "
                                            "workgroups per CU; VALU ~59 % active, 61 % of wave cycles waiting); the solver "
@@ -613,11 +671,18 @@ def run_rank(args):
             res["mintime_nlp"] = mintime_leg(args.mintime_batch, with_cpu=not args.no_cpu_baseline)
         if world == 1 and args.workload == "monza" and not args.no_qss:
             res["qss_sim"] = qss_leg(args.qss_batch, with_cpu=not args.no_cpu_baseline)
+        pos = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
+                res["cpu_baseline"], pos = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
             except Exception as e:
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.workload == "monza" and args.arith == "fast" and not args.no_reference_order:
+            try:
+                res["reference_order"] = reference_order_leg(groups[0], args, torch, search, kernel_ms, xy_gpu[0],
+                                                             pos[0] if pos else None, ref_run)
+            except Exception as e:
+                res["reference_order"] = {"error": f"{type(e).__name__}: {e}"}
         if ref_run:
             per = {d_["instance"]: d_ for d_ in res.get("cpu_baseline", {}).get("gpu_vs_oracle", {}).get("per_instance", [])}
             res["gpu_vs_reference_run"] = {
@@ -639,11 +704,29 @@ def run_rank(args):
                              "within_1e-4_of_a_rerounding_branch": gv_["within_1e-4_of_a_rerounding_branch"],
                              "failing": gv_["failing"], "nearest_branch_dev_m_max": gv_["nearest_branch_dev_m_max"],
                              "dev_vs_reference_run_m": res.get("gpu_vs_reference_run", {}).get("dev_m"),
+                             "conditioning": "at N = 2000, max_iter = 5 no instance of this batch is well-conditioned in the reference's own "
+                                             "formulation (rows min(L,R) - (p - b z) divide 1e-13 m of rounding by b ~ 1e-10): the 1e-4 m "
+                                             "tolerance is met per BRANCH for the fast arithmetic; the reference-order arithmetic returns "
+                                             "the oracle's own bits (reference_order leg)",
                              "ok": gv_["failing"] == 0}
+            ro = res.get("reference_order", {}).get("gpu_vs_oracle")
+            if ro:
+                res["parity"]["reference_order_bit_identical"] = f"{ro['bit_identical_to_the_correctly_rounded_oracle']} of {ro['sample']}"
+                res["parity"]["ok"] = bool(res["parity"]["ok"] and ro["bit_identical_to_the_correctly_rounded_oracle"] == ro["sample"])
         print(json.dumps(res), flush=True)
+        # a line whose parity check failed, or one of whose legs crashed, must not pass for a measurement
+        failed = [k_ for k_ in ("cpu_baseline", "global_qp", "mintime_nlp", "qss_sim", "reference_order")
+                  if isinstance(res.get(k_), dict) and "error" in res[k_]]
+        if "parity" in res and not res["parity"]["ok"]:
+            failed.append("parity")
+        if failed:
+            print(f"bench.py: FAILED legs / checks: {failed} (the JSON line above carries the details)", file=sys.stderr, flush=True)
+            exit_code = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 def main():
@@ -654,6 +737,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--workload", choices=["monza", "mixed"], default="monza")
     ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
+    ap.add_argument("--arith", choices=["fast", "reference"], default="fast",
+                    help="arithmetic of the headline's launches (include/rl_mincurv.h: RL_ARITH_*)")
+    ap.add_argument("--no-reference-order", action="store_true", help="skip the reference-order leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-global", action="store_true", help="skip the global-QP leg")
     ap.add_argument("--no-mintime", action="store_true", help="skip the min-time NLP leg")

@@ -28,12 +28,21 @@ for line in open(os.path.join(src, "stats.log")):
         open(os.path.join(dst, f"{round_tag}_bench_under_rocprof.json"), "w").write(line)
 
 
+def match(name, pattern):
+    """pattern = "substring" or "substring|last template argument": k_sweep's instantiations differ in their last
+    template argument (STRICT: the reference-order arithmetic)."""
+    sub, _, last = pattern.partition("|")
+    if sub not in name:
+        return False
+    return not last or name.split(">(")[0].rstrip().endswith(last)
+
+
 def durations(fname, pattern):
     p = os.path.join(src, fname)
     if not os.path.exists(p):
         return []
     return [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
-            for r in csv.DictReader(open(p)) if pattern in r["Kernel_Name"]]
+            for r in csv.DictReader(open(p)) if match(r["Kernel_Name"], pattern)]
 
 
 def per_kernel(pattern):
@@ -43,7 +52,7 @@ def per_kernel(pattern):
         if not os.path.exists(p):
             continue
         for r in csv.DictReader(open(p)):
-            if pattern in r["Kernel_Name"]:
+            if match(r["Kernel_Name"], pattern):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     dur = durations("stats_kernel_trace.csv", pattern)
     if not dur:
@@ -61,8 +70,8 @@ def per_kernel(pattern):
 
 
 kernels = {}
-for name in ("k_sweep", "k_global_qp"):
-    k = per_kernel(name)
+for name, pat in (("k_sweep", "k_sweep<|false"), ("k_sweep_reference_order", "k_sweep<|true"), ("k_global_qp", "k_global_qp")):
+    k = per_kernel(pat)
     if k:
         kernels[name] = k
 doc = {"source": f"profiles/{round_tag}_counters.json (rocprofv3 --pmc passes of tools/profile_bench.sh, bench.py --steps 5)",
