@@ -366,23 +366,44 @@ def qss_leg(B, with_cpu):
         P[:, :, 5] *= rng.uniform(0.9, 1.1, size=(B, 1))
         leg = {"workload": f"Monza centre line, N = {N}, {B} tables with turn radii scaled by 0.9 ... 1.1; the reference test's vehicle",
                "instances": B}
-        for name, tab in (("batch", P), ("single", P[:1])):
+        big = 1024
+        Pbig = np.repeat(pts[None], big, axis=0)
+        Pbig[:, :, 5] *= np.random.default_rng(8).uniform(0.9, 1.1, size=(big, 1))
+        for name, tab in (("batch", P), ("batch_1024", Pbig), ("single", P[:1])):
             d = torch.from_numpy(tab).cuda()
-            ops.qss_sim_torch(d.clone(), *veh); torch.cuda.synchronize()
-            best = None
-            for _ in range(2):
+            ops.qss_sim_torch(d.clone(), *veh); torch.cuda.synchronize()     # warm-up at this size
+            runs = []
+            for _ in range(3):
                 w = d.clone()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); it = ops.qss_sim_torch(w, *veh); e1.record(); torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1)
-                if best is None or ms < best[0]:
-                    best = (ms, w, it)
-            ms, w, it = best
+                runs.append((e0.elapsed_time(e1), w, it))
+            runs.sort(key=lambda r_: r_[0])
+            ms, w, it = runs[len(runs) // 2]          # the MEDIAN of three event-timed calls
             its = it.cpu().numpy()
-            leg[name] = {"instances": int(tab.shape[0]), "ms": ms, "simulations_per_s": tab.shape[0] / ms * 1e3,
+            leg[name] = {"instances": int(tab.shape[0]), "ms": ms, "ms_min": runs[0][0], "ms_all": [r_[0] for r_ in runs],
+                         "simulations_per_s": tab.shape[0] / ms * 1e3,
                          "global_iterations_mean": float(its.mean()), "raised": int((its < 0).sum())}
             if name == "batch":
                 out, its_batch = w.cpu().numpy(), its
+        leg["timing"] = "median of three calls after a warm-up at the same size, HIP events on the launch stream (device resident)"
+        cpath = os.path.join(ROOT, "profiles", "qss_counters_latest.json")
+        if os.path.exists(cpath):       # counters of the committed rocprofv3 passes (tools/profile_qss.sh): not measured in this run
+            try:
+                cj = json.load(open(cpath))
+                rows = [r_ for r_ in cj["kernels"] if r_["kernel"].startswith("k_qss_dfw") and r_["N"] == N]
+                row = max(rows, key=lambda r_: r_["instances"])
+                leg["counters"] = {
+                    "kernel": row["kernel"], "instances_profiled": row["instances"], "ms_profiled": row["ms"],
+                    "waiting_share_of_wave_cycles": row["SQ_WAIT_ANY"] / row["SQ_WAVE_CYCLES"],
+                    "valu_busy_share_of_wave_cycles": 4.0 * row["SQ_ACTIVE_INST_VALU"] / row["SQ_WAVE_CYCLES"],
+                    "lds_bank_conflict_share_of_lds_cycles": row["SQ_LDS_BANK_CONFLICT"] / row["SQ_LDS_IDX_ACTIVE"],
+                    "wave_instructions_per_trajectory": {k_: row["per_instance"][k_] for k_ in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")},
+                    "bound": "latency of a dependent chain of front steps (DESIGN.md 3c): no bandwidth or flop roofline applies; the "
+                             "counters say how much of a wave's time is waiting",
+                    "source": cj.get("source_file", "profiles/qss_counters_latest.json"), "measured_in_run": False}
+            except Exception as e:
+                leg["counters"] = {"error": f"{type(e).__name__}: {e}"}
         leg["kernel"] = "k_qss_dfw<4> (the reference's steps as a dataflow, four waves per instance) for every size its LDS tables hold, else k_qss_sim (list order)"
         if with_cpu:
             from oracle import oracle as orc
@@ -611,6 +632,7 @@ def run_rank(args):
                     assert torch.equal(got, all_chk[r][gi, :2]), f"group {gi}: the shard of rank {r} changed in the gather"
                     n_ok += 1
             gather_check = {"groups": len(groups), "ranks": world, "shards_equal": n_ok, "checksum": "wrapping int64 sums of the bit patterns",
+                            "collective": "grouped isend/irecv (dist.gather raised on this backend)" if batch._gather_fallback["p2p"] else "dist.gather",
                             "skipped_qps_per_rank": [[int(all_chk[r][gi, 2]) for gi in range(len(groups))] for r in range(world)]}
 
     if rank == 0:

@@ -130,7 +130,38 @@ def shard_range(B, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_to_root(tensor, rank, world, dist, total=None, out=None, async_op=False):
+class _Works:
+    """wait() on every work handle of a grouped send / receive (what dist.gather's single handle offers)."""
+
+    def __init__(self, works):
+        self.works = list(works or [])
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+
+_gather_fallback = {"p2p": os.environ.get("RL_GATHER", "") == "p2p"}   # RL_GATHER=p2p forces the grouped send / receive
+
+
+def _gather_p2p(pad, bufs, rank, world, dist, async_op):
+    """The same collective as grouped point-to-point transfers ("ncclGather-equivalent via grouped
+    ncclSend / ncclRecv"): rank 0 posts one receive per peer, every other rank one send, in ONE batch
+    (dist.batch_isend_irecv = ncclGroupStart ... ncclGroupEnd on RCCL); rank 0's own shard is a local copy."""
+    if rank == 0:
+        bufs[0].copy_(pad)
+        ops_ = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(1, world)]
+    else:
+        ops_ = [dist.P2POp(dist.isend, pad, 0)]
+    works = _Works(dist.batch_isend_irecv(ops_) if ops_ else [])
+    if async_op:
+        return works
+    works.wait()
+    return None
+
+
+def gather_to_root(tensor, rank, world, dist, total=None, out=None, async_op=False, method="auto"):
     """The single collective of the path: every rank's result shard to rank 0 (RCCL `gather` over
     xGMI; gloo in the CPU tests).  `total` = global instance count when the shards come from
     shard_range(total, r, world) (they may then differ by one instance and are padded to the
@@ -138,7 +169,10 @@ def gather_to_root(tensor, rank, world, dist, total=None, out=None, async_op=Fal
     `out` (rank 0, equal shards only): preallocated [world * B, ...] tensor the shards land in directly,
     no concatenation.  `async_op=True` returns the collective's work handle instead of the result: the
     gather then runs on the process group's own stream, ordered after what is already enqueued on the
-    current stream, and overlaps with whatever the caller enqueues next (bench.py: the next launch)."""
+    current stream, and overlaps with whatever the caller enqueues next (bench.py: the next launch).
+    `method`: "gather" = dist.gather; "p2p" = the same transfer as one batch of grouped isend / irecv; "auto" =
+    dist.gather, and from the first time it raises on this backend (every rank raises alike: an unsupported
+    collective is refused before anything is sent) the grouped form for the rest of the process."""
     import torch
     if world == 1:
         return None if async_op else tensor
@@ -158,7 +192,20 @@ def gather_to_root(tensor, rank, world, dist, total=None, out=None, async_op=Fal
             bufs = list(out.view((world, mx) + tuple(tensor.shape[1:])).unbind(0))
         else:
             bufs = [torch.empty_like(pad) for _ in range(world)]
-    work = dist.gather(pad, bufs, dst=0, async_op=async_op)
+    use_p2p = method == "p2p" or (method == "auto" and _gather_fallback["p2p"])
+    work = None
+    if not use_p2p:
+        try:
+            work = dist.gather(pad, bufs, dst=0, async_op=async_op)
+        except (RuntimeError, NotImplementedError) as e:
+            if method != "auto":
+                raise
+            print(f"gather_to_root: dist.gather raised on backend '{dist.get_backend()}' ({type(e).__name__}: {e}); "
+                  f"using grouped isend / irecv from here on", flush=True)
+            _gather_fallback["p2p"] = True
+            use_p2p = True
+    if use_p2p:
+        work = _gather_p2p(pad, bufs, rank, world, dist, async_op)
     if async_op:
         return work
     if rank != 0:

@@ -448,6 +448,7 @@ constexpr int kSweepWaves = 4;   // waves of the 256-thread sweep workgroup (the
 // (6 x 256 doubles = 12 KB: inside the staged stretches' 13.8 KB, which are idle between two refreshes), and the
 // window of derivative-spline coefficients the next step needs (2 coordinates x (2k + 2k-1) values)
 constexpr int kTermChunk = 256;
+constexpr int kTermStride = kTermChunk + 2;   // 6 lanes read 6 rows at the same index: 2064 B apart = 4 banks apart, no conflict (stride 256: six-fold)
 constexpr int kC12Doubles = 4 * (2 * kMaxK) + 8;
 
 // joint: the sliding-window instantiation (its QP scratch and per-sample flags are carved only then).  With the rings in
@@ -484,11 +485,11 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   if (rings_in_lds) {
     L.off_rL = o; o += (size_t)2 * (nL + kRingPad);
     L.off_rR = o; o += (size_t)2 * (nR + kRingPad);
-    if (strict) { L.off_terms = o; o += (size_t)6 * kTermChunk; }
+    if (strict) { L.off_terms = o; o += (size_t)6 * kTermStride; }
   } else {
     L.off_stage = o; o += (size_t)kSweepWaves * 2 * kStageSlots * 2;   // [wave][ring][kStageSlots] double2
     L.off_terms = L.off_stage;                                         // strict: the terms use the idle stretches
-    static_assert((size_t)kSweepWaves * 2 * kStageSlots * 2 >= (size_t)6 * kTermChunk, "the cost terms fit the staged stretches");
+    static_assert((size_t)kSweepWaves * 2 * kStageSlots * 2 >= (size_t)6 * kTermStride, "the cost terms fit the staged stretches");
   }
   L.total = o;
   return L;
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
     // ---- reference-order mode of run_min_curvature_qp (optimizer.py:256-341): the same three phases per step, with the
     // reference's operations in the reference's order (see the note above StrictRows)
     double* c12 = smem + L.off_c12;      // derivative-spline coefficients around the NEXT control point: c1x | c1y | c2x | c2y, 2K each
-    double* terms = smem + L.off_terms;  // [6][kTermChunk] cost terms of the current chunk of support samples
+    double* terms = smem + L.off_terms;  // [6][kTermStride] cost terms of the current chunk of support samples
     const int steps = i_max - i_min;
     const int total_steps = a.max_iter * 2 * steps;
     auto step_index = [&](int q) {       // optimizer.py:303-324
@@ -910,11 +911,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           const double Pyy = (dTx * dTx) / denom;
           double* tp = terms + tid;
           tp[0] = B2 * Pxx * B2;
-          tp[kTermChunk] = B2 * Pyy * B2;
-          tp[2 * kTermChunk] = Fx * Pxx * B2;
-          tp[3 * kTermChunk] = Fy * Pxy * B2;
-          tp[4 * kTermChunk] = Fy * Pyy * B2;
-          tp[5 * kTermChunk] = B2 * Pxy * Fx;
+          tp[kTermStride] = B2 * Pyy * B2;
+          tp[2 * kTermStride] = Fx * Pxx * B2;
+          tp[3 * kTermStride] = Fy * Pxy * B2;
+          tp[4 * kTermStride] = Fy * Pyy * B2;
+          tp[5 * kTermStride] = B2 * Pxy * Fx;
           // rows (optimizer.py:235-248): non_z = p - b z_old, lba = min(L, R) - non_z, uba = max(L, R) - non_z
           const double2 Lp = bL[i], Rp = bR[i];
           const double nzx = x - B0 * zx, nzy = y - B0 * zy;
@@ -936,7 +937,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         __syncthreads();
         if (wave == 0 && lane < 6) {      // hxx += ..., in index order (oracle: orc_min_curvature_cost)
           const int cnt = min(kTermChunk, M - ch * kTermChunk);
-          const double* tp = terms + lane * kTermChunk;
+          const double* tp = terms + lane * kTermStride;
           int j = 0;
           for (; j + 8 <= cnt; j += 8) {
             double v[8];

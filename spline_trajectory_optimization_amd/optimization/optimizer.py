@@ -115,8 +115,14 @@ class TrajectoryOptimizer:
         return joint_A, min_bound, max_bound
 
     def run_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, visualize=False,
-                             max_iter=5, *, i_start=None, simulate=False):
-        """optimizer.py:256-341 -> ONE launch of the LDS-resident sweep kernel (k_sweep)."""
+                             max_iter=5, *, i_start=None, simulate=False, arith=None):
+        """optimizer.py:256-341 -> ONE launch of the LDS-resident sweep kernel (k_sweep).
+
+        simulate=True reproduces what the reference prints: the simulator runs on the table after EVERY outer iteration
+        ("Iteration j" + the result, :333-336; its speeds never feed back into the spline) and once more at the end
+        (:338-339).  The sweep is then launched once per outer iteration, each launch continuing from the control points
+        of the one before -- the same bits as the single launch, since every launch re-derives the table from the
+        control points.  arith: _lib.ARITH_FAST / ARITH_REFERENCE for this call (None = the context's setting)."""
         traj_out_s = traj_in_s.copy()
         n = len(traj_out_s._spl_x.c)
         k = traj_out_s._spl_x.k
@@ -132,18 +138,37 @@ class TrajectoryOptimizer:
         trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
         trk.set_length(traj_out_s.get_length())
         t, cx, cy, _ = traj_out_s._tck()
-        cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start, want_points=True)
+
+        def table(pts):                                     # the traj_out_d of optimizer.py:286-288
+            tab = Trajectory(len(pts))
+            tab.points = pts
+            return tab
+        if simulate:
+            ns_all = []
+            self.last_sim_results = []
+            for j in range(max_iter):
+                cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start[j:j + 1], want_points=True, arith=arith)
+                ns_all.append(ns[0])
+                print(f"Forward pass: number of control points successfully updated: {ns[0, 0]}")
+                print(f"Backward pass: number of control points successfully updated: {ns[0, 1]}")
+                sim_result = self.sim.run_simulation(table(pts), enable_vis=False)          # :333
+                print(f"Iteration {j+1}")
+                print(sim_result)
+                self.last_sim_results.append(sim_result)
+            ns = np.array(ns_all)
+            sim_result = self.sim.run_simulation(sim_result.trajectory, enable_vis=False)   # :338-339
+            print(sim_result)
+            self.last_sim_results.append(sim_result)
+        else:
+            cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start, want_points=True, arith=arith)
+            for j in range(max_iter):
+                print(f"Forward pass: number of control points successfully updated: {ns[j, 0]}")
+                print(f"Backward pass: number of control points successfully updated: {ns[j, 1]}")
         traj_out_s._spl_x.c[:] = cx
         traj_out_s._spl_y.c[:] = cy
-        for j in range(max_iter):
-            print(f"Forward pass: number of control points successfully updated: {ns[j, 0]}")
-            print(f"Backward pass: number of control points successfully updated: {ns[j, 1]}")
         self.last_n_success = ns
         self.last_stats = stats
-        self.last_table = Trajectory(len(pts))          # the final traj_out_d of optimizer.py:286-288
-        self.last_table.points = pts
-        if simulate:
-            print(self.sim.run_simulation(self.last_table, enable_vis=False))
+        self.last_table = table(pts)
         return traj_out_s
 
     def run_joint_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, max_iter=3,

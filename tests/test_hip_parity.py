@@ -13,6 +13,9 @@ edge of a basis function's support ("Conditioning").  That is the FAS
 reference-order arithmetic (RL_ARITH_REFERENCE) is held to the oracle bit for bit in tests/test_reference_order.py.
 The fast kernel's per-step logic is pinned independently of that noise by
 tests/test_sweep_replay.py (teacher-forced replay of every step against the oracle)."""
+import contextlib
+import io
+
 import numpy as np
 import pytest
 
@@ -582,6 +585,23 @@ def test_drop_in_api(rl, fits, rings):
     track.fill_trajectory_boundaries(again)
     for col in (Trajectory.LEFT_BOUND_X, Trajectory.LEFT_BOUND_Y, Trajectory.RIGHT_BOUND_X, Trajectory.RIGHT_BOUND_Y):
         np.testing.assert_allclose(tab[:, col], again[:, col], rtol=0, atol=1e-8)
+    # simulate=True: the reference's per-iteration simulator output (optimizer.py:333-339: after every outer iteration
+    # and once more at the end) -- one launch per outer iteration, same bits as the single launch
+    np.random.seed(0)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out2 = optm.run_min_curvature_qp(traj_spline, traj_d, visualize=False, max_iter=2, simulate=True)
+    np.testing.assert_array_equal(out2._spl_x.c, out._spl_x.c); np.testing.assert_array_equal(out2._spl_y.c, out._spl_y.c)
+    np.testing.assert_array_equal(optm.last_n_success, g7[f"{key}_n_success"])
+    text = buf.getvalue()
+    assert "Iteration 1" in text and "Iteration 2" in text and "Iteration 3" not in text
+    assert len(optm.last_sim_results) == 3 and text.count("Forward pass") == 2
+    # and in the reference-order arithmetic: the oracle's bits (tests/test_reference_order.py), through the class API
+    np.random.seed(0)
+    out3 = optm.run_min_curvature_qp(traj_spline, traj_d, visualize=False, max_iter=2, arith=1)
+    dev3 = np.hypot(out3._spl_x.c - g7[f"{key}_cx"], out3._spl_y.c - g7[f"{key}_cy"]).max()
+    print("drop-in run_min_curvature_qp, reference-order arithmetic, deviation from the reference run [m]:", dev3)
+    assert dev3 < TIGHT_M
 
 
 def _sim_inputs():

@@ -152,20 +152,40 @@ rank, world = dist.get_rank(), dist.get_world_size()
 assert world == 8
 # BASELINE configs[2] runs on 8 ranks: an UNEVEN split (B = 1000 over 8 -> shards of 125; B = 1003 -> 126/125) through
 # gather_to_root(total=...), every instance tagged with its global index
-for B, N in ((1000, 16), (1003, 8), (5, 4)):
-    lo, hi = batch.shard_range(B, rank, world)
-    mine = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1, 1).repeat(1, N, 2) if hi > lo else torch.zeros((0, N, 2), dtype=torch.float64)
-    full = batch.gather_to_root(mine, rank, world, dist, total=B)
+# ... through dist.gather AND through the grouped isend / irecv form of the same collective (what "auto" falls back to
+# when a backend refuses gather)
+for method in ("gather", "p2p"):
+    for B, N in ((1000, 16), (1003, 8), (5, 4)):
+        lo, hi = batch.shard_range(B, rank, world)
+        mine = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1, 1).repeat(1, N, 2) if hi > lo else torch.zeros((0, N, 2), dtype=torch.float64)
+        full = batch.gather_to_root(mine, rank, world, dist, total=B, method=method)
+        if rank == 0:
+            assert full.shape == (B, N, 2), full.shape
+            assert torch.equal(full[:, 0, 0], torch.arange(B, dtype=torch.float64)) and torch.equal(full[:, N - 1, 1], full[:, 0, 0])
+        else:
+            assert full is None
+    # integer control data (status words) through the same gather
+    lo, hi = batch.shard_range(1000, rank, world)
+    st = batch.gather_to_root(torch.arange(lo, hi, dtype=torch.int32), rank, world, dist, total=1000, method=method)
     if rank == 0:
-        assert full.shape == (B, N, 2), full.shape
-        assert torch.equal(full[:, 0, 0], torch.arange(B, dtype=torch.float64)) and torch.equal(full[:, N - 1, 1], full[:, 0, 0])
-    else:
-        assert full is None
-# integer control data (status words) through the same gather
-lo, hi = batch.shard_range(1000, rank, world)
-st = batch.gather_to_root(torch.arange(lo, hi, dtype=torch.int32), rank, world, dist, total=1000)
+        assert torch.equal(st, torch.arange(1000, dtype=torch.int32))
+    # equal shards into a preallocated tensor, asynchronously (bench.py's use)
+    mine = torch.full((3, 4, 2), float(rank), dtype=torch.float64)
+    dst = torch.empty((world * 3, 4, 2), dtype=torch.float64) if rank == 0 else None
+    w = batch.gather_to_root(mine, rank, world, dist, out=dst, async_op=True, method=method)
+    w.wait()
+    if rank == 0:
+        assert torch.equal(dst[:, 0, 0], torch.arange(world, dtype=torch.float64).repeat_interleave(3))
+# "auto": a backend whose gather raises is served by the grouped form from then on
+real_gather = dist.gather
+def refusing(*a, **k):
+    raise RuntimeError("gather not supported on this backend (test)")
+dist.gather = refusing
+full = batch.gather_to_root(torch.full((2, 1), float(rank), dtype=torch.float64), rank, world, dist)
+dist.gather = real_gather
 if rank == 0:
-    assert torch.equal(st, torch.arange(1000, dtype=torch.int32))
+    assert torch.equal(full[:, 0], torch.arange(world, dtype=torch.float64).repeat_interleave(2))
+    assert batch._gather_fallback["p2p"]
     print("GLOO8_OK")
 dist.barrier()
 dist.destroy_process_group()
