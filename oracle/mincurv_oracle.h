@@ -163,6 +163,12 @@ void orc_replay_steps(const double* t, int nt, int k, int N, const double* ringL
                       const double* ringR, int nR, int n_steps, const int* idx,
                       const double* cxs, const double* cys, double* out, int nthreads);
 
+/* numpy's error state at the start of the two drivers (see mincurv_oracle.c, "numpy's error state"; fixture G12):
+ * 1 = np.seterr(all='raise') is already in effect (the simulator has run before, as in the reference's own test);
+ * thread-local; orc_last_raised() = steps / windows of the last driver call whose re-sampling raised */
+void orc_set_numpy_raise(int on);
+int orc_last_raised(void);
+
 /* heading of a tangent + the two normal directions as the sampling / boundary code takes them (test aid);
  * orc_libm_is_correctly_rounded() = 1 in the -DORC_LIBM_CR build (libmincurv_oracle_cr.so) */
 void orc_heading(const double* dx, const double* dy, int n, double* out /*[n,5]*/);

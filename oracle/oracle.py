@@ -175,9 +175,10 @@ def qp_solve_separable(H, g, A, lba, uba):
     return st, x
 
 
-def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None, rerounding=0):
+def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None, rerounding=0, numpy_raise=False):
     """Returns (cx, cy, points[N,19], n_success[max_iter,2]).  rerounding: seed of mincurv_oracle.c:
-    orc_set_rerounding for this run (0 = the unperturbed oracle)."""
+    orc_set_rerounding for this run (0 = the unperturbed oracle).  numpy_raise: np.seterr(all='raise') is in effect
+    from the start (mincurv_oracle.c, "numpy's error state"); last_raised() then tells how many steps raised."""
     t, tp = _d(t)
     cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
     ringL, lp = _d(ringL); ringR, rp = _d(ringR)
@@ -191,13 +192,20 @@ def run_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_ite
     setr.argtypes = [ctypes.c_ulonglong]
     setr.restype = None
     setr(int(rerounding))                      # thread-local in the oracle
+    lib().orc_set_numpy_raise(1 if numpy_raise else 0)
     try:
         lib().orc_run_min_curvature_qp(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k),
                                        float(length), pts.ctypes.data_as(_dp), int(N), lp, len(ringL),
                                        rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
     finally:
         setr(0)
+        lib().orc_set_numpy_raise(0)
     return cx, cy, pts, ns.reshape(max_iter, 2)
+
+
+def last_raised():
+    """Steps / windows of the last driver call on this thread whose re-sampling raised under numpy's raise mode."""
+    return int(lib().orc_last_raised())
 
 
 def last_kappa():
@@ -250,9 +258,10 @@ def qp_diag_rows(h, g, A, l, u):
     return st, x, lam
 
 
-def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None, rerounding=0):
+def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, max_iter=None, rerounding=0,
+                               numpy_raise=False):
     """Returns (cx, cy, points[N,19], n_success[max_iter]).  rerounding: seed of mincurv_oracle.c:
-    orc_set_rerounding for this run (0 = the unperturbed oracle)."""
+    orc_set_rerounding for this run (0 = the unperturbed oracle).  numpy_raise: as for run_min_curvature_qp."""
     t, tp = _d(t)
     cx = np.array(cx, dtype=np.float64, copy=True); cy = np.array(cy, dtype=np.float64, copy=True)
     ringL, lp = _d(ringL); ringR, rp = _d(ringR)
@@ -268,11 +277,13 @@ def run_joint_min_curvature_qp(t, cx, cy, k, length, N, ringL, ringR, i_start, m
     setr.argtypes = [ctypes.c_ulonglong]
     setr.restype = None
     setr(int(rerounding))
+    lib().orc_set_numpy_raise(1 if numpy_raise else 0)
     try:
         f(tp, len(t), cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), int(k), float(length),
           pts.ctypes.data_as(_dp), int(N), lp, len(ringL), rp, len(ringR), ip, int(max_iter), ns.ctypes.data_as(_ip))
     finally:
         setr(0)
+        lib().orc_set_numpy_raise(0)
     return cx, cy, pts, ns
 
 

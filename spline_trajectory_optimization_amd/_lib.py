@@ -45,6 +45,7 @@ _SIGNATURES = {
     "rl_ctx_synchronize": (ctypes.c_int, [_vp]),
     "rl_ctx_set_arith": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rl_ctx_get_arith": (ctypes.c_int, [_vp]),
+    "rl_ctx_set_numpy_raise": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rl_debug_cr_heading": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, _dp]),
     "rl_spline_eval": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp,
                                       ctypes.c_int, ctypes.c_int, _dp]),
@@ -177,6 +178,11 @@ class Context:
         old = self.lib.rl_ctx_get_arith(self.h)
         check(self.lib.rl_ctx_set_arith(self.h, int(arith)))
         return old
+
+    def set_numpy_raise(self, on):
+        """Reference-order sweep: np.seterr(all='raise') is already in effect when the driver starts
+        (include/rl_mincurv.h: rl_ctx_set_numpy_raise)."""
+        check(self.lib.rl_ctx_set_numpy_raise(self.h, 1 if on else 0))
 
     def arith(self, arith):
         """with ctx.arith(ARITH_REFERENCE): ...  -- the sweep calls inside run in that arithmetic."""

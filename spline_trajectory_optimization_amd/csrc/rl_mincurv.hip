@@ -73,6 +73,7 @@ struct rl_ctx {
   int num_cu = 0;
   bool force_global_v1 = false;  // test hook: RL_GLOBAL_V1=1 keeps the generic kernel
   int arith = RL_ARITH_FAST;     // rl_ctx_set_arith: arithmetic of the sweep (RL_ARITH_FAST / RL_ARITH_REFERENCE)
+  int np_raise_at_start = 0;     // rl_ctx_set_numpy_raise: the reference-order sweep starts with np.seterr(all='raise') in effect
   // Device scratch owned by the context (grow-only): the *_dev entry points of the QSS simulator and the
   // min-time solve carve their work arrays out of it, so that steady-state calls allocate nothing.
   void* arena = nullptr;
@@ -211,6 +212,7 @@ struct rl_track {
   // directions, built by the first solve that asks for them, rebuilt when the control points change
   mutable DevBuf<double> Ds, base_s;
   mutable bool strict_valid = false;
+  mutable DevBuf<double> aux;   // reference-order sweep, per instance: table control points + per-sample flags (numpy's error state)
   DevBuf<double> ringL, ringR;  // shared rings as (x,y) pairs
   int nL = 0, nR = 0;
   double length = 0.0;          // BSplineTrajectory._length of the INITIAL spline (rl_track_set_length); 0 = not given
@@ -292,9 +294,9 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, boo
   return p;
 }
 
-template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL, bool STRICT = false>
+template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL, bool STRICT = false, bool RAISE = false>
 int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
-  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL, STRICT>;
+  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL, STRICT, RAISE>;
   RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
@@ -305,8 +307,12 @@ int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
 int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false, bool strict = false) {
   if (strict) {   // RL_ARITH_REFERENCE: the degree-5 sweep (the reference's wrap is written for k = 5, optimizer.py:281-285)
     if (joint || k != 5 || a.dbg) return fail(RL_ERR_UNSUPPORTED, "reference-order arithmetic: run_min_curvature_qp on a degree-5 spline, no step dump");
-    return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, false, true, true>(ctx, a, p.lds_bytes)
-                          : launch_sweep_t<5, 256, false, false, false, false, true>(ctx, a, p.lds_bytes);
+    // the plain kernel flags the instances that need numpy's error state modelled (a sample of exactly zero curvature while
+    // numpy is in raise mode); the RAISE instantiation behind it redoes those and returns at once on all others
+    if (int rc = p.rings_in_lds ? launch_sweep_t<5, 256, true, false, false, true, true>(ctx, a, p.lds_bytes)
+                                : launch_sweep_t<5, 256, false, false, false, false, true>(ctx, a, p.lds_bytes)) return rc;
+    return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, false, true, true, true>(ctx, a, p.lds_bytes)
+                          : launch_sweep_t<5, 256, false, false, false, false, true, true>(ctx, a, p.lds_bytes);
   }
   if (joint) {
     if (k != 5) return fail(RL_ERR_UNSUPPORTED, "the sliding-window variant is built for degree 5 (span 5)");
@@ -443,6 +449,12 @@ int rl_ctx_set_arith(rl_ctx* ctx, int arith) {
 }
 
 int rl_ctx_get_arith(const rl_ctx* ctx) { return ctx ? ctx->arith : RL_ERR_ARG; }
+
+int rl_ctx_set_numpy_raise(rl_ctx* ctx, int on) {
+  if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
+  ctx->np_raise_at_start = on ? 1 : 0;
+  return RL_OK;
+}
 
 int rl_debug_cr_heading(rl_ctx* ctx, const double* dx, const double* dy, int n, double* out) {
   if (!ctx || !dx || !dy || !out || n <= 0) return fail(RL_ERR_ARG, "bad argument");
@@ -791,6 +803,17 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     if (trk->gscratch.n < need) RL_HIP(trk->gscratch.alloc(need));
     a.gscratch = trk->gscratch.p;
     a.gscratch_stride = p.gscratch_doubles;
+  }
+  if (strict) {
+    // per instance: [2 cpad] reserved | [ceil(N/16)*2] doubles of per-sample flag bytes | [N] double2 snapshot of the table's X, Y
+    const size_t per = (size_t)2 * ((n + 1) & ~1) + (size_t)2 * ((N + 15) / 16) + (size_t)2 * N;
+    const size_t flags = ((size_t)B + 1) / 2;    // [B] ints behind the per-instance blocks
+    if (trk->aux.n < per * (size_t)B + flags) RL_HIP(trk->aux.alloc(per * (size_t)B + flags));
+    a.aux = trk->aux.p;
+    a.aux_stride = per;
+    a.np_raise_at_start = ctx->np_raise_at_start;
+    a.raise_flag = reinterpret_cast<int*>(trk->aux.p + per * (size_t)B);
+    RL_HIP(hipMemsetAsync(a.raise_flag, 0, (size_t)B * sizeof(int), ctx->stream));
   }
   if (stats) {
     stats->lds_bytes = (int)p.lds_bytes;

@@ -245,6 +245,35 @@ def test_g7b_benchmarked_configuration(fits, rings):
             assert len(g[f"{key}_i_start"]) == 5 and dev < 1e-5, (key, dev)
 
 
+def test_g12_numpy_raise_semantics():
+    """Fixture G12: the reference's two drivers run under np.seterr(all='raise') -- which the simulator switches on for
+    the whole process (simulator.py:164) and the reference's own test does before it calls run_min_curvature_qp
+    (tests/test_optimizer.py:35-37) -- on a track with a run of control points exactly on the diagonal y = x: there
+    x' y'' - y' x'' == 0 exactly, sample_along raises in 1 / |curvature| (trajectory.py:253-260) INSIDE the try block,
+    after set_control_point has written the new control points: the step fails, the spline keeps the update, the table
+    stays stale (optimizer.py:276-293, :197-214).  The oracle models that state (orc_set_numpy_raise) and reproduces the
+    reference's run: same per-pass success counts, same number of raising windows, same line; without the model it does
+    not."""
+    g = golden("G12_numpy_raise_semantics.npz")
+    t, cx, cy, k, length = g["t"], g["cx"], g["cy"], int(g["k"]), float(g["length"])
+    ocx, ocy, _, ns = orc.run_min_curvature_qp(t, cx, cy, k, length, 300, g["ringL"], g["ringR"], g["sweep_N300_i_start"],
+                                               numpy_raise=True)
+    np.testing.assert_array_equal(ns, g["sweep_N300_n_success"])
+    assert orc.last_raised() > 0 and ns[0, 0] < ns[0, 1]          # the stale phase is the start of the first pass
+    dev = float(np.hypot(ocx - g["sweep_N300_cx"], ocy - g["sweep_N300_cy"]).max())
+    print("G12 sweep: oracle vs the reference's run [m]:", dev, "steps whose re-sampling raised:", orc.last_raised())
+    assert dev < 1e-5
+    plain = orc.run_min_curvature_qp(t, cx, cy, k, length, 300, g["ringL"], g["ringR"], g["sweep_N300_i_start"])
+    assert not np.array_equal(plain[3], g["sweep_N300_n_success"])
+    assert np.hypot(plain[0] - g["sweep_N300_cx"], plain[1] - g["sweep_N300_cy"]).max() > 1.0
+    jcx, jcy, _, jns = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, 240, g["ringL"], g["ringR"], g["joint_N240_i_start"],
+                                                      numpy_raise=True)
+    assert orc.last_raised() == int(g["joint_N240_n_raised"]) and int(jns.sum()) == int(g["joint_N240_n_ok"])
+    jdev = float(np.hypot(jcx - g["joint_N240_cx"], jcy - g["joint_N240_cy"]).max())
+    print("G12 sliding window: oracle vs the reference's run [m]:", jdev, "windows whose re-sampling raised:", orc.last_raised())
+    assert jdev < 1e-6
+
+
 def test_g6_qss_simulator():
     """The oracle's port of Simulator.run_simulation against the reference's own run (fixture G6)."""
     from scipy.interpolate import CubicSpline

@@ -238,3 +238,45 @@ def test_reference_order_refuses_what_it_does_not_cover(rl, fits, rings):
     w = np.full((1, 200, 2), 5.0)
     with pytest.raises(rl.lib.RlError):
         rl.ops.solve_batch_host(trk3, rl.lib.BOUNDS_WIDTHS, w, np.array([3]), arith=REF)
+
+
+def test_numpy_raise_semantics_g12(rl):
+    """Fixture G12 (the reference's own loop under np.seterr(all='raise') on a track with a stretch of exactly zero
+    curvature): steps whose re-sampling raises leave the control point written and the table stale, and are not
+    counted.  The reference-order sweep models numpy's error state (rl_ctx_set_numpy_raise): same per-pass success counts
+    as the reference's run, the line within the oracle's own distance of it, and the oracle's bits."""
+    g = golden("G12_numpy_raise_semantics.npz")
+    t, cx, cy, k, length = g["t"], g["cx"], g["cy"], int(g["k"]), float(g["length"])
+    N = 300
+    i_start = g["sweep_N300_i_start"]
+    ctx = rl.lib.Context.get(0)
+    trk = rl.lib.Track(ctx, t, cx, cy, k, N)
+    trk.set_rings(g["ringL"], g["ringR"])
+    ctx.set_numpy_raise(True)
+    try:
+        res = {}
+        for search in (0, 2):
+            ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_SHARED_RINGS, None, i_start, search=search,
+                                                               B=3, arith=REF)
+            res[search] = (ctrl, ns)
+    finally:
+        ctx.set_numpy_raise(False)
+    ctrl, ns = res[2]
+    np.testing.assert_array_equal(res[0][0], ctrl); np.testing.assert_array_equal(res[0][1], ns)
+    np.testing.assert_array_equal(ns[0], g["sweep_N300_n_success"])
+    np.testing.assert_array_equal(ns[1], ns[0]); np.testing.assert_array_equal(ctrl[2], ctrl[0])
+    dev = float(np.hypot(ctrl[0, :, 0] - g["sweep_N300_cx"], ctrl[0, :, 1] - g["sweep_N300_cy"]).max())
+    print("G12: reference-order HIP vs the reference's run [m]:", dev, "successes", ns[0].ravel().tolist())
+    assert dev < 1e-5
+    with orc.cr_variant():
+        ocx, ocy, _, ons = orc.run_min_curvature_qp(t, cx, cy, k, length, N, g["ringL"], g["ringR"], i_start, numpy_raise=True)
+        assert orc.last_raised() > 0
+    np.testing.assert_array_equal(ns[0], ons)
+    np.testing.assert_array_equal(ctrl[0, :, 0], ocx); np.testing.assert_array_equal(ctrl[0, :, 1], ocy)
+    # numpy's default state at the start (raise mode from the end of outer iteration 0): the oracle's bits too
+    ctrl2, _, ns2, _, _ = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_SHARED_RINGS, None, i_start, B=1, arith=REF)
+    with orc.cr_variant():
+        pcx, pcy, _, pns = orc.run_min_curvature_qp(t, cx, cy, k, length, N, g["ringL"], g["ringR"], i_start)
+    np.testing.assert_array_equal(ns2[0], pns)
+    np.testing.assert_array_equal(ctrl2[0, :, 0], pcx); np.testing.assert_array_equal(ctrl2[0, :, 1], pcy)
+    assert not np.array_equal(pns, ons)
