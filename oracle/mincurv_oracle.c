@@ -1472,7 +1472,11 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
       mu /= (double)(2 * N);
       double rdmax = 0.0;
       for (int j = 0; j < np_; ++j) rdmax = fmax(rdmax, fabs(rd[j]));
-      if (fmax(rdmax / (1.0 + qinf), rpmax) < 1e-9 && mu < 1e-10) break;
+      { /* all but the last linearisation are solved inexactly (complementarity 1e-5, residuals 1e-4): the next
+         * Gauss-Newton step moves the line by decimetres; same constants as csrc/rl_global.hpp kGLooseMu / kGLooseRes */
+        const int last_qp = outer + 1 >= n_outer;
+        if (fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : 1e-4) && mu < (last_qp ? 1e-10 : 1e-5)) break;
+      }
       ++total_it;
       /* normal matrix */
       memcpy(Kq, P, (size_t)np_ * np_ * sizeof(double));

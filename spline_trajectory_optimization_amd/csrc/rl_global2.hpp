@@ -1115,7 +1115,11 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
           for (int j = lane; j < np; j += kWave) rdmax = fmax(rdmax, fabs(rd[j]));
           rdmax = wave_max(rdmax);
           const double mu = mu_sum / (double)(2 * N);
-          conv = fmax(rdmax / (1.0 + qinf), rpmax) < 1e-9 && mu < 1e-10;
+          // the linearisations before the last are solved INEXACTLY (complementarity 1e-5, residuals 1e-4): the next
+          // Gauss-Newton step moves the line by decimetres, so their last digits buy nothing (92.7 -> 73 interior-point
+          // iterations on the benchmarked batch, same final sum kappa^2; rl_global.hpp: kGLooseMu; twin: orc_global_mincurv)
+          const bool last_qp = outer + 1 >= a.n_outer;
+          conv = fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : kGLooseRes) && mu < (last_qp ? 1e-10 : kGLooseMu);
           if (lane == 0) ctl[0] = conv ? 1.0 : 0.0;
         }
         double bx[G];
