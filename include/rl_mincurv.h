@@ -23,7 +23,8 @@
  *     changed between calls (rl_ctx_set_stream): the *_dev calls that use the arena order themselves behind the
  *     previous user of the arena with an event when the stream has changed, so two such calls enqueued on different
  *     streams without a host synchronisation in between run one after the other, never on the same scratch at once;
- *   - the only environment variables the product library reads are RL_ARITH (default arithmetic of new contexts), RL_GLOBAL_V1, RL_MT_HES_SWEEP, RL_MT_UNFUSED, RL_MT_KKT4, RL_MT_GROUPS (test
+ *   - the only environment variables the product library reads are RL_ARITH (default arithmetic of new contexts), RL_QSS_DF, RL_QSS_V1,
+ *     RL_QSS_DF_WAVES, RL_QSS_DF_BAIL_AT (QSS test hooks, see rl_ctx_set_option), RL_GLOBAL_V1, RL_MT_HES_SWEEP, RL_MT_UNFUSED, RL_MT_KKT4, RL_MT_GROUPS (test
  *     hooks selecting a second implementation, read once in rl_ctx_create) and RL_FORCE_RESIDENCY / RL_FORCE_GLOBAL_RINGS
  *     (residency of the sweep's per-instance state; all variants are bit-identical): INTEGRATION.md lists them.  Solver
  *     strategy constants are compile-time; RL_MT_* / RL_DEBUG_FLAGS overrides exist only in a -DRL_ABLATION diagnostic build;
@@ -108,6 +109,14 @@ int rl_ctx_get_arith(const rl_ctx* ctx);
  * end of outer iteration 0 (optimizer.py:333).  The fast arithmetic does not model numpy's error state: on such input a
  * step whose QP solves always refreshes the table. */
 int rl_ctx_set_numpy_raise(rl_ctx* ctx, int on);
+/* Test hooks (no effect on results: every variant returns the same bits).  name / value:
+ *   "qss_kernel"      -1 = rl_qss_sim[_dev] picks by the rounds the batch takes on the chip (default), 0 = the list-order kernel
+ *                     k_qss_sim, 1 = the dataflow kernel k_qss_dfw for every size its tables hold
+ *   "qss_df_waves"    1 | 2 | 4 waves per instance of the dataflow kernel (default 4)
+ *   "qss_df_bail_at"  g > 0: the dataflow kernel hands every instance back to the list-order kernel at iteration g (the path
+ *                     taken when its tables overflow); 0 = never
+ * Defaults come from RL_QSS_DF / RL_QSS_V1 / RL_QSS_DF_WAVES / RL_QSS_DF_BAIL_AT, read ONCE in rl_ctx_create. */
+int rl_ctx_set_option(rl_ctx* ctx, const char* name, int value);
 /* test aid: out[n,5] = yaw, cos / sin(yaw + pi/2), cos / sin(yaw - pi/2) of the tangents (dx, dy), as the
  * reference-order mode computes them (csrc/rl_crmath.hpp: correctly rounded; trajectory.py:87-92, 250) */
 int rl_debug_cr_heading(rl_ctx* ctx, const double* dx, const double* dy, int n, double* out);

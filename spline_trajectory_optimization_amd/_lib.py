@@ -46,6 +46,7 @@ _SIGNATURES = {
     "rl_ctx_set_arith": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rl_ctx_get_arith": (ctypes.c_int, [_vp]),
     "rl_ctx_set_numpy_raise": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rl_ctx_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "rl_debug_cr_heading": (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int, _dp]),
     "rl_spline_eval": (ctypes.c_int, [_vp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp,
                                       ctypes.c_int, ctypes.c_int, _dp]),
@@ -178,6 +179,10 @@ class Context:
         old = self.lib.rl_ctx_get_arith(self.h)
         check(self.lib.rl_ctx_set_arith(self.h, int(arith)))
         return old
+
+    def set_option(self, name, value):
+        """Test hooks (include/rl_mincurv.h: rl_ctx_set_option): "qss_kernel", "qss_df_waves", "qss_df_bail_at"."""
+        check(self.lib.rl_ctx_set_option(self.h, name.encode(), int(value)))
 
     def set_numpy_raise(self, on):
         """Reference-order sweep: np.seterr(all='raise') is already in effect when the driver starts

@@ -74,6 +74,12 @@ struct rl_ctx {
   bool force_global_v1 = false;  // test hook: RL_GLOBAL_V1=1 keeps the generic kernel
   int arith = RL_ARITH_FAST;     // rl_ctx_set_arith: arithmetic of the sweep (RL_ARITH_FAST / RL_ARITH_REFERENCE)
   int np_raise_at_start = 0;     // rl_ctx_set_numpy_raise: the reference-order sweep starts with np.seterr(all='raise') in effect
+  // test hooks of the QSS simulator (rl_ctx_set_option; defaults from RL_QSS_DF / RL_QSS_V1 / RL_QSS_DF_WAVES / RL_QSS_DF_BAIL_AT, read
+  // once in rl_ctx_create): which kernel (-1 = by the rounds the batch takes, 0 = list order, 1 = dataflow), waves per instance of
+  // the dataflow kernel, the iteration at which it hands every instance back (0 = never)
+  int qss_kernel = -1, qss_df_waves = 4, qss_df_bail_at = 0;
+  // largest dynamic-LDS size already granted per kernel (hipFuncSetAttribute is issued only when a call needs more)
+  std::vector<std::pair<const void*, int>> dyn_lds;
   // Device scratch owned by the context (grow-only): the *_dev entry points of the QSS simulator and the
   // min-time solve carve their work arrays out of it, so that steady-state calls allocate nothing.
   void* arena = nullptr;
@@ -106,6 +112,19 @@ struct rl_ctx {
 };
 
 namespace {
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (context, kernel, size class) instead of once per call
+hipError_t grant_dyn_lds(rl_ctx* ctx, const void* fn, size_t bytes) {
+  for (auto& e : ctx->dyn_lds)
+    if (e.first == fn) {
+      if ((size_t)e.second >= bytes) return hipSuccess;
+      const hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (r == hipSuccess) e.second = (int)bytes;
+      return r;
+    }
+  const hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (r == hipSuccess) ctx->dyn_lds.emplace_back(fn, (int)bytes);
+  return r;
+}
 // per-call device staging of the host-pointer entry points, from the context's pool (every such entry point ends
 // with a stream synchronisation, so a block is idle when it is returned)
 template <typename T>
@@ -297,8 +316,7 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, boo
 template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL, bool STRICT = false, bool RAISE = false>
 int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
   auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL, STRICT, RAISE>;
-  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RL_HIP(grant_dyn_lds(const_cast<rl_ctx*>(ctx), reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
   return RL_OK;
@@ -403,6 +421,10 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
   c->num_cu = prop.multiProcessorCount;
   if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
   if (const char* v = getenv("RL_ARITH")) c->arith = (v[0] == 'r' || v[0] == '1') ? RL_ARITH_REFERENCE : RL_ARITH_FAST;
+  if (const char* v = getenv("RL_QSS_DF")) if (v[0] == '0' || v[0] == '1') c->qss_kernel = v[0] - '0';
+  if (const char* v = getenv("RL_QSS_V1")) if (v[0] == '1') c->qss_kernel = 0;
+  if (const char* v = getenv("RL_QSS_DF_WAVES")) { const int w = atoi(v); if (w == 1 || w == 2 || w == 4) c->qss_df_waves = w; }
+  if (const char* v = getenv("RL_QSS_DF_BAIL_AT")) { const int g = atoi(v); if (g >= 0) c->qss_df_bail_at = g; }
   if (const char* v = getenv("RL_MT_HES_SWEEP")) c->mt_hes_sweep = v[0] == '1';
   if (const char* v = getenv("RL_MT_UNFUSED")) c->mt_unfused = v[0] == '1';
   if (const char* v = getenv("RL_MT_KKT4")) c->mt_kkt4 = v[0] == '1';
@@ -449,6 +471,16 @@ int rl_ctx_set_arith(rl_ctx* ctx, int arith) {
 }
 
 int rl_ctx_get_arith(const rl_ctx* ctx) { return ctx ? ctx->arith : RL_ERR_ARG; }
+
+int rl_ctx_set_option(rl_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return fail(RL_ERR_ARG, "null argument");
+  const std::string k(name);
+  if (k == "qss_kernel") { if (value < -1 || value > 1) return fail(RL_ERR_ARG, "qss_kernel: -1 (auto), 0 (list order), 1 (dataflow)"); ctx->qss_kernel = value; }
+  else if (k == "qss_df_waves") { if (value != 1 && value != 2 && value != 4) return fail(RL_ERR_ARG, "qss_df_waves: 1, 2 or 4"); ctx->qss_df_waves = value; }
+  else if (k == "qss_df_bail_at") { if (value < 0) return fail(RL_ERR_ARG, "qss_df_bail_at >= 0"); ctx->qss_df_bail_at = value; }
+  else return fail(RL_ERR_ARG, "unknown option '" + k + "'");
+  return RL_OK;
+}
 
 int rl_ctx_set_numpy_raise(rl_ctx* ctx, int on) {
   if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
@@ -945,8 +977,7 @@ int global_tables(const rl_ctx* ctx, const rl_track* trk) {
 template <int K, int MAXB>
 int launch_global_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block, size_t lds) {
   auto kern = rl::k_global_qp<K, MAXB>;
-  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RL_HIP(grant_dyn_lds(const_cast<rl_ctx*>(ctx), reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3(B), dim3(block), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
   return RL_OK;
@@ -955,8 +986,7 @@ int launch_global_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block
 template <int K, int R, int G, bool AREG>
 int launch_global2_t(const rl_ctx* ctx, const rl::GlobalArgs& a, int B, int block, size_t lds) {
   auto kern = rl::k_global_qp2<K, R, G, AREG>;
-  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RL_HIP(grant_dyn_lds(const_cast<rl_ctx*>(ctx), reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3(B), dim3(block), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
   return RL_OK;
@@ -1102,8 +1132,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   a.max_lon_acc = params[0]; a.max_lon_dcc = params[1]; a.max_left_acc = params[2];
   a.max_right_acc = params[3]; a.max_speed = params[4]; a.max_jerk = params[5];
   a.flags = dfl; a.fresh = dnw; a.cst = dcst; a.cap = cap; a.iters = iters;
-  a.tab_n = 0; a.redo = 0; a.dbg = nullptr; a.df_bail_at = 0;
-  if (const char* ba = getenv("RL_QSS_DF_BAIL_AT")) a.df_bail_at = atoi(ba);
+  a.tab_n = 0; a.redo = 0; a.dbg = nullptr; a.df_bail_at = ctx->qss_df_bail_at;
   if (by_value) {
     double* q = a.tab;
     for (int i = 0; i <= acc_m; ++i) *q++ = acc_x[i];
@@ -1117,8 +1146,6 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   // Which kernel: the dataflow kernel finishes an instance 2 - 4.5 times sooner but its tables fill the LDS (one instance per CU at
   // N = 2000, three at N = 500), the list-order kernel holds four and more per CU.  Compare the number of ROUNDS the batch
   // takes on the chip (measured); RL_QSS_DF=1 / 0 forces one or the other (tests run both).
-  const char* v1 = getenv("RL_QSS_V1");
-  const char* fdf = getenv("RL_QSS_DF");
   bool use_df = rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
   if (use_df) {
     const long long per_cu_df = (long long)((size_t)ctx->max_lds / rl::df_layout(N, acc_m, dcc_m).bytes);
@@ -1126,35 +1153,38 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     per_cu_list = per_cu_list > 8 ? 8 : per_cu_list;
     const long long cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
     const long long rounds_df = (B + per_cu_df * cus - 1) / (per_cu_df * cus), rounds_list = (B + per_cu_list * cus - 1) / (per_cu_list * cus);
-    use_df = rounds_df <= 4 * rounds_list;   // (a round of the dataflow kernel takes 1/5 (N = 2000) ... 1/2 (N = 500) of a list-order round)
+    // a round of the dataflow kernel takes from 1/5 (N = 2000: 29 against 168 ms) to 1/2 (N = 500: 4.4 against 9.3 ms) of a
+    // list-order round: the ratio the comparison allows grows with N between those two measurements
+    const double ratio = N <= 500 ? 2.0 : (N >= 2000 ? 5.0 : 2.0 + 3.0 * (double)(N - 500) / 1500.0);
+    use_df = (double)rounds_df <= ratio * (double)rounds_list;
   }
-  if (fdf && (fdf[0] == '0' || fdf[0] == '1')) use_df = fdf[0] == '1' && rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
-  if (v1 && v1[0] == '1') use_df = false;
+  if (ctx->qss_kernel == 0) use_df = false;
+  if (ctx->qss_kernel == 1) use_df = rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
   if (use_df) {
     const size_t lds_df = rl::df_layout(N, acc_m, dcc_m).bytes;
-    const char* dbg = getenv("RL_QSS_DEBUG");
     int* ddbg = nullptr;
-    if (dbg && dbg[0] == '1') { RL_HIP(hipMalloc(&ddbg, (size_t)B * 12 * sizeof(int))); a.dbg = ddbg; }
-    // RL_QSS_DF_WAVES = 1 / 2 / 4: waves of the (one) workgroup an instance's tables leave room for; four is the fastest at every
-    // size measured, the others exist for the tests.
-    int df_waves = 4;
-    if (const char* dw = getenv("RL_QSS_DF_WAVES")) df_waves = atoi(dw);
-    if (df_waves == 1) {
-      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+#ifdef RL_ABLATION
+    if (const char* dbg = getenv("RL_QSS_DEBUG")) if (dbg[0] == '1') { RL_HIP(hipMalloc(&ddbg, (size_t)B * 12 * sizeof(int))); a.dbg = ddbg; }
+#endif
+    // waves of the (one) workgroup an instance's tables leave room for: four is the fastest at every size measured
+    // (DESIGN.md 3c); one and two exist for the tests (rl_ctx_set_option "qss_df_waves")
+    if (ctx->qss_df_waves == 1) {
+      RL_HIP(grant_dyn_lds(ctx, reinterpret_cast<const void*>(rl::k_qss_dfw<1>), lds_df));
       hipLaunchKernelGGL(rl::k_qss_dfw<1>, dim3(B), dim3(64), lds_df, ctx->stream, a);
-    } else if (df_waves == 2) {
-      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+    } else if (ctx->qss_df_waves == 2) {
+      RL_HIP(grant_dyn_lds(ctx, reinterpret_cast<const void*>(rl::k_qss_dfw<2>), lds_df));
       hipLaunchKernelGGL(rl::k_qss_dfw<2>, dim3(B), dim3(128), lds_df, ctx->stream, a);
     } else {
-      RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_dfw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_df));
+      RL_HIP(grant_dyn_lds(ctx, reinterpret_cast<const void*>(rl::k_qss_dfw<4>), lds_df));
       hipLaunchKernelGGL(rl::k_qss_dfw<4>, dim3(B), dim3(256), lds_df, ctx->stream, a);
     }
     RL_HIP(hipGetLastError());
-    if (ddbg) {   // diagnostics only: synchronous
+    if (ddbg) {   // diagnostic build only: synchronous
       std::vector<int> hd((size_t)B * 12);
       RL_HIP(hipStreamSynchronize(ctx->stream));
-      RL_HIP(hipMemcpy(hd.data(), ddbg, hd.size() * sizeof(int), hipMemcpyDeviceToHost));
-      RL_HIP(hipFree(ddbg));
+      const hipError_t ce = hipMemcpy(hd.data(), ddbg, hd.size() * sizeof(int), hipMemcpyDeviceToHost);
+      (void)hipFree(ddbg);
+      RL_HIP(ce);
       long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int handed = 0;
       for (int i = 0; i < B; ++i) { for (int q = 0; q < 8; ++q) tot[q] += hd[(size_t)i * 12 + q]; handed += hd[(size_t)i * 12 + 7] != 0; }
       fprintf(stderr, "k_qss_dfw: B=%d N=%d lds=%zu  per instance: passes %.0f chunks %.0f examinations %.0f steps %.0f longest queue %.0f numberings %.0f spawned %.0f; handed back %d (reason of instance 0: %d)\n",
@@ -1164,7 +1194,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     }
     a.redo = 1;
   }
-  RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rl::k_qss_sim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RL_HIP(grant_dyn_lds(ctx, reinterpret_cast<const void*>(rl::k_qss_sim), lds));
   hipLaunchKernelGGL(rl::k_qss_sim, dim3(B), dim3(64), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
   RL_HIP(ar.end());

@@ -604,6 +604,19 @@ def test_drop_in_api(rl, fits, rings):
     assert dev3 < TIGHT_M
 
 
+@contextlib.contextmanager
+def qss_options(rl, qss_kernel=-1, qss_df_waves=4, qss_df_bail_at=0):
+    """The simulator's test hooks for the calls inside (rl_ctx_set_option), the defaults again afterwards."""
+    ctx = rl.lib.Context.get(0)
+    try:
+        for k_, v_ in (("qss_kernel", qss_kernel), ("qss_df_waves", qss_df_waves), ("qss_df_bail_at", qss_df_bail_at)):
+            ctx.set_option(k_, v_)
+        yield ctx
+    finally:
+        for k_, v_ in (("qss_kernel", -1), ("qss_df_waves", 4), ("qss_df_bail_at", 0)):
+            ctx.set_option(k_, v_)
+
+
 def _sim_inputs():
     from scipy.interpolate import CubicSpline
     g = golden("G6_simulator.npz")
@@ -663,16 +676,15 @@ def test_qss_dataflow_same_bits_whatever_the_timing(rl, monkeypatch):
     from instance to instance, the RESULT may not: 96 copies of one trajectory in one launch (different CUs, different timing) and
     three launches return the same bits."""
     g, pts, veh = _sim_inputs()
-    monkeypatch.setenv("RL_QSS_DF", "1")
-    monkeypatch.delenv("RL_QSS_DF_WAVES", raising=False)
     first = None
-    for rep in range(3):
-        out, it = rl.ops.qss_sim(np.repeat(pts[None], 96, axis=0), *veh)
-        if first is None:
-            first = (out[0].copy(), int(it[0]))
-        assert (np.asarray(it) == first[1]).all()
-        for b in range(out.shape[0]):
-            np.testing.assert_array_equal(out[b], first[0])
+    with qss_options(rl, qss_kernel=1, qss_df_waves=4):
+        for rep in range(3):
+            out, it = rl.ops.qss_sim(np.repeat(pts[None], 96, axis=0), *veh)
+            if first is None:
+                first = (out[0].copy(), int(it[0]))
+            assert (np.asarray(it) == first[1]).all()
+            for b in range(out.shape[0]):
+                np.testing.assert_array_equal(out[b], first[0])
 
 
 def test_qss_sizes_around_the_dataflow_tables(rl, fits, monkeypatch):
@@ -680,15 +692,14 @@ def test_qss_sizes_around_the_dataflow_tables(rl, fits, monkeypatch):
     they do (N = 2110; and 2048) and the smallest (N = 256; below it the list order again), each against the oracle."""
     g, pts, veh = _sim_inputs()
     t, cx, cy, k, length = spline(fits, "c100")
-    for k_ in ("RL_QSS_DF", "RL_QSS_DF_WAVES", "RL_QSS_DF_BAIL_AT"):
-        monkeypatch.delenv(k_, raising=False)
-    for N in (200, 256, 2048, 2110, 2200):
-        p = orc.sample_along(t, cx, cy, k, length, np.linspace(0, 1, N, endpoint=False))
-        out, it = rl.ops.qss_sim(p, *veh)
-        ref, oit = orc.qss_sim(p, *veh)
-        assert int(np.atleast_1d(it)[0]) == oit > 5, N
-        np.testing.assert_array_equal(out[:, 18], ref[:, 18])
-        np.testing.assert_allclose(out[:, [4, 14, 15, 16]], ref[:, [4, 14, 15, 16]], rtol=0, atol=1e-10)
+    with qss_options(rl):          # the defaults: rl_qss_sim picks the kernel
+        for N in (200, 256, 2048, 2110, 2200):
+            p = orc.sample_along(t, cx, cy, k, length, np.linspace(0, 1, N, endpoint=False))
+            out, it = rl.ops.qss_sim(p, *veh)
+            ref, oit = orc.qss_sim(p, *veh)
+            assert int(np.atleast_1d(it)[0]) == oit > 5, N
+            np.testing.assert_array_equal(out[:, 18], ref[:, 18])
+            np.testing.assert_allclose(out[:, [4, 14, 15, 16]], ref[:, [4, 14, 15, 16]], rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize("kernel", ["dataflow, one wave", "dataflow, four waves", "list-order"])  # k_qss_dfw<1>, <4>; k_qss_sim
@@ -714,16 +725,13 @@ def test_qss_kernels_bitwise_equal_and_hand_back(rl, monkeypatch):
     taken when its tables overflow)."""
     g, pts, veh = _sim_inputs()
     res = {}
-    for name, env in (("list", {"RL_QSS_DF": "0"}), ("flow", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "1"}),
-                      ("flow2", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "2"}), ("flow4", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "4"}),
-                      ("back", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "1", "RL_QSS_DF_BAIL_AT": "40"}),
-                      ("back4", {"RL_QSS_DF": "1", "RL_QSS_DF_WAVES": "4", "RL_QSS_DF_BAIL_AT": "40"})):
-        for k in ("RL_QSS_DF", "RL_QSS_DF_BAIL_AT", "RL_QSS_DF_WAVES"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        one, it1 = rl.ops.qss_sim(pts, *veh)
-        many, itb = rl.ops.qss_sim(np.repeat(pts[None], 5, axis=0), *veh)
+    for name, opt in (("list", dict(qss_kernel=0)), ("flow", dict(qss_kernel=1, qss_df_waves=1)),
+                      ("flow2", dict(qss_kernel=1, qss_df_waves=2)), ("flow4", dict(qss_kernel=1, qss_df_waves=4)),
+                      ("back", dict(qss_kernel=1, qss_df_waves=1, qss_df_bail_at=40)),
+                      ("back4", dict(qss_kernel=1, qss_df_waves=4, qss_df_bail_at=40))):
+        with qss_options(rl, **opt):
+            one, it1 = rl.ops.qss_sim(pts, *veh)
+            many, itb = rl.ops.qss_sim(np.repeat(pts[None], 5, axis=0), *veh)
         res[name] = (one, int(np.atleast_1d(it1)[0]), many, np.asarray(itb))
     for name in ("flow", "flow2", "flow4", "back", "back4"):
         np.testing.assert_array_equal(res[name][0], res["list"][0])

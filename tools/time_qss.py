@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from scipy.interpolate import CubicSpline
-from spline_trajectory_optimization_amd import batch, ops
+from spline_trajectory_optimization_amd import _lib, batch, ops
 
 acc = CubicSpline([0.0, 50.0, 100.0], [10.0, 7.0, 0.5]); dcc = CubicSpline([0.0, 50.0, 100.0], [-13.0, -15.0, -20.0])
 veh = (acc.x, acc.c, dcc.x, dcc.c, np.array([10.0, -20.0, 15.0, -15.0, 100.0, 30.0]))
@@ -20,10 +20,8 @@ for N in (2000, 500):
     for B in Bs:
         P = np.repeat(pts[None], B, axis=0) if B > 1 else pts
         for name, val in modes:
-            if val is None:
-                os.environ.pop("RL_QSS_DF", None)
-            else:
-                os.environ["RL_QSS_DF"] = val
+            # RL_QSS_DF only sets the default of a new context (read once): switch per call with the option hook
+            _lib.Context.get().set_option("qss_kernel", -1 if val is None else int(val))
             ops.qss_sim(P, *veh)
             best = 1e9
             for _ in range(2):
