@@ -194,7 +194,8 @@ def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref
         d = {bi: float(np.hypot(ctrl[bi, :, 0] - rc[0], ctrl[bi, :, 1] - rc[1]).max()) for bi, rc in ref_run.items()}
         leg["gpu_vs_reference_run"] = {"instances": sorted(d), "dev_m": [d[b_] for b_ in sorted(d)],
                                        "within_1e-4": int(sum(v <= 1e-4 for v in d.values())),
-                                       "fixture": "tests/golden/G7b_benchmarked_config.npz (the reference's own loop, numpy on glibc)"}
+                                       "fixture": "tests/golden/G7b_benchmarked_config.npz, G7d_benchmarked_batch_sample.npz (the reference's own "
+                                                  "loop, numpy on glibc)"}
     return leg
 
 
@@ -499,15 +500,16 @@ def run_rank(args):
     # tests/golden/make_golden.py): take their widths from the fixture bit for bit (the batch's own base widths come from
     # this GPU's fill_bounds and agree with the fixture's to ~1e-10 m only), so that the result can be laid beside that run.
     ref_run = {}
-    g7b_path = os.path.join(ROOT, "tests", "golden", "G7b_benchmarked_config.npz")
-    if rank == 0 and b_monza > 3 and os.path.exists(g7b_path):
-        g7b = np.load(g7b_path)
-        for key in [str(k_) for k_ in g7b["cases"] if "bench" in str(k_)]:
-            bi = int(key.split("bench")[1])
-            if np.abs(groups[0]["widths"][bi] - g7b[f"{key}_widths"]).max() < 1e-6 and \
-                    np.array_equal(g7b[f"{key}_i_start"], batch.default_i_start(len(cx), k, MAX_ITER, seed=0)):
-                groups[0]["widths"][bi] = g7b[f"{key}_widths"]
-                ref_run[bi] = (g7b[f"{key}_cx"], g7b[f"{key}_cy"])
+    for fname in ("G7b_benchmarked_config.npz", "G7d_benchmarked_batch_sample.npz"):   # G7d (round 5): instances 1, 2, 4 ... 7
+        g7b_path = os.path.join(ROOT, "tests", "golden", fname)
+        if rank == 0 and b_monza > 7 and os.path.exists(g7b_path):
+            g7b = np.load(g7b_path)
+            for key in [str(k_) for k_ in g7b["cases"] if "bench" in str(k_)]:
+                bi = int(key.split("bench")[1])
+                if np.abs(groups[0]["widths"][bi] - g7b[f"{key}_widths"]).max() < 1e-6 and \
+                        np.array_equal(g7b[f"{key}_i_start"], batch.default_i_start(len(cx), k, MAX_ITER, seed=0)):
+                    groups[0]["widths"][bi] = g7b[f"{key}_widths"]
+                    ref_run[bi] = (g7b[f"{key}_cx"], g7b[f"{key}_cy"])
     if args.workload == "mixed":
         oval = batch.oval_centerline(SPLINE_S, SPLINE_K)
         ot, ocx, ocy, ok_ = oval._tck()
@@ -709,8 +711,8 @@ def run_rank(args):
             per = {d_["instance"]: d_ for d_ in res.get("cpu_baseline", {}).get("gpu_vs_oracle", {}).get("per_instance", [])}
             res["gpu_vs_reference_run"] = {
                 "what": "instances of THIS batch that also exist as a run of the reference's own run_min_curvature_qp loop "
-                        "(fixture tests/golden/G7b_benchmarked_config.npz: same widths bit for bit, same sweep order); "
-                        "max control-point deviation [m]",
+                        "(fixtures tests/golden/G7b_benchmarked_config.npz, G7d_benchmarked_batch_sample.npz: same widths bit for bit, "
+                        "same sweep order); max control-point deviation [m]",
                 "instances": sorted(dev_ref), "dev_m": [dev_ref[b_] for b_ in sorted(dev_ref)],
                 "within_1e-4": int(sum(v <= 1e-4 for v in dev_ref.values())),
                 "nearest_branch_dev_m": [per.get(b_, {}).get("nearest_branch_dev_m") for b_ in sorted(dev_ref)],

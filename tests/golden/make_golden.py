@@ -272,8 +272,8 @@ def main():
     right = load_xy("MONZA_RIGHT_BOUNDARY_enu.csv")
 
     def want(tag):
-        if tag == "G7b":                 # ~6 CPU-minutes per case: only on request
-            return args.only == "G7b"
+        if tag in ("G7b", "G7d"):        # ~6 CPU-minutes per case: only on request
+            return args.only == tag
         if tag == "G12" and args.only == "G12":
             return True
         return args.only is None or args.only == tag
@@ -436,23 +436,28 @@ def main():
     # executed by the reference's own loop: three runs on the real Monza rings and two on instances of bench.py's own
     # width-perturbed batch (rings p0 +- w n0, sweep order of batch.default_i_start(seed 0) = np.random.seed(0)).
     # One subprocess per case (python make_golden.py --only G7b); ~6 minutes each.
-    if want("G7b"):
+    # G7d (round 5): the same for instances 1, 2, 4, 5, 6, 7 of bench.py's batch -- with G7b's 0 and 3 the WHOLE sample
+    # bench.py lays beside the CPU oracle then also exists as runs of the reference's own loop.
+    if want("G7b") or want("G7d"):
         from spline_trajectory_optimization_amd import batch as amd_batch
+        g7tag = "G7d" if args.only == "G7d" else "G7b"
         cases = [("rings", 2000, 5, 11, -1), ("rings", 2000, 5, 12, -1), ("rings", 1929, 5, 13, -1),
                  ("bench", 2000, 5, 0, 0), ("bench", 2000, 5, 0, 3)]
+        if g7tag == "G7d":
+            cases = [("bench", 2000, 5, 0, b_) for b_ in (1, 2, 4, 5, 6, 7)]
         names = [f"c100_N{N}_it{it}_seed{sd}" + (f"_bench{b}" if kind == "bench" else "") for kind, N, it, sd, b in cases]
         if args.case is None:
             import subprocess
             import tempfile
             tmp = tempfile.mkdtemp()
-            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--only", "G7b", "--case", str(ci),
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--only", g7tag, "--case", str(ci),
                                        "--out", os.path.join(tmp, f"{ci}.npz")]) for ci in range(len(cases))]
             assert all(p.wait() == 0 for p in procs)
             kw = {"cases": np.array(names)}
             for ci in range(len(cases)):
                 d = np.load(os.path.join(tmp, f"{ci}.npz"))
                 kw.update({k_: d[k_] for k_ in d.files})
-            save("G7b_benchmarked_config.npz", **kw)
+            save("G7b_benchmarked_config.npz" if g7tag == "G7b" else "G7d_benchmarked_batch_sample.npz", **kw)
         else:
             kind, N, max_iter, seed, b = cases[args.case]
             key = names[args.case]

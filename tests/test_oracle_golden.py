@@ -229,6 +229,20 @@ def test_g7b_benchmarked_configuration(fits, rings):
     per-pass success counts, lines within 1e-5 m (measured 2e-11 .. 4e-6 m)."""
     from concurrent.futures import ThreadPoolExecutor
     g = golden("G7b_benchmarked_config.npz")
+    _check_reference_runs(g, fits, rings, n_cases=5, n_bench=2)
+
+
+@pytest.mark.slow
+def test_g7d_benchmarked_batch_sample(fits, rings):
+    """Fixture G7d (round 5): the reference's own loop for instances 1, 2, 4, 5, 6, 7 of bench.py's batch -- with G7b's 0 and 3
+    the whole sample bench.py lays beside the oracle.  The oracle reproduces all six lines to <= 1.8e-6 m with the reference's
+    success counts in every pass but the last, where on two of the six one QP is decided the other way (numpy's matrix products
+    sum in another order than the oracle's loop: the control point then differs in its last bits)."""
+    _check_reference_runs(golden("G7d_benchmarked_batch_sample.npz"), fits, rings, n_cases=6, n_bench=6)
+
+
+def _check_reference_runs(g, fits, rings, n_cases, n_bench):
+    from concurrent.futures import ThreadPoolExecutor
     t, cx, cy, k, length = spline(fits, "c100")
 
     def run(key):
@@ -237,11 +251,16 @@ def test_g7b_benchmarked_configuration(fits, rings):
         ocx, ocy, pts, ns = orc.run_min_curvature_qp(t, cx, cy, k, length, N, rl_, rr_, g[f"{key}_i_start"])
         return key, ns, float(np.hypot(ocx - g[f"{key}_cx"], ocy - g[f"{key}_cy"]).max())
     keys = [str(k_) for k_ in g["cases"]]
-    assert len(keys) == 5 and sum("bench" in k_ for k_ in keys) == 2
+    assert len(keys) == n_cases and sum("bench" in k_ for k_ in keys) == n_bench
     with ThreadPoolExecutor(len(keys)) as ex:       # ctypes releases the GIL: one case per thread
         for key, ns, dev in ex.map(run, keys):
             print(key, "oracle vs the reference's run [m]:", dev, "successes", ns.ravel().tolist())
-            np.testing.assert_array_equal(ns, g[f"{key}_n_success"])
+            if n_cases == 5:     # G7b: identical per-pass success counts on all five
+                np.testing.assert_array_equal(ns, g[f"{key}_n_success"])
+            else:                # G7d: on two of six (bench1, bench6) ONE QP of the last backward pass flips in the noise
+                ref_ns = g[f"{key}_n_success"]
+                np.testing.assert_array_equal(ns.ravel()[:-1], ref_ns.ravel()[:-1])
+                assert abs(int(ns.ravel()[-1]) - int(ref_ns.ravel()[-1])) <= 1
             assert len(g[f"{key}_i_start"]) == 5 and dev < 1e-5, (key, dev)
 
 
