@@ -18,6 +18,12 @@
  *     qpOASES itself; pinned through KKT residual tests instead.
  *   - fill_bounds (shapely/GEOS LineString.intersection(LinearRing), absent as well) is
  *     restated geometrically: PARITY UNPINNED against GEOS.
+ *   - atan2 / cos / sin of the sampled heading (numpy -> the platform libm): the platform's in the default
+ *     build, the correctly rounded values (libquadmath) in the -DORC_LIBM_CR build (oracle/Makefile); both
+ *     builds pass the same fixture tests with the same numbers.
+ *   - numpy's error state (np.seterr(all='raise'), which the reference's simulator leaves the process in) is
+ *     modelled in the two drivers (orc_set_numpy_raise) and pinned by fixture G12, runs of the reference's own
+ *     loops in that state.
  */
 #ifndef MINCURV_ORACLE_H
 #define MINCURV_ORACLE_H

@@ -29,8 +29,9 @@ for line in open(os.path.join(src, "stats.log")):
 
 
 def match(name, pattern):
-    """pattern = "substring" or "substring|last template argument": k_sweep's instantiations differ in their last
-    template argument (STRICT: the reference-order arithmetic)."""
+    """pattern = "substring" or "substring|end of the template argument list": k_sweep's instantiations differ in their
+    last two template arguments (STRICT: the reference-order arithmetic; RAISE: its numpy-error-state variant, which
+    returns at once for instances that do not need it)."""
     sub, _, last = pattern.partition("|")
     if sub not in name:
         return False
@@ -70,7 +71,8 @@ def per_kernel(pattern):
 
 
 kernels = {}
-for name, pat in (("k_sweep", "k_sweep<|false"), ("k_sweep_reference_order", "k_sweep<|true"), ("k_global_qp", "k_global_qp")):
+for name, pat in (("k_sweep", "k_sweep<|false, false"), ("k_sweep_reference_order", "k_sweep<|true, false"),
+                  ("k_sweep_reference_order_raise", "k_sweep<|true, true"), ("k_global_qp", "k_global_qp")):
     k = per_kernel(pat)
     if k:
         kernels[name] = k
