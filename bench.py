@@ -146,7 +146,7 @@ def cpu_legs(groups, i_starts, xy_gpu, ninst_total):
     return cb, pos
 
 
-def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref_run):
+def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref_run, fast_ns_all=None):
     """The same batch through the sweep's REFERENCE-ORDER arithmetic (RL_ARITH_REFERENCE, include/rl_mincurv.h): the
     reference's operations in the reference's order, which returns the oracle's bits.  Timed like the headline (events on
     the launch stream around each of `steps` launches after a warm-up); compared, on the cpu_baseline sample, with the
@@ -166,6 +166,7 @@ def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     B = g["widths"].shape[0]
     xy = out["xy"].cpu().numpy(); ctrl = out["ctrl"].cpu().numpy(); ns = out["n_success"].cpu().numpy()
+    fast_xy_all = fast_xy
     leg = {"what": "the headline batch in RL_ARITH_REFERENCE: unfused de Boor recurrences and sums, splder derivative splines in the "
                    "cost, sequential cost sums, unfused cross products, correctly rounded atan2 / cos / sin (csrc/rl_crmath.hpp)",
            "kernel": "k_sweep<..., STRICT>", "kernel_ms": ms, "solves_per_s": B / ms * 1e3, "steps": args.steps,
@@ -190,6 +191,31 @@ def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref
                                         "control points, sampled line and success counts compared as bit patterns",
             "cr_oracle_vs_libm_oracle_dev_m_max": float(np.abs(oxy - po.xy0).max()),
             "fast_arithmetic_dev_m_median": float(np.median(np.abs(fast_xy[:m] - po.xy0).reshape(m, -1).max(axis=1)))}
+    # the WHOLE batch: the reference-order result is the oracle's bits (checked on the sample above), so it is the oracle for
+    # every instance -- how far the cheaper arithmetic modes end from it
+    try:
+        br = ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search, arith=_lib.ARITH_BRANCH)
+        torch.cuda.synchronize()
+        evb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a_, b_ in evb:
+            a_.record()
+            ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search, out=br, arith=_lib.ARITH_BRANCH)
+            b_.record()
+        torch.cuda.synchronize()
+        whole = {"oracle": "the reference-order result of every instance (bit-identical to the CPU oracle on the sample)"}
+        for name, other_xy, other_ns in (("fast", fast_xy_all, fast_ns_all), ("branch", br["xy"].cpu().numpy(), br["n_success"].cpu().numpy())):
+            dv = np.abs(other_xy - xy).reshape(B, -1).max(axis=1)
+            whole[name] = {"dev_m_median": float(np.median(dv)), "dev_m_p99": float(np.quantile(dv, 0.99)), "dev_m_max": float(dv.max()),
+                           "instances_beyond_1e-4_m": int((dv > 1e-4).sum()), "instances": B,
+                           "instances_with_other_success_counts": int((other_ns.reshape(B, -1) != ns.reshape(B, -1)).any(axis=1).sum())}
+        whole["branch"]["kernel_ms"] = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evb]))
+        whole["branch"]["what"] = ("RL_ARITH_BRANCH: positions, ring crossings, bound points and rows in the reference's order; normals from a "
+                                   "reciprocal square root, cost sums from the fast tables in a tree")
+        whole["reading"] = ("the reference's formulation is chaotic in the last bits (DESIGN.md 5): every operation that rounds differently moves a few "
+                            "per cent of the instances to another branch; only the reference-order arithmetic stays on the oracle's")
+        leg["whole_batch_vs_reference_order"] = whole
+    except Exception as e:
+        leg["whole_batch_vs_reference_order"] = {"error": f"{type(e).__name__}: {e}"}
     if ref_run:
         d = {bi: float(np.hypot(ctrl[bi, :, 0] - rc[0], ctrl[bi, :, 1] - rc[1]).max()) for bi, rc in ref_run.items()}
         leg["gpu_vs_reference_run"] = {"instances": sorted(d), "dev_m": [d[b_] for b_ in sorted(d)],
@@ -517,7 +543,7 @@ def run_rank(args):
         groups.append({"name": "oval", "t": ot, "cx": ocx, "cy": ocy, "k": ok_, "length": oval.get_length(),
                        "widths": batch.width_batch(owl, owr, B // 2, seed=5678 + rank)})
     search = {"windowed": _lib.SEARCH_WINDOWED, "culled": _lib.SEARCH_CULLED, "brute": _lib.SEARCH_BRUTE}[args.search]
-    ctx.set_arith(_lib.ARITH_REFERENCE if args.arith == "reference" else _lib.ARITH_FAST)   # of the headline's launches
+    ctx.set_arith({"fast": _lib.ARITH_FAST, "reference": _lib.ARITH_REFERENCE, "branch": _lib.ARITH_BRANCH}[args.arith])   # of the headline's launches
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in groups[1:]]
     for g in groups:
         g["n"] = len(g["cx"])
@@ -664,7 +690,8 @@ def run_rank(args):
                 "control_point_qps_per_s": qps_per_step * world * args.steps / elapsed, "search": args.search,
                 "arith": args.arith + (" (fma, rsqrt normal, tree sums: a legal rounding of the reference's arithmetic; the reference-order "
                                        "mode is the `reference_order` leg)" if args.arith == "fast" else
-                                       " (RL_ARITH_REFERENCE: the reference's operations in the reference's order)"),
+                                       (" (RL_ARITH_REFERENCE: the reference's operations in the reference's order)" if args.arith == "reference" else
+                                        " (RL_ARITH_BRANCH: positions, crossings, bound points and rows in the reference's order, the rest fast)")),
                 "parallelism": f"{world} rank(s) x independent instances"
                                + (f", 1 gather to rank 0 per step and group over torch.distributed backend "
                                   f"'{dist.get_backend()}' ({'gloo: --share-gpu test hook' if args.share_gpu else 'nccl = RCCL over xGMI'})"
@@ -675,7 +702,7 @@ def run_rank(args):
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": prof.get("hbm_bytes_fetch_x2") if prof else None,
                          "traffic_source": prof.get("source") if prof else None, "traffic_measured_in_run": False,
-                         "kernel": "k_sweep" if args.arith == "fast" else "k_sweep<..., STRICT>", "kernel_ms": kernel_ms,
+                         "kernel": {"fast": "k_sweep", "reference": "k_sweep<..., STRICT>", "branch": "k_sweep<..., STRICT, LITE>"}[args.arith], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
                          "actual_limiter": "latency of one step's dependent chain at the occupancy the batch allows (4 "
                                            "workgroups per CU; VALU ~59 % active, 61 % of wave cycles waiting); the solver "
@@ -704,7 +731,7 @@ def run_rank(args):
         if world == 1 and args.workload == "monza" and args.arith == "fast" and not args.no_reference_order:
             try:
                 res["reference_order"] = reference_order_leg(groups[0], args, torch, search, kernel_ms, xy_gpu[0],
-                                                             pos[0] if pos else None, ref_run)
+                                                             pos[0] if pos else None, ref_run, fast_ns_all=ns_gpu[0])
             except Exception as e:
                 res["reference_order"] = {"error": f"{type(e).__name__}: {e}"}
         if ref_run:
@@ -761,7 +788,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--workload", choices=["monza", "mixed"], default="monza")
     ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
-    ap.add_argument("--arith", choices=["fast", "reference"], default="fast",
+    ap.add_argument("--arith", choices=["fast", "reference", "branch"], default="fast",
                     help="arithmetic of the headline's launches (include/rl_mincurv.h: RL_ARITH_*)")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the reference-order leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

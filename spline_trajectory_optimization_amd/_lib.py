@@ -16,7 +16,7 @@ NCOL = 19
 MAX_ITER = 32
 BOUNDS_SHARED_RINGS, BOUNDS_WIDTHS, BOUNDS_POINTS = 0, 1, 2
 SEARCH_BRUTE, SEARCH_CULLED, SEARCH_WINDOWED = 0, 1, 2
-ARITH_FAST, ARITH_REFERENCE = 0, 1   # include/rl_mincurv.h: RL_ARITH_*
+ARITH_FAST, ARITH_REFERENCE, ARITH_BRANCH = 0, 1, 2   # include/rl_mincurv.h: RL_ARITH_*
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)

@@ -313,18 +313,23 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, boo
   return p;
 }
 
-template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL, bool STRICT = false, bool RAISE = false>
+template <int K, int BLOCK, bool RL, bool JOINT = false, bool DUMP = false, bool SL = RL, bool STRICT = false, bool RAISE = false,
+          bool LITE = false>
 int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
-  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL, STRICT, RAISE>;
+  auto kern = rl::k_sweep<K, BLOCK, RL, JOINT, DUMP, SL, STRICT, RAISE, LITE>;
   RL_HIP(grant_dyn_lds(const_cast<rl_ctx*>(ctx), reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), lds, ctx->stream, a);
   RL_HIP(hipGetLastError());
   return RL_OK;
 }
 
-int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false, bool strict = false) {
-  if (strict) {   // RL_ARITH_REFERENCE: the degree-5 sweep (the reference's wrap is written for k = 5, optimizer.py:281-285)
-    if (joint || k != 5 || a.dbg) return fail(RL_ERR_UNSUPPORTED, "reference-order arithmetic: run_min_curvature_qp on a degree-5 spline, no step dump");
+int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false, bool strict = false,
+                 bool lite = false) {
+  if (strict) {   // RL_ARITH_REFERENCE / _BRANCH: the degree-5 sweep (the reference's wrap is written for k = 5, optimizer.py:281-285)
+    if (joint || k != 5 || a.dbg) return fail(RL_ERR_UNSUPPORTED, "reference-order / branch arithmetic: run_min_curvature_qp on a degree-5 spline, no step dump");
+    if (lite)     // RL_ARITH_BRANCH
+      return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, false, true, true, false, true>(ctx, a, p.lds_bytes)
+                            : launch_sweep_t<5, 256, false, false, false, false, true, false, true>(ctx, a, p.lds_bytes);
     // the plain kernel flags the instances that need numpy's error state modelled (a sample of exactly zero curvature while
     // numpy is in raise mode); the RAISE instantiation behind it redoes those and returns at once on all others
     if (int rc = p.rings_in_lds ? launch_sweep_t<5, 256, true, false, false, true, true>(ctx, a, p.lds_bytes)
@@ -420,7 +425,7 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
   }
   c->num_cu = prop.multiProcessorCount;
   if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
-  if (const char* v = getenv("RL_ARITH")) c->arith = (v[0] == 'r' || v[0] == '1') ? RL_ARITH_REFERENCE : RL_ARITH_FAST;
+  if (const char* v = getenv("RL_ARITH")) c->arith = (v[0] == 'r' || v[0] == '1') ? RL_ARITH_REFERENCE : ((v[0] == 'b' || v[0] == '2') ? RL_ARITH_BRANCH : RL_ARITH_FAST);
   if (const char* v = getenv("RL_QSS_DF")) if (v[0] == '0' || v[0] == '1') c->qss_kernel = v[0] - '0';
   if (const char* v = getenv("RL_QSS_V1")) if (v[0] == '1') c->qss_kernel = 0;
   if (const char* v = getenv("RL_QSS_DF_WAVES")) { const int w = atoi(v); if (w == 1 || w == 2 || w == 4) c->qss_df_waves = w; }
@@ -465,7 +470,8 @@ int rl_ctx_set_stream(rl_ctx* ctx, void* hip_stream) {
 
 int rl_ctx_set_arith(rl_ctx* ctx, int arith) {
   if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
-  if (arith != RL_ARITH_FAST && arith != RL_ARITH_REFERENCE) return fail(RL_ERR_ARG, "arith must be RL_ARITH_FAST or RL_ARITH_REFERENCE");
+  if (arith != RL_ARITH_FAST && arith != RL_ARITH_REFERENCE && arith != RL_ARITH_BRANCH)
+    return fail(RL_ERR_ARG, "arith must be RL_ARITH_FAST, RL_ARITH_REFERENCE or RL_ARITH_BRANCH");
   ctx->arith = arith;
   return RL_OK;
 }
@@ -774,9 +780,10 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     if (widest > rl::kJointRowsPerThread * 256)
       return fail(RL_ERR_UNSUPPORTED, "sliding-window variant: a window spans more than 768 samples");
   }
-  const bool strict = ctx->arith == RL_ARITH_REFERENCE;
+  const bool lite = ctx->arith == RL_ARITH_BRANCH;
+  const bool strict = ctx->arith == RL_ARITH_REFERENCE || lite;    // the branch mode shares the reference-order kernel's tables and state
   if (strict) {
-    if (joint) return fail(RL_ERR_UNSUPPORTED, "reference-order arithmetic (rl_ctx_set_arith) covers run_min_curvature_qp, not the sliding-window driver");
+    if (joint) return fail(RL_ERR_UNSUPPORTED, "reference-order / branch arithmetic (rl_ctx_set_arith) covers run_min_curvature_qp, not the sliding-window driver");
     RL_HIP(hipSetDevice(ctx->device));
     if (int rc = ensure_strict_tables(ctx, trk)) return rc;
   }
@@ -836,7 +843,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     a.gscratch = trk->gscratch.p;
     a.gscratch_stride = p.gscratch_doubles;
   }
-  if (strict) {
+  if (strict && !lite) {
     // per instance: [2 cpad] reserved | [ceil(N/16)*2] doubles of per-sample flag bytes | [N] double2 snapshot of the table's X, Y
     const size_t per = (size_t)2 * ((n + 1) & ~1) + (size_t)2 * ((N + 15) / 16) + (size_t)2 * N;
     const size_t flags = ((size_t)B + 1) / 2;    // [B] ints behind the per-instance blocks
@@ -851,10 +858,10 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     stats->lds_bytes = (int)p.lds_bytes;
     stats->block_threads = p.block;
     stats->rings_in_lds = p.rings_in_lds ? 1 : (p.sigma_in_lds ? 2 : 0);
-    stats->reserved[0] = strict ? RL_ARITH_REFERENCE : RL_ARITH_FAST;
+    stats->reserved[0] = ctx->arith;
   }
   if (plan_out) *plan_out = p;
-  return launch_sweep(ctx, k, p, a, joint, strict);
+  return launch_sweep(ctx, k, p, a, joint, strict, lite);
 }
 
 int rl_mincurv_solve_batch_dev(rl_ctx* ctx, const rl_track* trk, int bounds_form, const double* in,

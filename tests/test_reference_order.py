@@ -294,3 +294,31 @@ def test_numpy_raise_semantics_g12(rl):
     np.testing.assert_array_equal(ns2[0], pns)
     np.testing.assert_array_equal(ctrl2[0, :, 0], pcx); np.testing.assert_array_equal(ctrl2[0, :, 1], pcy)
     assert not np.array_equal(pns, ons)
+
+
+@pytest.mark.parametrize("tag,N,B,max_iter", [("c100", 200, 24, 2), ("c100", 500, 16, 2), ("c30", 333, 16, 1)])
+def test_branch_arithmetic_small_batches(rl, fits, rings, monkeypatch, tag, N, B, max_iter):
+    """RL_ARITH_BRANCH -- positions, ring crossings, bound points and rows in the reference's order, normals and cost sums fast:
+    judged by the nearest-branch rule like the fast arithmetic (it is NOT the oracle's bits), identical across the three search
+    strategies and the two residencies, and on these batches at least as close to the oracle as the fast arithmetic."""
+    from parity_rule import ParityOracle, batch_parity
+    t, cx, cy, k, length = spline(fits, tag)
+    widths = widths_like_monza(rl, fits, rings, tag, N, B, seed=1234)
+    i_start = rl.batch.default_i_start(len(cx), k, max_iter, seed=B)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    BR = rl.lib.ARITH_BRANCH
+    res = {}
+    for residency in ("0", "1"):
+        monkeypatch.setenv("RL_FORCE_RESIDENCY", residency)
+        for search in (0, 1, 2):
+            res[(residency, search)] = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=search, arith=BR)
+            assert res[(residency, search)][4].reserved[0] == BR
+    first = res[("0", 2)]
+    for key, r in res.items():
+        np.testing.assert_array_equal(r[0], first[0], err_msg=str(key)); np.testing.assert_array_equal(r[2], first[2], err_msg=str(key))
+    po = ParityOracle(t, cx, cy, k, length, N, widths, i_start)
+    c = batch_parity(first[1], po, f"branch arithmetic {tag} N={N} it={max_iter}")
+    fast = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, arith=rl.lib.ARITH_FAST)
+    dev_fast = np.abs(fast[1] - po.xy0).reshape(B, -1).max(axis=1)
+    print(f"median deviation from the strict oracle [m]: branch {np.median(c['dev']):.2e}, fast {np.median(dev_fast):.2e}")
+    assert np.median(c["dev"]) <= np.median(dev_fast) * 1.5 + 1e-12
