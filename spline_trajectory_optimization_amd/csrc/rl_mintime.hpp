@@ -2121,7 +2121,7 @@ __device__ __forceinline__ void mt_trial_node(const MtProblem& P, const MtStepPt
 }
 
 // grid (node blocks, B): the first kMtTrials trial points, one node pair per thread -> vec[b][j][2 k .. 2 k + 1], k = trial.
-// Round 4: ONE trial point (a = ap: 72 % of the accepted steps of the benchmark batch take it, tools/mintime_halvings.py);
+// Round 4: ONE trial point (a = ap: 72 % of the accepted steps of the benchmark batch take it: histogram of a -DRL_MT_HIST build);
 // the 28 % that need ap / 2, ap / 4, ... evaluate them in k_mt_step, whose halving loop forms the same per-node shares and
 // adds them in the same order, so the decisions are bit for bit those of the three-point build (RL_MT_TRIALS=3 rebuilds it).
 #ifndef RL_MT_TRIALS
