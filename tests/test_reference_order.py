@@ -322,3 +322,30 @@ def test_branch_arithmetic_small_batches(rl, fits, rings, monkeypatch, tag, N, B
     dev_fast = np.abs(fast[1] - po.xy0).reshape(B, -1).max(axis=1)
     print(f"median deviation from the strict oracle [m]: branch {np.median(c['dev']):.2e}, fast {np.median(dev_fast):.2e}")
     assert np.median(c["dev"]) <= np.median(dev_fast) * 1.5 + 1e-12
+
+
+def test_other_configurations_bitwise(rl, fits, rings):
+    """The reference-order arithmetic on the other BASELINE shapes: the rotated oval of configs[2] (another spline: 32 control
+    points, long straights) at N = 2000, max_iter = 5, and Monza at N = 4000 (configs[3]'s size: supports of up to ~670
+    samples, i.e. THREE chunks of the sequential cost sums) -- the CR oracle's bits on every instance."""
+    oval = rl.batch.oval_centerline(100.0, 5)
+    t, cx, cy, k = oval._tck()
+    N, B, max_iter = 2000, 6, 5
+    wl, wr = rl.batch.oval_half_widths(N)
+    widths = rl.batch.width_batch(wl, wr, B, seed=5678)
+    i_start = rl.batch.default_i_start(len(cx), k, max_iter, seed=0)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, arith=REF)
+    with orc.cr_variant():
+        octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, oval.get_length(), N, widths, i_start, nthreads=8)
+    np.testing.assert_array_equal(ns, ons); np.testing.assert_array_equal(ctrl, octrl); np.testing.assert_array_equal(xy, oxy)
+    assert ns.sum() > 0.9 * ns.size * (len(cx) - 5)
+    t, cx, cy, k, length = spline(fits, "c100")
+    N, B, max_iter = 4000, 4, 1
+    widths = widths_like_monza(rl, fits, rings, "c100", N, B, seed=77)
+    i_start = rl.batch.default_i_start(len(cx), k, max_iter, seed=5)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, arith=REF)
+    with orc.cr_variant():
+        octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, length, N, widths, i_start, nthreads=8)
+    np.testing.assert_array_equal(ns, ons); np.testing.assert_array_equal(ctrl, octrl); np.testing.assert_array_equal(xy, oxy)
