@@ -67,8 +67,9 @@ enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1, RL_SEARCH_WINDOWED = 2 };
  *   RL_ARITH_REFERENCE  the reference's operations in the reference's order (numpy / scipy: unfused de Boor
  *                       recurrences and sums, splder derivative splines in the cost, sequential cost sums, unfused
  *                       cross products, yaw = atan2 and the normals cos / sin(yaw +- pi/2) CORRECTLY ROUNDED): returns
- *                       the bits of oracle/mincurv_oracle.c built with -DORC_LIBM_CR.  run_min_curvature_qp on
- *                       degree-5 splines (the reference's wrap, optimizer.py:281-285, is written for k = 5).
+ *                       the bits of oracle/mincurv_oracle.c built with -DORC_LIBM_CR.  run_min_curvature_qp and
+ *                       run_joint_min_curvature_qp (rl_mincurv_sweep_joint) on degree-5 splines (the reference's wrap,
+ *                       optimizer.py:281-285, is written for k = 5).
  *   RL_ARITH_BRANCH     the reference-order kernel without what is expensive and does not decide the branch: positions, ring
  *                       crossings, bound points and rows in the reference's order; normals from a reciprocal square root, cost
  *                       sums from the fast tables in a tree.  Not the oracle's bits: the oracle's BRANCH. */

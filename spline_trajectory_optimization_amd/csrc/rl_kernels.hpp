@@ -487,7 +487,7 @@ __host__ __device__ inline SweepLds sweep_lds_layout(int n, int N, int nL, int n
   L.off_pR = o; o += (size_t)((L.ncR + 1) & ~1);
   L.off_joint = o; o += joint ? 128 + (size_t)((N + 15) / 16) * 2 : 0;  // joint variant: QP scratch + 1 byte per sample
   L.off_hint = o; o += (size_t)(((size_t)2 * ((N + 3) & ~3) * sizeof(unsigned short) + 15) / 16) * 2;  // u16 [2][Npad]
-  L.off_c12 = o; o += strict ? kC12Doubles : 0;
+  L.off_c12 = o; o += strict ? (joint ? (size_t)4 * L.cpad : kC12Doubles) : 0;   // sliding window: c1x, c1y, c2x, c2y of the whole spline
   L.off_sL = L.off_sR = L.off_rL = L.off_rR = 0;
   if (sigma_in_lds) {
     const size_t per = (size_t)((N + 1) & ~1) * (strict ? 2 : 1);
@@ -528,7 +528,8 @@ constexpr int kSweepDumpHead = 16;
 template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false, bool SIGMA_LDS = RINGS_LDS, bool STRICT = false,
           bool RAISE = false, bool LITE = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS && !JOINT)) ? 4 : 1) void k_sweep(SweepArgs a) {
-  static_assert(!STRICT || (!JOINT && !DUMP && BLOCK == 256 && SIGMA_LDS == RINGS_LDS), "reference-order mode: the 256-thread sweep, all-LDS or all-global residency");
+  static_assert(!STRICT || (!DUMP && BLOCK == 256 && SIGMA_LDS == RINGS_LDS), "reference-order mode: the 256-thread kernels, all-LDS or all-global residency");
+  static_assert(!(JOINT && (RAISE || LITE)), "the sliding-window driver exists in the fast and in the reference-order arithmetic");
   static_assert(!RAISE || STRICT, "numpy's error state is modelled in the reference-order mode");
   static_assert(!LITE || (STRICT && !RAISE), "the branch mode is a reduction of the reference-order kernel");
   if constexpr (RAISE) { if (!a.raise_flag || a.raise_flag[blockIdx.x] == 0) return; }
@@ -671,6 +672,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
     const int was = outside[i];
     if ((int)out != was) { outside[i] = out ? 1 : 0; atomicAdd(n_outside, out ? 1 : -1); }
   };
+  auto note_outside_pts = [&](int i, double px, double py, double2 Lp, double2 Rp) {   // reference-order mode: from the stored bound points
+    const bool out = fmin(Lp.x, Rp.x) > px || fmax(Lp.x, Rp.x) < px || fmin(Lp.y, Rp.y) > py || fmax(Lp.y, Rp.y) < py;
+    const int was = outside[i];
+    if ((int)out != was) { outside[i] = out ? 1 : 0; atomicAdd(n_outside, out ? 1 : -1); }
+  };
   if (JOINT) {
     for (int i = tid; i < N; i += BLOCK) outside[i] = 0;
     if (tid == 0) *n_outside = 0;
@@ -737,10 +743,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           const Hit hr = search_ring_windowed<STAGED, true>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], px, py,
                                                             dRx, dRy, a.max_dist, false, nullptr, stgR);
           if (active) {   // no crossing: best_s = 0, the waypoint itself (trajectory.py:127)
-            bL[i] = make_double2(uf_madd(px, hl.best_s, dLx), uf_madd(py, hl.best_s, dLy));
-            bR[i] = make_double2(uf_madd(px, hr.best_s, dRx), uf_madd(py, hr.best_s, dRy));
+            const double2 Lp = make_double2(uf_madd(px, hl.best_s, dLx), uf_madd(py, hl.best_s, dLy));
+            const double2 Rp = make_double2(uf_madd(px, hr.best_s, dRx), uf_madd(py, hr.best_s, dRy));
+            bL[i] = Lp; bR[i] = Rp;
             hints[i] = (unsigned short)(hl.edge == kNoEdge ? 0xFFFF : hl.edge);
             hints[Npad + i] = (unsigned short)(hr.edge == kNoEdge ? 0xFFFF : hr.edge);
+            if (JOINT) note_outside_pts(i, px, py, Lp, Rp);
           }
         }
         if constexpr (RAISE) { if (delta != 0) atomicAdd(n_degen, delta); }
@@ -764,6 +772,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         hints[side * Npad + i] = (unsigned short)(h.edge == kNoEdge ? 0xFFFF : h.edge);
       }
       if constexpr (RAISE) { if (delta != 0) atomicAdd(n_degen, delta); }
+      if (JOINT) {  // per-lane search modes: the box flags need both bound points -> second sweep over the samples
+        __syncthreads();
+        for (int r = tid; r < m; r += BLOCK) {
+          const int i = r < m0 ? i0 + r : j0 + (r - m0);
+          const int l = tr.ell[i];
+          note_outside_pts(i, seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i),
+                           seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i), bL[i], bR[i]);
+        }
+      }
       return;
     }
     if (mode == 2) {
@@ -896,7 +913,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   const double* __restrict__ D2 = tr.D + (size_t)2 * (K + 1) * N;
   int n_skipped = 0;
 
-  if constexpr (STRICT) {
+  if constexpr (STRICT && !JOINT) {
     // ---- reference-order mode of run_min_curvature_qp (optimizer.py:256-341): the same three phases per step, with the
     // reference's operations in the reference's order (see the note above StrictRows)
     double* c12 = smem + L.off_c12;      // derivative-spline coefficients around the NEXT control point: c1x | c1y | c2x | c2y, 2K each
@@ -1255,6 +1272,78 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         if (kk >= j_max) kk = kk - j_max + i_min;
         const int u0 = tr.sup[2 * kk], u1 = tr.sup[2 * (kk + SP - 1) + 1];  // union of the supports
         // ---- cost: the five 2x2 diagonal blocks (joint_min_curvature_cost, :103-108)
+        if constexpr (STRICT) {
+          // reference-order arithmetic: the derivative splines of the whole line (splder; oracle: orc_bspline_derivative), then
+          // every block as orc_min_curvature_cost forms it -- the six sums in sample order
+          double* c1x = smem + L.off_c12; double* c1y = c1x + L.cpad; double* c2x = c1y + L.cpad; double* c2y = c2x + L.cpad;
+          double* terms = smem + L.off_terms;
+          for (int j = tid; j < n - 1; j += BLOCK) {
+#pragma clang fp contract(off)
+            const double dt = tr.t[j + K + 1] - tr.t[j + 1];
+            c1x[j] = (cx[j + 1] - cx[j]) * (double)K / dt;
+            c1y[j] = (cy[j + 1] - cy[j]) * (double)K / dt;
+          }
+          __syncthreads();
+          for (int j = tid; j < n - 2; j += BLOCK) {
+#pragma clang fp contract(off)
+            const double dt = tr.t[j + K + 1] - tr.t[j + 2];
+            c2x[j] = (c1x[j + 1] - c1x[j]) * (double)(K - 1) / dt;
+            c2y[j] = (c1y[j + 1] - c1y[j]) * (double)(K - 1) / dt;
+          }
+          __syncthreads();
+          for (int j = 0; j < SP; ++j) {
+            const int idx = kk + j;
+            const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+            const double zx = cx[idx], zy = cy[idx];
+            const int M = s1 - s0, nchunks = (M + kTermChunk - 1) / kTermChunk;
+            double sacc = 0.0;
+            for (int ch = 0; ch < nchunks; ++ch) {
+              const int i = s0 + ch * kTermChunk + tid;
+              if (i < s1) {
+#pragma clang fp contract(off)
+                const int l = tr.ell[i];
+                const double dTx = seq_dot<K>(c1x + (l - K), Ds + (size_t)SR::E1 * N, N, i);
+                const double dTy = seq_dot<K>(c1y + (l - K), Ds + (size_t)SR::E1 * N, N, i);
+                const double d2Tx = seq_dot<K - 1>(c2x + (l - K), Ds + (size_t)SR::E2 * N, N, i);
+                const double d2Ty = seq_dot<K - 1>(c2y + (l - K), Ds + (size_t)SR::E2 * N, N, i);
+                const double B2 = Ds[(size_t)(SR::D2 + idx - l + K) * N + i];
+                const double Fx = d2Tx - B2 * zx, Fy = d2Ty - B2 * zy;
+                const double s2 = dTx * dTx + dTy * dTy;
+                const double denom = s2 * s2 * s2;
+                const double Pxx = (dTy * dTy) / denom;
+                const double Pxy = (-2.0 * dTx * dTy) / denom;
+                const double Pyy = (dTx * dTx) / denom;
+                double* tp = terms + tid;
+                tp[0] = B2 * Pxx * B2;
+                tp[kTermStride] = B2 * Pyy * B2;
+                tp[2 * kTermStride] = Fx * Pxx * B2;
+                tp[3 * kTermStride] = Fy * Pxy * B2;
+                tp[4 * kTermStride] = Fy * Pyy * B2;
+                tp[5 * kTermStride] = B2 * Pxy * Fx;
+              }
+              __syncthreads();
+              if (wave == 0 && lane < 6) {
+                const int cnt = min(kTermChunk, M - ch * kTermChunk);
+                const double* tp = terms + lane * kTermStride;
+                for (int q_ = 0; q_ < cnt; ++q_) sacc += tp[q_];
+              }
+              __syncthreads();
+            }
+            if (wave == 0) {
+              auto lane_val = [&](int src) {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), src),
+                                        __builtin_amdgcn_readlane(__double2loint(sacc), src));
+              };
+              const double t0 = lane_val(0), t1 = lane_val(1), t2 = lane_val(2), t3 = lane_val(3), t4 = lane_val(4), t5 = lane_val(5);
+              if (tid == 0) {
+                jh[j] = 2.0 * t0; jh[SP + j] = 2.0 * t1;                       // optimizer.py:83
+                jg[j] = t2 + t2; jg[SP + j] = (t3 + t4) + (t5 + t4);           // optimizer.py:85
+                jz[j] = zx; jz[SP + j] = zy;
+              }
+            }
+          }
+          __syncthreads();
+        } else {
         for (int j = 0; j < SP; ++j) {
           const int idx = kk + j;
           const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
@@ -1285,6 +1374,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           jz[tid] = cx[kk + tid]; jz[SP + tid] = cy[kk + tid];
         }
         __syncthreads();
+        }
         // ---- rows of the union support, two samples per thread at most (joint_track_constraint)
         constexpr int RPT = kJointRowsPerThread;
         double ra[RPT][SP], rlx[RPT], rux[RPT], rly[RPT], ruy[RPT], rn[RPT];
@@ -1296,6 +1386,26 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           rn[q] = -1.0;  // no row
           if (i < u1) {
             const int l = tr.ell[i];
+            if constexpr (STRICT) {   // oracle: orc_run_joint_min_curvature_qp, the rows of joint_track_constraint (:129-159)
+#pragma clang fp contract(off)
+              const double x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+              const double y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+              const double2 Lp = bL[i], Rp = bR[i];
+              double azx = 0.0, azy = 0.0, nn = 0.0;
+#pragma unroll
+              for (int j = 0; j < SP; ++j) {
+                const int aa = kk + j - l + K;
+                const double bj = (aa >= 0 && aa <= K) ? Ds[(size_t)(SR::D0 + aa) * N + i] : 0.0;
+                ra[q][j] = bj;
+                azx += bj * jz[j]; azy += bj * jz[SP + j];
+                nn += bj * bj;
+              }
+              const double nzx = x - azx, nzy = y - azy;  // :148
+              rlx[q] = fmin(Lp.x, Rp.x) - nzx; rux[q] = fmax(Lp.x, Rp.x) - nzx;
+              rly[q] = fmin(Lp.y, Rp.y) - nzy; ruy[q] = fmax(Lp.y, Rp.y) - nzy;
+              rn[q] = sqrt(nn);
+              n_out_union += outside[i];
+            } else {
             CurvePoint<K, 1> c;
             eval_sample<K, 1>(tr, cx, cy, i, l, c);
             double ndx, ndy, inv_s2;
@@ -1317,6 +1427,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
             rly[q] = fmin(Ly, Ry) - nzy; ruy[q] = fmax(Ly, Ry) - nzy;
             rn[q] = sqrt(nn);
             n_out_union += outside[i];
+            }
           }
         }
         // test aid (rl_debug_dump_enable): per window 48 header doubles, 9 per row of the union support, then the control
@@ -1367,11 +1478,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         for (int coord = 0; coord < 2 && feasible; ++coord) {
           const double* hh = jh + coord * SP;
           const double* gg = jg + coord * SP;
+          double* jhv = jq + 104;       // [SP] reference-order arithmetic: 1 / h (oracle: orc_qp_diag_rows, hinv)
           if (tid == 0) {
             bool okd = true;
             for (int j = 0; j < SP; ++j) {
               if (!(hh[j] > 0.0) || !isfinite(hh[j]) || !isfinite(gg[j])) okd = false;
-              jx[j] = okd ? -gg[j] / hh[j] : 0.0;
+              if constexpr (STRICT) { jhv[j] = 1.0 / hh[j]; jx[j] = okd ? -gg[j] * jhv[j] : 0.0; }
+              else jx[j] = okd ? -gg[j] / hh[j] : 0.0;
             }
             jctl[2] = okd ? 0.0 : 3.0;  // status: 0 running, 1 solved, 2 infeasible, 3 bad
             jctl[3] = 0.0;              // q = active rows
@@ -1381,6 +1494,21 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
             if (jctl[2] != 0.0) break;
             // most violated row, normalised (ties: lowest sample, lower bound first)
             double worst = 1e-10; int wrow = -1, wsgn = 0;
+            if constexpr (STRICT) {
+#pragma clang fp contract(off)
+#pragma unroll
+              for (int q = 0; q < RPT; ++q) {
+                if (rn[q] > 0.0) {
+                  double ax = 0.0;
+#pragma unroll
+                  for (int j = 0; j < SP; ++j) ax += ra[q][j] * jx[j];
+                  const double lo_ = coord ? rly[q] : rlx[q], hi_ = coord ? ruy[q] : rux[q];
+                  const double vl = (lo_ - ax) / rn[q], vu = (ax - hi_) / rn[q];
+                  if (vl > worst) { worst = vl; wrow = tid + q * BLOCK; wsgn = +1; }
+                  if (vu > worst) { worst = vu; wrow = tid + q * BLOCK; wsgn = -1; }
+                }
+              }
+            } else {
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
               if (rn[q] > 0.0) {
@@ -1392,6 +1520,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
                 if (vl > worst) { worst = vl; wrow = tid + q * BLOCK; wsgn = +1; }
                 if (vu > worst) { worst = vu; wrow = tid + q * BLOCK; wsgn = -1; }
               }
+            }
             }
             const double wmax = wave_max(worst);
             // lowest row index among the lanes that hold the wave maximum
@@ -1416,7 +1545,84 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
               jcand[5] = wsgn > 0 ? (coord ? rly[q] : rlx[q]) : -(coord ? ruy[q] : rux[q]);  // np.x >= beta
             }
             __syncthreads();
-            if (tid == 0) {
+            if (STRICT && tid == 0) {
+              // the oracle's operations in the oracle's order (orc_qp_diag_rows): products with hinv = 1 / h, no contraction
+#pragma clang fp contract(off)
+              int q = (int)jctl[3];
+              double up = 0.0;
+              int done_p = 0;
+              for (int inner = 0; inner < 4 * SP + 8 && !done_p; ++inner) {
+                double Mq[SP * SP], r[SP], z[SP];
+                for (int a_ = 0; a_ < q; ++a_) {
+                  for (int b_ = 0; b_ < q; ++b_) {
+                    double s_ = 0.0;
+                    for (int j = 0; j < SP; ++j) s_ += jact[a_ * 8 + j] * jhv[j] * jact[b_ * 8 + j];
+                    Mq[a_ * SP + b_] = s_;
+                  }
+                  double s_ = 0.0;
+                  for (int j = 0; j < SP; ++j) s_ += jact[a_ * 8 + j] * jhv[j] * jcand[j];
+                  r[a_] = s_;
+                }
+                bool sing = false;
+                for (int c_ = 0; c_ < q; ++c_) {  // small_spd_solve: Cholesky + two triangular solves
+                  double d = Mq[c_ * SP + c_];
+                  for (int k_ = 0; k_ < c_; ++k_) d -= Mq[c_ * SP + k_] * Mq[c_ * SP + k_];
+                  if (!(d > 0.0)) { sing = true; break; }
+                  d = sqrt(d);
+                  Mq[c_ * SP + c_] = d;
+                  for (int r_ = c_ + 1; r_ < q; ++r_) {
+                    double s_ = Mq[r_ * SP + c_];
+                    for (int k_ = 0; k_ < c_; ++k_) s_ -= Mq[r_ * SP + k_] * Mq[c_ * SP + k_];
+                    Mq[r_ * SP + c_] = s_ / d;
+                  }
+                }
+                if (sing) { jctl[2] = 3.0; done_p = 2; break; }
+                for (int r_ = 0; r_ < q; ++r_) {
+                  double s_ = r[r_];
+                  for (int k_ = 0; k_ < r_; ++k_) s_ -= Mq[r_ * SP + k_] * r[k_];
+                  r[r_] = s_ / Mq[r_ * SP + r_];
+                }
+                for (int r_ = q - 1; r_ >= 0; --r_) {
+                  double s_ = r[r_];
+                  for (int k_ = r_ + 1; k_ < q; ++k_) s_ -= Mq[k_ * SP + r_] * r[k_];
+                  r[r_] = s_ / Mq[r_ * SP + r_];
+                }
+                double zn = 0.0, scale = 0.0;
+                for (int j = 0; j < SP; ++j) {
+                  double s_ = jcand[j];
+                  for (int a_ = 0; a_ < q; ++a_) s_ -= jact[a_ * 8 + j] * r[a_];
+                  z[j] = jhv[j] * s_;
+                  zn += z[j] * jcand[j];
+                  scale += jcand[j] * jhv[j] * jcand[j];
+                }
+                const bool z0_ = (q == SP) || !(zn > 1e-13 * scale);
+                double t1 = INFINITY; int kdrop = -1;
+                for (int a_ = 0; a_ < q; ++a_)
+                  if (r[a_] > 0.0) { const double tt = jact[a_ * 8 + 6] / r[a_]; if (tt < t1) { t1 = tt; kdrop = a_; } }
+                double cp = -jcand[5];
+                for (int j = 0; j < SP; ++j) cp += jcand[j] * jx[j];
+                double t2 = z0_ ? INFINITY : -cp / zn;
+                if (t2 < 0.0) t2 = 0.0;
+                const double ts = t1 < t2 ? t1 : t2;
+                if (!(ts < INFINITY)) { jctl[2] = 2.0; done_p = 2; break; }
+                if (!z0_) for (int j = 0; j < SP; ++j) jx[j] += ts * z[j];
+                for (int a_ = 0; a_ < q; ++a_) jact[a_ * 8 + 6] -= ts * r[a_];
+                up += ts;
+                if (!z0_ && t2 <= t1) {
+                  for (int j = 0; j < 6; ++j) jact[q * 8 + j] = jcand[j];
+                  jact[q * 8 + 6] = up;
+                  ++q;
+                  done_p = 1;
+                } else {
+                  for (int a_ = kdrop; a_ + 1 < q; ++a_)
+                    for (int j = 0; j < 7; ++j) jact[a_ * 8 + j] = jact[(a_ + 1) * 8 + j];
+                  --q;
+                }
+              }
+              if (!done_p && jctl[2] == 0.0) jctl[2] = 3.0;
+              jctl[3] = (double)q;
+            }
+            if (!STRICT && tid == 0) {
               int q = (int)jctl[3];
               double up = 0.0;
               int done_p = 0;

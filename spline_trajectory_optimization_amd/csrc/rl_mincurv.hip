@@ -325,8 +325,11 @@ int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
 
 int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false, bool strict = false,
                  bool lite = false) {
-  if (strict) {   // RL_ARITH_REFERENCE / _BRANCH: the degree-5 sweep (the reference's wrap is written for k = 5, optimizer.py:281-285)
-    if (joint || k != 5 || a.dbg) return fail(RL_ERR_UNSUPPORTED, "reference-order / branch arithmetic: run_min_curvature_qp on a degree-5 spline, no step dump");
+  if (strict) {   // RL_ARITH_REFERENCE / _BRANCH: degree-5 splines (the reference's wrap is written for k = 5, optimizer.py:281-285)
+    if (k != 5 || a.dbg || (joint && lite)) return fail(RL_ERR_UNSUPPORTED, "reference-order / branch arithmetic: degree-5 splines, no step dump; the sliding-window driver in the reference-order arithmetic only");
+    if (joint)    // run_joint_min_curvature_qp in the reference-order arithmetic
+      return p.rings_in_lds ? launch_sweep_t<5, 256, true, true, false, true, true>(ctx, a, p.lds_bytes)
+                            : launch_sweep_t<5, 256, false, true, false, false, true>(ctx, a, p.lds_bytes);
     if (lite)     // RL_ARITH_BRANCH
       return p.rings_in_lds ? launch_sweep_t<5, 256, true, false, false, true, true, false, true>(ctx, a, p.lds_bytes)
                             : launch_sweep_t<5, 256, false, false, false, false, true, false, true>(ctx, a, p.lds_bytes);
@@ -783,7 +786,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
   const bool lite = ctx->arith == RL_ARITH_BRANCH;
   const bool strict = ctx->arith == RL_ARITH_REFERENCE || lite;    // the branch mode shares the reference-order kernel's tables and state
   if (strict) {
-    if (joint) return fail(RL_ERR_UNSUPPORTED, "reference-order / branch arithmetic (rl_ctx_set_arith) covers run_min_curvature_qp, not the sliding-window driver");
+    if (joint && lite) return fail(RL_ERR_UNSUPPORTED, "the branch arithmetic (rl_ctx_set_arith) covers run_min_curvature_qp; the sliding-window driver exists in the fast and in the reference-order arithmetic");
     RL_HIP(hipSetDevice(ctx->device));
     if (int rc = ensure_strict_tables(ctx, trk)) return rc;
   }
@@ -843,7 +846,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     a.gscratch = trk->gscratch.p;
     a.gscratch_stride = p.gscratch_doubles;
   }
-  if (strict && !lite) {
+  if (strict && !lite && !joint) {
     // per instance: [2 cpad] reserved | [ceil(N/16)*2] doubles of per-sample flag bytes | [N] double2 snapshot of the table's X, Y
     const size_t per = (size_t)2 * ((n + 1) & ~1) + (size_t)2 * ((N + 15) / 16) + (size_t)2 * N;
     const size_t flags = ((size_t)B + 1) / 2;    // [B] ints behind the per-instance blocks

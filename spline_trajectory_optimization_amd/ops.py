@@ -114,7 +114,7 @@ def mincurv_sweep(track, cx, cy, i_start, want_points=True, arith=None):
     return cx, cy, pts, ns.reshape(max_iter, 2), st
 
 
-def mincurv_sweep_joint(track, cx, cy, i_start, want_points=True):
+def mincurv_sweep_joint(track, cx, cy, i_start, want_points=True, arith=None):
     """TrajectoryOptimizer.run_joint_min_curvature_qp (optimization/optimizer.py:163-220) for one
     instance bounded by the track's shared rings.  Returns (cx, cy, points|None, n_success[max_iter], stats)."""
     ctx = track.ctx
@@ -124,10 +124,11 @@ def mincurv_sweep_joint(track, cx, cy, i_start, want_points=True):
     pts = np.zeros((track.N, _lib.NCOL)) if want_points else None
     ns = np.zeros(max_iter, dtype=np.int32)
     st = Stats()
-    check(ctx.lib.rl_mincurv_sweep_joint(ctx.h, track.h, ip, max_iter, cx.ctypes.data_as(_dp),
-                                         cy.ctypes.data_as(_dp),
-                                         pts.ctypes.data_as(_dp) if want_points else None,
-                                         ns.ctypes.data_as(_ip), ctypes.byref(st)))
+    with _arith_scope(ctx, arith):
+        check(ctx.lib.rl_mincurv_sweep_joint(ctx.h, track.h, ip, max_iter, cx.ctypes.data_as(_dp),
+                                             cy.ctypes.data_as(_dp),
+                                             pts.ctypes.data_as(_dp) if want_points else None,
+                                             ns.ctypes.data_as(_ip), ctypes.byref(st)))
     return cx, cy, pts, ns, st
 
 

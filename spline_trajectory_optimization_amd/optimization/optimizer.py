@@ -172,7 +172,7 @@ class TrajectoryOptimizer:
         return traj_out_s
 
     def run_joint_min_curvature_qp(self, traj_in_s: BSplineTrajectory, traj_in_d: Trajectory, max_iter=3,
-                                   visualize=False, *, i_start=None):
+                                   visualize=False, *, i_start=None, arith=None):
         """optimizer.py:163-220 (sliding window, span 5) -> ONE launch of the joint sweep kernel.
         The per-window simulator call (:208-209) never feeds back into the spline and is not run."""
         traj_out_s = traj_in_s.copy()
@@ -191,7 +191,7 @@ class TrajectoryOptimizer:
         trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
         trk.set_length(traj_out_s.get_length())
         t, cx, cy, _ = traj_out_s._tck()
-        cx, cy, pts, ns, stats = ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=True)
+        cx, cy, pts, ns, stats = ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=True, arith=arith)
         traj_out_s._spl_x.c[:] = cx
         traj_out_s._spl_y.c[:] = cy
         self.last_n_success = ns

@@ -243,15 +243,46 @@ def test_reference_order_refuses_what_it_does_not_cover(rl, fits, rings):
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, 200)
     trk.set_rings(rings[0], rings[1])
     ctx = rl.lib.Context.get(0)
-    with ctx.arith(REF):
+    with ctx.arith(rl.lib.ARITH_BRANCH):          # the sliding-window driver: fast and reference-order arithmetic only
         with pytest.raises(rl.lib.RlError):
             rl.ops.mincurv_sweep_joint(trk, cx, cy, np.array([10]))
     assert ctx.lib.rl_ctx_get_arith(ctx.h) == 0
-    t3, cx3, cy3, k3, _ = spline(fits, "l10")
+    t3, cx3, cy3, k3, _ = spline(fits, "l10")     # degree 3: the reference's wrap is written for k = 5
     trk3 = rl.lib.Track(ctx, t3, cx3, cy3, k3, 200)
     w = np.full((1, 200, 2), 5.0)
     with pytest.raises(rl.lib.RlError):
         rl.ops.solve_batch_host(trk3, rl.lib.BOUNDS_WIDTHS, w, np.array([3]), arith=REF)
+
+
+def test_sliding_window_driver_bitwise(rl, fits, rings):
+    """run_joint_min_curvature_qp (optimizer.py:163-220) in the reference-order arithmetic: the five cost blocks as
+    orc_min_curvature_cost forms them, the rows of joint_track_constraint unfused, the window QP by the oracle's
+    Goldfarb-Idnani iteration operation for operation (orc_qp_diag_rows).  Fixtures G9 (six runs of the reference's own loop
+    on CHAOTIC cases: in the fast arithmetic the kernel reproduces two of them) and G9b (eight well-conditioned ones): the CR
+    oracle's bits on all fourteen -- hence the reference's run wherever the oracle reproduces it."""
+    n_ref = 0
+    for fname in ("G9_run_joint_min_curvature_qp.npz", "G9b_joint_wellconditioned.npz"):
+        g = golden(fname)
+        for key in [str(k_) for k_ in g["cases"]]:
+            tag, N = key.split("_")[0], int(key.split("_")[1][1:])
+            t, cx, cy, k, length = spline(fits, tag)
+            i_start = g[f"{key}_i_start"]
+            trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+            trk.set_rings(rings[0], rings[1])
+            hcx, hcy, _, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=False, arith=REF)
+            with orc.cr_variant():
+                ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start)
+            np.testing.assert_array_equal(ns, ons, err_msg=key)
+            np.testing.assert_array_equal(hcx, ocx, err_msg=key); np.testing.assert_array_equal(hcy, ocy, err_msg=key)
+            dev = float(np.hypot(hcx - g[f"{key}_cx"], hcy - g[f"{key}_cy"]).max())
+            on_run = dev < 1e-6
+            n_ref += on_run
+            print(fname.split("_")[0], key, "windows", ns.tolist(), "vs the reference's run [m]:", dev)
+            flag = f"{key}_oracle_reproduces_run"
+            if fname.startswith("G9b") or (flag in g.files and bool(g[flag])):   # the (libm) oracle reproduces the run: so must this
+                assert on_run, (key, dev)
+    print("on the reference's run:", n_ref, "of 14")
+    assert n_ref >= 13
 
 
 def test_numpy_raise_semantics_g12(rl):
