@@ -174,6 +174,14 @@ def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref
            "default": "fast (the reference-order mode costs more than 10 %): rl_ctx_set_arith(ctx, RL_ARITH_REFERENCE) / RL_ARITH=reference / "
                       "bench.py --arith reference select it",
            "lds_bytes_per_workgroup": int(out["stats"].lds_bytes)}
+    prof = profile_block("k_sweep_reference_order")
+    ach = (BYTES_PER_SOLVE * B) / (ms * 1e-3) / 1e9
+    leg["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                       "traffic": prof.get("hbm_bytes_fetch_x2") if prof else None, "traffic_source": prof.get("source") if prof else None,
+                       "traffic_measured_in_run": False, "kernel_ms": ms, "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
+                       "actual_limiter": "as the fast kernel (latency of a step's dependent chain at four workgroups per CU), with 46 % more VALU "
+                                         "instructions per step: the double-double heading, IEEE divisions and unfused sums (DESIGN.md 5b)",
+                       "valu": valu_block(prof, ms)}
     if po is not None:
         m = po.xy0.shape[0]
         dev = np.abs(xy[:m] - po.xy0).reshape(m, -1).max(axis=1)

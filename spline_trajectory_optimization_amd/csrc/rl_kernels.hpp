@@ -397,6 +397,111 @@ __global__ void k_constraint(TrackDev tr, const double* __restrict__ cx,
   }
 }
 
+// a7 / a8 in the reference-order arithmetic (RL_ARITH_REFERENCE): the standalone entry points return the oracle's bits too
+// (orc_min_curvature_cost, orc_track_constraint).  One workgroup of 256 threads per requested control point; same steps as
+// phase 1 / 2 of k_sweep<STRICT>: derivative-spline coefficients around idx, the six cost terms per support sample, their sums
+// in sample order.
+constexpr int kTermChunkA = 256, kTermStrideA = kTermChunkA + 2;
+template <int K>
+__global__ __launch_bounds__(256) void k_cost_strict(TrackDev tr, const double* __restrict__ cx,
+                                                     const double* __restrict__ cy, const int* __restrict__ idxs,
+                                                     const double* __restrict__ z, double* __restrict__ H,
+                                                     double* __restrict__ g, int* __restrict__ Mout) {
+  __shared__ double terms[6 * kTermStrideA];
+  __shared__ double c12[8 * K];
+  using SR = StrictRows<K>;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int idx = idxs[q], n = tr.n, N = tr.N;
+  const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+  const double zx = z ? z[2 * q] : cx[idx], zy = z ? z[2 * q + 1] : cy[idx];
+  const double* __restrict__ Ds = tr.Ds;
+  if (wave == 0) {   // splder coefficients c1[j], c2[j] for j = idx-K .. idx+K-1 (x: lanes 0.., y: lanes 32..)
+    const int w = lane & 31;
+    const double* cc = lane < 32 ? cx : cy;
+    const int j = idx - K + w;
+    double c1 = 0.0, c2 = 0.0;
+    if (w < 2 * K && j >= 0 && j + 1 <= n - 1) {
+#pragma clang fp contract(off)
+      c1 = (cc[j + 1] - cc[j]) * (double)K / (tr.t[j + K + 1] - tr.t[j + 1]);
+    }
+    const double c1n = __shfl_down(c1, 1, kWave);
+    if (w < 2 * K - 1 && j >= 0 && j + 2 <= n - 1) {
+#pragma clang fp contract(off)
+      c2 = (c1n - c1) * (double)(K - 1) / (tr.t[j + K + 1] - tr.t[j + 2]);
+    }
+    if (w < 2 * K) { c12[(lane < 32 ? 0 : 2 * K) + w] = c1; c12[4 * K + (lane < 32 ? 0 : 2 * K) + w] = c2; }
+  }
+  __syncthreads();
+  const int M = s1 - s0, nchunks = (M + kTermChunkA - 1) / kTermChunkA;
+  double sacc = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int i = s0 + ch * kTermChunkA + tid;
+    if (i < s1) {
+#pragma clang fp contract(off)
+      const int l = tr.ell[i];
+      const int wofs = l - idx;
+      const double dTx = seq_dot<K>(c12 + wofs, Ds + (size_t)SR::E1 * N, N, i);
+      const double dTy = seq_dot<K>(c12 + 2 * K + wofs, Ds + (size_t)SR::E1 * N, N, i);
+      const double d2Tx = seq_dot<K - 1>(c12 + 4 * K + wofs, Ds + (size_t)SR::E2 * N, N, i);
+      const double d2Ty = seq_dot<K - 1>(c12 + 6 * K + wofs, Ds + (size_t)SR::E2 * N, N, i);
+      const double B2 = Ds[(size_t)(SR::D2 + idx - l + K) * N + i];
+      const double Fx = d2Tx - B2 * zx, Fy = d2Ty - B2 * zy;
+      const double s2 = dTx * dTx + dTy * dTy;
+      const double denom = s2 * s2 * s2;
+      const double Pxx = (dTy * dTy) / denom;
+      const double Pxy = (-2.0 * dTx * dTy) / denom;
+      const double Pyy = (dTx * dTx) / denom;
+      double* tp = terms + tid;
+      tp[0] = B2 * Pxx * B2;
+      tp[kTermStrideA] = B2 * Pyy * B2;
+      tp[2 * kTermStrideA] = Fx * Pxx * B2;
+      tp[3 * kTermStrideA] = Fy * Pxy * B2;
+      tp[4 * kTermStrideA] = Fy * Pyy * B2;
+      tp[5 * kTermStrideA] = B2 * Pxy * Fx;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 6) {
+      const int cnt = min(kTermChunkA, M - ch * kTermChunkA);
+      const double* tp = terms + lane * kTermStrideA;
+      for (int u = 0; u < cnt; ++u) sacc += tp[u];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    auto lane_val = [&](int src) {
+      return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), src), __builtin_amdgcn_readlane(__double2loint(sacc), src));
+    };
+    const double t0 = lane_val(0), t1 = lane_val(1), t2 = lane_val(2), t3 = lane_val(3), t4 = lane_val(4), t5 = lane_val(5);
+    if (tid == 0) {
+      H[4 * q + 0] = 2.0 * t0; H[4 * q + 1] = 0.0; H[4 * q + 2] = 0.0; H[4 * q + 3] = 2.0 * t1;
+      g[2 * q + 0] = t2 + t2;
+      g[2 * q + 1] = (t3 + t4) + (t5 + t4);
+      if (Mout) Mout[q] = M;
+    }
+  }
+}
+
+template <int K>
+__global__ void k_constraint_strict(TrackDev tr, const double* __restrict__ cx, const double* __restrict__ cy,
+                                    const double* __restrict__ points, int idx, double* __restrict__ b,
+                                    double* __restrict__ lba, double* __restrict__ uba) {
+#pragma clang fp contract(off)
+  const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+  const double zx = cx[idx], zy = cy[idx];
+  for (int i = s0 + blockIdx.x * blockDim.x + threadIdx.x; i < s1; i += gridDim.x * blockDim.x) {
+    const int l = tr.ell[i];
+    const double bi = tr.Ds[(size_t)(StrictRows<K>::D0 + idx - l + K) * tr.N + i];
+    const double* p = points + (size_t)i * 19;
+    const double nzx = p[0] - bi * zx, nzy = p[1] - bi * zy;
+    const int r = i - s0;
+    b[r] = bi;
+    lba[2 * r] = fmin(p[9], p[11]) - nzx;
+    lba[2 * r + 1] = fmin(p[10], p[12]) - nzy;
+    uba[2 * r] = fmax(p[9], p[11]) - nzx;
+    uba[2 * r + 1] = fmax(p[10], p[12]) - nzy;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a12: the sweep.
 constexpr int kJointRowsPerThread = 3;  // sliding-window variant: union of 5 supports <= 3 * 256 samples

@@ -702,10 +702,13 @@ int rl_mincurv_cost(rl_ctx* ctx, const rl_track* trk, const int* idx, int n_idx,
     RL_HIP(dz.alloc((size_t)2 * n_idx));
     RL_HIP(hipMemcpyAsync(dz.p, z, (size_t)2 * n_idx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
+  if (ctx->arith == RL_ARITH_REFERENCE && trk->k == 5) if (int rc = ensure_strict_tables(ctx, trk)) return rc;
   const rl::TrackDev td = trk->dev();
   const double* cx = trk->c0.p;
   const double* cy = trk->c0.p + trk->n;
-  if (trk->k == 3)
+  if (ctx->arith == RL_ARITH_REFERENCE && trk->k == 5)     // the oracle's bits (orc_min_curvature_cost)
+    hipLaunchKernelGGL(rl::k_cost_strict<5>, dim3(n_idx), dim3(256), 0, ctx->stream, td, cx, cy, didx.p, dz.p, dH.p, dg.p, dM.p);
+  else if (trk->k == 3)
     hipLaunchKernelGGL(rl::k_cost<3>, dim3(n_idx), dim3(256), 0, ctx->stream, td, cx, cy, didx.p, dz.p, dH.p, dg.p, dM.p);
   else
     hipLaunchKernelGGL(rl::k_cost<5>, dim3(n_idx), dim3(256), 0, ctx->stream, td, cx, cy, didx.p, dz.p, dH.p, dg.p, dM.p);
@@ -736,11 +739,14 @@ int rl_track_constraint(rl_ctx* ctx, const rl_track* trk, const double* points, 
   PoolBuf<double> dpts(ctx), db(ctx), dl(ctx), du(ctx);
   RL_HIP(dpts.alloc((size_t)N * RL_NCOL)); RL_HIP(db.alloc(m)); RL_HIP(dl.alloc((size_t)2 * m)); RL_HIP(du.alloc((size_t)2 * m));
   RL_HIP(hipMemcpyAsync(dpts.p, points, dpts.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->arith == RL_ARITH_REFERENCE && k == 5) if (int rc = ensure_strict_tables(ctx, trk)) return rc;
   const rl::TrackDev td = trk->dev();
   const double* cx = trk->c0.p;
   const double* cy = trk->c0.p + trk->n;
   const dim3 grid((m + 255) / 256), block(256);
-  if (k == 3)
+  if (ctx->arith == RL_ARITH_REFERENCE && k == 5)          // the oracle's bits (orc_track_constraint)
+    hipLaunchKernelGGL(rl::k_constraint_strict<5>, grid, block, 0, ctx->stream, td, cx, cy, dpts.p, idx, db.p, dl.p, du.p);
+  else if (k == 3)
     hipLaunchKernelGGL(rl::k_constraint<3>, grid, block, 0, ctx->stream, td, cx, cy, dpts.p, idx, db.p, dl.p, du.p);
   else
     hipLaunchKernelGGL(rl::k_constraint<5>, grid, block, 0, ctx->stream, td, cx, cy, dpts.p, idx, db.p, dl.p, du.p);

@@ -380,3 +380,31 @@ def test_other_configurations_bitwise(rl, fits, rings):
     with orc.cr_variant():
         octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, length, N, widths, i_start, nthreads=8)
     np.testing.assert_array_equal(ns, ons); np.testing.assert_array_equal(ctrl, octrl); np.testing.assert_array_equal(xy, oxy)
+
+
+def test_cost_and_constraint_entry_points_bitwise(rl, fits, rings):
+    """rl_mincurv_cost / rl_track_constraint (TrajectoryOptimizer.min_curvature_cost / track_constraint, optimizer.py:24-86,
+    222-254) under RL_ARITH_REFERENCE: the oracle's H, g and rows bit for bit, for every free control point."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    N = 500
+    ctx = rl.lib.Context.get(0)
+    trk = rl.lib.Track(ctx, t, cx, cy, k, N)
+    idx = np.arange(2, len(cx) - 3)
+    pts = orc.sample_along(t, cx, cy, k, length, np.linspace(0.0, 1.0, N, endpoint=False))
+    orc.fill_bounds(pts, rings[0], rings[1], 100.0)
+    rng = np.random.default_rng(3)
+    z = np.stack([cx[idx], cy[idx]], axis=1) + rng.normal(0.0, 2.0, (len(idx), 2))
+    with ctx.arith(REF):
+        H, g, M = rl.ops.mincurv_cost(trk, idx, z=z)
+        H0, g0, _ = rl.ops.mincurv_cost(trk, idx)
+        rows = [rl.ops.track_constraint(trk, pts, int(i)) for i in idx[::7]]
+    for q, i in enumerate(idx):
+        oH, og, oM = orc.min_curvature_cost(z[q], int(i), t, cx, cy, k, N)
+        assert M[q] == oM
+        np.testing.assert_array_equal(H[q], oH, err_msg=f"H of control point {i}")
+        np.testing.assert_array_equal(g[q], og, err_msg=f"g of control point {i}")
+        oH0, og0, _ = orc.min_curvature_cost(np.array([cx[i], cy[i]]), int(i), t, cx, cy, k, N)
+        np.testing.assert_array_equal(H0[q], oH0); np.testing.assert_array_equal(g0[q], og0)
+    for (A, lba, uba), i in zip(rows, idx[::7]):
+        oA, olba, ouba = orc.track_constraint(int(i), t, cx, cy, k, pts)
+        np.testing.assert_array_equal(A, oA); np.testing.assert_array_equal(lba, olba); np.testing.assert_array_equal(uba, ouba)
