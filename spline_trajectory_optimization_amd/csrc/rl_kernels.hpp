@@ -1369,6 +1369,38 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
     double* jcand = jq + 56;    // [8]  candidate row: SP coefficients, bound, sign
     double* jact = jq + 64;     // [SP][8] active rows: SP coefficients (signed), beta, lambda
     double* jctl = jq + 112;    // [0] verdict / row id, [1] violation, ...
+    // reference-order arithmetic: numpy's error state in the sliding-window loop (optimizer.py:197-214; oracle: "numpy's error
+    // state"; fixture G12).  The simulator call inside the try block (:208) switches np.seterr(all='raise') on: from the first
+    // window that gets that far -- or from the start (a.np_raise_at_start) -- a window whose re-sampled line holds a sample of
+    // exactly zero curvature raises in sample_along AFTER its five control points are written: the spline keeps them, the table
+    // (positions, bound points, the outside-its-box flags) stays as it was, the window is not counted.
+    unsigned char* jdegen = (STRICT && a.aux) ? reinterpret_cast<unsigned char*>(a.aux + (size_t)b * a.aux_stride + 2 * L.cpad) : nullptr;
+    double2* jptab = (STRICT && a.aux) ? reinterpret_cast<double2*>(a.aux + (size_t)b * a.aux_stride + 2 * L.cpad) + ((N + 15) / 16) : nullptr;
+    int* jn_degen = reinterpret_cast<int*>(red + 190);
+    bool jraise = false, jstale = false, jflags_valid = false;
+    auto jflags_pass = [&](int i0, int i1, int j0, int j1) {   // flags of the CURRENT spline on two sample ranges
+      if constexpr (STRICT) {
+        const int m0 = i1 - i0, m = m0 + (j1 - j0);
+        int delta = 0;
+        for (int r = tid; r < m; r += BLOCK) {
+#pragma clang fp contract(off)
+          const int i = r < m0 ? i0 + r : j0 + (r - m0);
+          const int l = tr.ell[i];
+          const double dx = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D1 * N, N, i);
+          const double dy = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D1 * N, N, i);
+          const double d2x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D2 * N, N, i);
+          const double d2y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D2 * N, N, i);
+          const double s2 = dx * dx + dy * dy;
+          const double den = sqrt(s2 * s2 * s2);
+          const double curvature = fabs(dx * d2y - dy * d2x) / den;
+          const int now = (den == 0.0 || !(curvature > 0.0) || !isfinite(curvature)) ? 1 : 0;
+          delta += now - (int)jdegen[i];
+          jdegen[i] = (unsigned char)now;
+        }
+        if (delta != 0) atomicAdd(jn_degen, delta);
+      }
+    };
+    if (STRICT && jdegen && a.np_raise_at_start) jraise = true;
     for (int it = 0; it < a.max_iter; ++it) {
       const int st = a.i_start[it];
       int ok_count = 0;
@@ -1493,8 +1525,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
             const int l = tr.ell[i];
             if constexpr (STRICT) {   // oracle: orc_run_joint_min_curvature_qp, the rows of joint_track_constraint (:129-159)
 #pragma clang fp contract(off)
-              const double x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i);
-              const double y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+              double x, y;              // the table's X, Y: of the current spline unless the table is stale (numpy's error state)
+              if (jstale) { const double2 ps = jptab[i]; x = ps.x; y = ps.y; }
+              else {
+                x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+                y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i);
+              }
               const double2 Lp = bL[i], Rp = bR[i];
               double azx = 0.0, azy = 0.0, nn = 0.0;
 #pragma unroll
@@ -1825,9 +1861,53 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           int a0 = 0, a1 = 0;
           if (kk <= 4) { a0 = tr.sup[2 * (max(kk, 2) + n - 5)]; a1 = tr.sup[2 * (min(kk + SP - 1, 4) + n - 5) + 1]; }
           else if (kk + SP - 1 >= n - 5) { a0 = tr.sup[2 * (max(kk, n - 5) - (n - 5))]; a1 = tr.sup[2 * (min(kk + SP - 1, n - 4) - (n - 5)) + 1]; }
-          refresh(u0, u1, a0, a1, mode);
-          __syncthreads();
-          ++ok_count;
+          bool raised = false;
+          if (STRICT && jdegen && jraise) {   // sample_along of the new spline under np.seterr(all='raise'): does it raise anywhere?
+            if (!jflags_valid) {               // first time in raise mode: the flags of the whole line
+              if (tid == 0) *jn_degen = 0;
+              for (int i = tid; i < N; i += BLOCK) jdegen[i] = 0;
+              __syncthreads();
+              jflags_pass(0, N, 0, 0);
+              jflags_valid = true;
+            } else {
+              jflags_pass(u0, u1, a0, a1);
+            }
+            __syncthreads();
+            raised = *jn_degen > 0;
+            if (raised && !jstale) {
+              // the table now belongs to the control points BEFORE this window: put them back for a moment (jz holds them),
+              // snapshot the table's X, Y, write the new ones again
+              __syncthreads();
+              if (tid == 0) {
+                for (int j = 0; j < SP; ++j) { cx[kk + j] = jz[j]; cy[kk + j] = jz[SP + j]; }
+                cx[0] = cx[n - 5]; cy[0] = cy[n - 5]; cx[1] = cx[n - 4]; cy[1] = cy[n - 4];
+                cx[n - 3] = cx[2]; cy[n - 3] = cy[2]; cx[n - 2] = cx[3]; cy[n - 2] = cy[3]; cx[n - 1] = cx[4]; cy[n - 1] = cy[4];
+              }
+              __syncthreads();
+              for (int i = tid; i < N; i += BLOCK) {
+                const int l = tr.ell[i];
+                jptab[i] = make_double2(seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i),
+                                        seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i));
+              }
+              __syncthreads();
+              if (tid == 0) {
+                for (int j = 0; j < SP; ++j) { cx[kk + j] = newz[0][j]; cy[kk + j] = newz[1][j]; }
+                cx[0] = cx[n - 5]; cy[0] = cy[n - 5]; cx[1] = cx[n - 4]; cy[1] = cy[n - 4];
+                cx[n - 3] = cx[2]; cy[n - 3] = cy[2]; cx[n - 2] = cx[3]; cy[n - 2] = cy[3]; cx[n - 1] = cx[4]; cy[n - 1] = cy[4];
+              }
+              jstale = true;
+              __syncthreads();
+            }
+          }
+          if (raised) {
+            ++n_skipped;
+          } else {
+            if (jstale) refresh(0, N, 0, 0, mode); else refresh(u0, u1, a0, a1, mode);
+            jstale = false;
+            jraise = STRICT && jdegen != nullptr;   // :208 the simulator has run (simulator.py:164)
+            __syncthreads();
+            ++ok_count;
+          }
         } else {
           ++n_skipped;
         }

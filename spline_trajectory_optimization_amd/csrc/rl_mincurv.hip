@@ -852,7 +852,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     a.gscratch = trk->gscratch.p;
     a.gscratch_stride = p.gscratch_doubles;
   }
-  if (strict && !lite && !joint) {
+  if (strict && !lite) {
     // per instance: [2 cpad] reserved | [ceil(N/16)*2] doubles of per-sample flag bytes | [N] double2 snapshot of the table's X, Y
     const size_t per = (size_t)2 * ((n + 1) & ~1) + (size_t)2 * ((N + 15) / 16) + (size_t)2 * N;
     const size_t flags = ((size_t)B + 1) / 2;    // [B] ints behind the per-instance blocks

@@ -408,3 +408,36 @@ def test_cost_and_constraint_entry_points_bitwise(rl, fits, rings):
     for (A, lba, uba), i in zip(rows, idx[::7]):
         oA, olba, ouba = orc.track_constraint(int(i), t, cx, cy, k, pts)
         np.testing.assert_array_equal(A, oA); np.testing.assert_array_equal(lba, olba); np.testing.assert_array_equal(uba, ouba)
+
+
+def test_numpy_raise_semantics_g12_sliding_window(rl):
+    """Fixture G12, the sliding-window half: the reference's run_joint_min_curvature_qp under np.seterr(all='raise') -- 28 of
+    38 windows raise in the re-sampling after their control points are written, 9 have no feasible QP, ONE goes through.  The
+    reference-order kernel models numpy's error state here too: the oracle's bits, the reference's counts and line."""
+    g = golden("G12_numpy_raise_semantics.npz")
+    t, cx, cy, k, length = g["t"], g["cx"], g["cy"], int(g["k"]), float(g["length"])
+    N = 240
+    i_start = g["joint_N240_i_start"]
+    ctx = rl.lib.Context.get(0)
+    trk = rl.lib.Track(ctx, t, cx, cy, k, N)
+    trk.set_rings(g["ringL"], g["ringR"])
+    ctx.set_numpy_raise(True)
+    try:
+        hcx, hcy, _, ns, st = rl.ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=False, arith=REF)
+    finally:
+        ctx.set_numpy_raise(False)
+    assert int(ns.sum()) == int(g["joint_N240_n_ok"])
+    dev = float(np.hypot(hcx - g["joint_N240_cx"], hcy - g["joint_N240_cy"]).max())
+    print("G12 sliding window: reference-order HIP vs the reference's run [m]:", dev, "windows that went through:", ns.tolist())
+    assert dev < 1e-6
+    with orc.cr_variant():
+        ocx, ocy, _, ons = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, g["ringL"], g["ringR"], i_start, numpy_raise=True)
+        assert orc.last_raised() == int(g["joint_N240_n_raised"])
+    np.testing.assert_array_equal(ns, ons)
+    np.testing.assert_array_equal(hcx, ocx); np.testing.assert_array_equal(hcy, ocy)
+    # numpy's default state at the start: raise mode only after the first window that gets as far as the simulator
+    hcx2, hcy2, _, ns2, _ = rl.ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=False, arith=REF)
+    with orc.cr_variant():
+        pcx, pcy, _, pns = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, g["ringL"], g["ringR"], i_start)
+    np.testing.assert_array_equal(ns2, pns)
+    np.testing.assert_array_equal(hcx2, pcx); np.testing.assert_array_equal(hcy2, pcy)
