@@ -11,6 +11,11 @@ Differences from the reference, all additive and keyword-only:
     into the returned spline (they only rewrite SPEED/ACC/TIME columns of a table that is
     discarded); they are skipped unless `simulate=True`.
   * the matplotlib visualiser (optimizer.py:261, 331-340) is not constructed.
+  * ARITHMETIC.  This class is the drop-in for the reference's, so by default it answers in the REFERENCE-ORDER arithmetic
+    (`TrajectoryOptimizer.arith = _lib.ARITH_REFERENCE`: the reference's operations in numpy's / scipy's order, the CPU oracle's
+    bits; include/rl_mincurv.h) wherever that exists (degree-5 splines: both drivers and the four assembly methods).  Set
+    `optm.arith = _lib.ARITH_FAST` (or pass `arith=` to a driver) for the fast arithmetic of the batched entry points; a
+    single solve costs about 6 ms in either.
   * `run_global_min_curvature_qp` is NEW (no reference counterpart that works: the Julia notebook
     prototype): the whole line as ONE banded QP per linearisation, solved by the
     interior-point kernel (include/rl_mincurv.h: rl_mincurv_global_batch_*).
@@ -25,6 +30,16 @@ from ..simulator.simulator import Simulator
 
 
 class TrajectoryOptimizer:
+    arith = _lib.ARITH_REFERENCE     # see the module docstring; the batched ops default to the context's (fast) arithmetic
+
+    def _scope(self, k, arith=None):
+        """The arithmetic the calls inside run in: `arith` if given, else this object's; the fast one where the
+        reference-order kernels do not exist (degree != 5)."""
+        a = self.arith if arith is None else arith
+        if k != 5:
+            a = _lib.ARITH_FAST
+        return _lib.Context.get().arith(a)
+
     def __init__(self, race_track: RaceTrack, center_line: BSplineTrajectory, vehicle: Vehicle) -> None:
         self.track = race_track
         self.left_bound = race_track.left_s
@@ -51,7 +66,8 @@ class TrajectoryOptimizer:
     def min_curvature_cost(self, z: np.ndarray, idx: int, traj_s: BSplineTrajectory, traj_d: Trajectory):
         """optimizer.py:24-86 -> k_cost.  Returns H (2x2), g (2)."""
         trk = self._device_track(traj_s, len(traj_d))
-        H, g, _ = ops.mincurv_cost(trk, [idx], z=np.asarray(z, dtype=np.float64).reshape(1, 2))
+        with self._scope(traj_s._spl_x.k):
+            H, g, _ = ops.mincurv_cost(trk, [idx], z=np.asarray(z, dtype=np.float64).reshape(1, 2))
         return H[0], g[0]
 
     def joint_min_curvature_cost(self, traj_s: BSplineTrajectory, traj_d: Trajectory, start_idx=None, span=None):
@@ -65,7 +81,8 @@ class TrajectoryOptimizer:
             i_min, i_max = start_idx, start_idx + span
         nw = i_max - i_min
         trk = self._device_track(traj_s, len(traj_d))
-        H, g, _ = ops.mincurv_cost(trk, np.arange(i_min, i_max))  # z = current control points
+        with self._scope(traj_s._spl_x.k):
+            H, g, _ = ops.mincurv_cost(trk, np.arange(i_min, i_max))  # z = current control points
         joint_H = np.zeros((nw * 2, nw * 2), np.float64)
         joint_g = np.zeros(nw * 2, np.float64)
         for j in range(nw):
@@ -76,7 +93,8 @@ class TrajectoryOptimizer:
     def track_constraint(self, idx: int, traj_s: BSplineTrajectory, traj_d: Trajectory):
         """optimizer.py:222-254 -> k_constraint.  Returns A (2M x 2), lba (2M), uba (2M)."""
         trk = self._device_track(traj_s, len(traj_d))
-        return ops.track_constraint(trk, traj_d.points, idx)
+        with self._scope(traj_s._spl_x.k):
+            return ops.track_constraint(trk, traj_d.points, idx)
 
     def joint_track_constraint(self, traj_s: BSplineTrajectory, traj_d: Trajectory, start_idx=None, span=None):
         """optimizer.py:112-161: dense A over ALL samples for the window's control points."""
@@ -96,7 +114,8 @@ class TrajectoryOptimizer:
         z = np.zeros(nw * 2, np.float64)
         for i in range(i_min, i_max):
             j = i - i_min
-            A, _, _ = ops.track_constraint(trk, traj_d.points, i)
+            with self._scope(k):
+                A, _, _ = ops.track_constraint(trk, traj_d.points, i)
             t_mask = (ts >= traj_s._spl_x.t[i]) & (ts < traj_s._spl_x.t[i + k + 1])
             s0 = int(np.argmax(t_mask)) if t_mask.any() else 0
             m = len(A) // 2
@@ -122,7 +141,7 @@ class TrajectoryOptimizer:
         ("Iteration j" + the result, :333-336; its speeds never feed back into the spline) and once more at the end
         (:338-339).  The sweep is then launched once per outer iteration, each launch continuing from the control points
         of the one before -- the same bits as the single launch, since every launch re-derives the table from the
-        control points.  arith: _lib.ARITH_FAST / ARITH_REFERENCE for this call (None = the context's setting)."""
+        control points.  arith: _lib.ARITH_FAST / ARITH_REFERENCE for this call (None = this object's `arith`: the reference-order arithmetic unless changed)."""
         traj_out_s = traj_in_s.copy()
         n = len(traj_out_s._spl_x.c)
         k = traj_out_s._spl_x.k
@@ -138,6 +157,7 @@ class TrajectoryOptimizer:
         trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
         trk.set_length(traj_out_s.get_length())
         t, cx, cy, _ = traj_out_s._tck()
+        arith_ = (self.arith if arith is None else arith) if k == 5 else _lib.ARITH_FAST
 
         def table(pts):                                     # the traj_out_d of optimizer.py:286-288
             tab = Trajectory(len(pts))
@@ -147,7 +167,7 @@ class TrajectoryOptimizer:
             ns_all = []
             self.last_sim_results = []
             for j in range(max_iter):
-                cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start[j:j + 1], want_points=True, arith=arith)
+                cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start[j:j + 1], want_points=True, arith=arith_)
                 ns_all.append(ns[0])
                 print(f"Forward pass: number of control points successfully updated: {ns[0, 0]}")
                 print(f"Backward pass: number of control points successfully updated: {ns[0, 1]}")
@@ -160,7 +180,7 @@ class TrajectoryOptimizer:
             print(sim_result)
             self.last_sim_results.append(sim_result)
         else:
-            cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start, want_points=True, arith=arith)
+            cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start, want_points=True, arith=arith_)
             for j in range(max_iter):
                 print(f"Forward pass: number of control points successfully updated: {ns[j, 0]}")
                 print(f"Backward pass: number of control points successfully updated: {ns[j, 1]}")
@@ -191,7 +211,10 @@ class TrajectoryOptimizer:
         trk.set_rings(_ring_coords(self.track.left_r), _ring_coords(self.track.right_r))
         trk.set_length(traj_out_s.get_length())
         t, cx, cy, _ = traj_out_s._tck()
-        cx, cy, pts, ns, stats = ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=True, arith=arith)
+        arith_ = (self.arith if arith is None else arith) if k == 5 else _lib.ARITH_FAST
+        if arith_ == _lib.ARITH_BRANCH:
+            arith_ = _lib.ARITH_FAST      # the branch arithmetic exists for the sweep only
+        cx, cy, pts, ns, stats = ops.mincurv_sweep_joint(trk, cx, cy, i_start, want_points=True, arith=arith_)
         traj_out_s._spl_x.c[:] = cx
         traj_out_s._spl_y.c[:] = cy
         self.last_n_success = ns

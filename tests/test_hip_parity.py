@@ -567,8 +567,8 @@ def test_drop_in_api(rl, fits, rings):
     assert isinstance(out, BSplineTrajectory)
     np.testing.assert_array_equal(optm.last_n_success, g7[f"{key}_n_success"])
     dev = np.hypot(out._spl_x.c - g7[f"{key}_cx"], out._spl_y.c - g7[f"{key}_cy"]).max()
-    print("drop-in run_min_curvature_qp deviation from the reference run [m]:", dev)
-    assert dev < TOL_M
+    print("drop-in run_min_curvature_qp (the class's default: reference-order arithmetic) deviation from the reference run [m]:", dev)
+    assert optm.arith == rl.lib.ARITH_REFERENCE and dev < TIGHT_M
     # the input spline is not modified (optimizer.py:257)
     np.testing.assert_array_equal(traj_spline._spl_x.c, cx)
     # the table the sweep hands back is the reference's final traj_out_d (optimizer.py:286-288): the
@@ -596,12 +596,20 @@ def test_drop_in_api(rl, fits, rings):
     text = buf.getvalue()
     assert "Iteration 1" in text and "Iteration 2" in text and "Iteration 3" not in text
     assert len(optm.last_sim_results) == 3 and text.count("Forward pass") == 2
-    # and in the reference-order arithmetic: the oracle's bits (tests/test_reference_order.py), through the class API
+    # the fast arithmetic through the class API: per call, or as the object's setting (then the assembly methods use it too)
     np.random.seed(0)
-    out3 = optm.run_min_curvature_qp(traj_spline, traj_d, visualize=False, max_iter=2, arith=1)
+    out3 = optm.run_min_curvature_qp(traj_spline, traj_d, visualize=False, max_iter=2, arith=rl.lib.ARITH_FAST)
     dev3 = np.hypot(out3._spl_x.c - g7[f"{key}_cx"], out3._spl_y.c - g7[f"{key}_cy"]).max()
-    print("drop-in run_min_curvature_qp, reference-order arithmetic, deviation from the reference run [m]:", dev3)
-    assert dev3 < TIGHT_M
+    print("drop-in run_min_curvature_qp, fast arithmetic, deviation from the reference run [m]:", dev3)
+    assert dev3 < TOL_M and not np.array_equal(out3._spl_x.c, out._spl_x.c)
+    optm.arith = rl.lib.ARITH_FAST
+    np.random.seed(0)
+    out4 = optm.run_min_curvature_qp(traj_spline, traj_d, visualize=False, max_iter=2)
+    np.testing.assert_array_equal(out4._spl_x.c, out3._spl_x.c)
+    Hf, gf = optm.min_curvature_cost(np.array(traj_spline.get_control_point(10)), 10, traj_spline, traj_d)
+    np.testing.assert_allclose(Hf, H, rtol=1e-12); np.testing.assert_allclose(gf, g, rtol=0, atol=1e-12 * np.abs(g).max())
+    ctx0 = rl.lib.Context.get(0)
+    assert ctx0.lib.rl_ctx_get_arith(ctx0.h) == rl.lib.ARITH_FAST    # the scopes above restored the context's setting
 
 
 @contextlib.contextmanager
