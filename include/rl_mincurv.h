@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 101          /* 0.1.1: rl_ctx_set_arith */
+#define RL_VERSION 102          /* 0.1.2: rl_mincurv_global_xy_batch_* (0.1.1: rl_ctx_set_arith) */
 #define RL_NCOL 19              /* Trajectory columns, models/trajectory.py:26-44 */
 #define RL_MAX_ITER 32          /* max outer iterations per sweep call */
 #define RL_MAX_DEGREE 5
@@ -229,6 +229,29 @@ int rl_mincurv_global_batch_dev(rl_ctx* ctx, const rl_track* trk, const double* 
 int rl_mincurv_global_batch_host(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,
                                  double margin, int n_outer, double* out_ctrl, double* out_xy,
                                  double* out_a, double* out_stats, rl_stats* stats);
+
+/* The same global problem with BOTH coordinates of every control point free -- the choice of unknowns and rows of the
+ * reference's Julia prototype (julia/spline_traj_opt.ipynb L247-281: A = R blockdiag(B, B), one lateral and one longitudinal
+ * row per sample; L410-412: Z = [c_x; c_y]; L276-279: bounds from the widths and +-1 m), with the corrections of SURVEY.md
+ * App. A.6 (second-derivative basis in the cost, linear term kept, one normal convention).  Replaces the notebook's driver
+ * cell L384-444; OSQP's role is taken by the interior-point kernel k_global_xy (csrc/rl_global_xy.hpp).
+ *   unknowns   z = (zx_j, zy_j) per free control point (n-k of them): c_j = c0_j + z_j
+ *   rows       -(w_right_i - margin) <= n0_i . (r_i - p0_i) <= w_left_i - margin   and   -lon <= t0_i . (r_i - p0_i) <= lon
+ *   cost       sum_i kappa_i^2, Gauss-Newton in both coordinates, n_outer linearisations; the step of a linearisation is
+ *              taken whole or halved, whichever gives the smaller sum kappa^2
+ *   lon        [m] longitudinal bound (> 0; the notebook uses 1.0)
+ *   out_ctrl   [B,n,2]   out_xy [B,N,2] (may be NULL)   out_z [B,n-k,2] (may be NULL)
+ *   out_stats  [B,8]: interior-point iterations, sum kappa^2 before / after, largest bound violation of the result [m]
+ *              (both row kinds), last step max|delta z| [m], lateral / longitudinal rows of the result within 1e-6 m of a
+ *              bound, number of halved steps
+ * Limits: 2 (n-k) <= 192, N <= 4096 and the per-instance state must fit LDS (N <= ~2300 at n-k = 61), else RL_ERR_UNSUPPORTED.
+ * CPU twin for tests: oracle/mincurv_oracle.c: orc_global_mincurv_xy. */
+int rl_mincurv_global_xy_batch_dev(rl_ctx* ctx, const rl_track* trk, const double* widths, int B, double margin, double lon,
+                                   int n_outer, double* out_ctrl, double* out_xy, double* out_z, double* out_stats,
+                                   rl_stats* stats);
+int rl_mincurv_global_xy_batch_host(rl_ctx* ctx, const rl_track* trk, const double* widths, int B, double margin, double lon,
+                                    int n_outer, double* out_ctrl, double* out_xy, double* out_z, double* out_stats,
+                                    rl_stats* stats);
 
 /* ---- f4, first slice (BASELINE config 5): FUNCTION EVALUATION of the min-time
  * double-track NLP for B candidate solutions x N nodes -- what an NLP / SQP solver calls at every

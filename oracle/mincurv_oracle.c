@@ -1557,3 +1557,271 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
   free(cx); free(P); free(xv); free(av); free(lo); free(kap); free(G); free(A); free(p0); free(nu); free(D); free(ell);
   return 0;
 }
+
+/* ---------------------------------------------------------------- global QP, both coordinates of every control point free */
+
+/* The Julia prototype's choice of unknowns and rows (julia/spline_traj_opt.ipynb L247-281, L410-432) with the corrections of
+ * SURVEY.md App. A.6 -- NOT a restatement of code that runs: the notebook's recorded run does not converge.  CPU twin of the HIP
+ * kernel k_global_xy (csrc/rl_global_xy.hpp):
+ *
+ *   unknowns   z = (zx_j, zy_j), j < n_p = n - k, interleaved: periodic control point j is c0_j + (zx_j, zy_j)  (ipynb L410-412: Z = [c_x; c_y])
+ *   rows       two per sample (ipynb L263-279: A = R blockdiag(B, B), one row pair per sample):
+ *                lateral       -(w_R,i - margin) <= n0_i . (r_i(z) - p0_i) <= w_L,i - margin
+ *                longitudinal  -lon <= t0_i . (r_i(z) - p0_i) <= lon                   (the notebook's +-1 m; `lon` here)
+ *              with n0 the left unit normal and t0 the unit tangent of the centre line (A.6 (3): ONE convention)
+ *   cost       sum_i kappa_i(z)^2 with the second-derivative basis (A.6 (1)), Gauss-Newton with the linear term (A.6 (2)):
+ *              kappa linearised at the current z in both coordinates, P = 2 G'G scaled to trace n + 1e-9 I, q = 2 G'(kappa - G z)
+ *   QP solve   the same Mehrotra predictor-corrector iteration as orc_global_mincurv, 4N bound rows, 2 n_p unknowns;
+ *              the normal matrix is cyclic-banded with half-bandwidth 2k + 1 in the interleaved order
+ *   step       Gauss-Newton on this cost 2-cycles on near-straights (the neglected second-order term is as large as the one
+ *              kept: measured, Monza, 0.53 m from one linearisation to the next with the cost equal to 2e-6); so the QP
+ *              step d is taken whole or halved, whichever of cost(z + d), cost(z + d/2) is smaller (both are feasible:
+ *              the rows are linear and z, z + d are inside).
+ * stats[0] interior-point iterations, [1] / [2] sum kappa^2 before / after, [3] largest bound violation of the final line [m]
+ * (both row kinds), [4] last step max|z_new - z| [m], [5] / [6] lateral / longitudinal rows of the final line within 1e-6 m of
+ * a bound, [7] number of halved steps. */
+int orc_global_mincurv_xy(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
+                          const double* w_left, const double* w_right, double margin, double lon, int n_outer,
+                          double* out_cx, double* out_cy, double* out_xy, double* out_z, double* stats) {
+  const int n = nt - k - 1, np_ = n - k, K1 = k + 1, K2 = 2 * K1, nz = 2 * np_, R = 2 * N;
+  if (np_ < 2 * K1 || k > ORC_MAXK) return -1;
+  int* ell = (int*)malloc((size_t)N * sizeof(int));
+  double* D = (double*)malloc((size_t)3 * K1 * N * sizeof(double));
+  double work[2 * ORC_MAXK + 2];
+  for (int i = 0; i < N; ++i) {
+    const double u = grid_u(i, N);
+    ell[i] = find_interval(t, nt, k, u);
+    for (int m = 0; m < 3; ++m) {
+      deboor_d(t, u, k, ell[i], m, work);
+      for (int a = 0; a < K1; ++a) D[((size_t)m * K1 + a) * N + i] = work[a];
+    }
+  }
+#define DD(m, a, i) D[((size_t)(m) * K1 + (a)) * N + (i)]
+#define JH(i, a) ((ell[i] - k + (a)) >= np_ ? (ell[i] - k + (a)) - np_ : (ell[i] - k + (a)))
+#define COL(i, e) (2 * JH((i), (e) >> 1) + ((e) & 1))     /* column of coefficient e = 2 a + c of a row of sample i */
+  double* p0 = (double*)malloc((size_t)N * 4 * sizeof(double)); /* p0x p0y n0x n0y */
+  double* A = (double*)malloc((size_t)R * K2 * sizeof(double)); /* rows i < N lateral, N + i longitudinal */
+  double* G = (double*)malloc((size_t)N * K2 * sizeof(double));
+  double* kap = (double*)malloc((size_t)N * sizeof(double));
+  double* lo = (double*)malloc((size_t)R * 10 * sizeof(double));
+  double *hi = lo + R, *sl = lo + 2 * R, *su = lo + 3 * R, *ll = lo + 4 * R, *lu = lo + 5 * R;
+  double *dsl = lo + 6 * R, *dsu = lo + 7 * R, *dll = lo + 8 * R, *dlu = lo + 9 * R;
+  for (int i = 0; i < N; ++i) {
+    double x = 0, y = 0, dx = 0, dy = 0;
+    for (int a = 0; a < K1; ++a) {
+      const int j = ell[i] - k + a;
+      x += cx0[j] * DD(0, a, i); y += cy0[j] * DD(0, a, i);
+      dx += cx0[j] * DD(1, a, i); dy += cy0[j] * DD(1, a, i);
+    }
+    const double s = sqrt(dx * dx + dy * dy);
+    const double nx = -dy / s, ny = dx / s;
+    p0[4 * i] = x; p0[4 * i + 1] = y; p0[4 * i + 2] = nx; p0[4 * i + 3] = ny;
+    for (int a = 0; a < K1; ++a) {
+      A[(size_t)i * K2 + 2 * a] = DD(0, a, i) * nx;       A[(size_t)i * K2 + 2 * a + 1] = DD(0, a, i) * ny;
+      A[(size_t)(N + i) * K2 + 2 * a] = DD(0, a, i) * ny; A[(size_t)(N + i) * K2 + 2 * a + 1] = DD(0, a, i) * -nx;   /* t0 = (ny, -nx) */
+    }
+    lo[i] = -(w_right[i] - margin); hi[i] = w_left[i] - margin;
+    lo[N + i] = -lon; hi[N + i] = lon;
+  }
+  double* zv = (double*)calloc((size_t)nz, sizeof(double));
+  double* xv = (double*)malloc((size_t)nz * 6 * sizeof(double));
+  double *rd = xv + nz, *rhs = xv + 2 * nz, *dxa = xv + 3 * nz, *qv = xv + 4 * nz, *dxc = xv + 5 * nz;
+  double* P = (double*)malloc((size_t)nz * nz * 2 * sizeof(double));
+  double* Kq = P + (size_t)nz * nz;
+  double* cx = (double*)malloc((size_t)n * 2 * sizeof(double));
+  double* cy = cx + n;
+  double k2_first = 0.0, k2_last = 0.0, last_step = 0.0;
+  int total_it = 0, n_halved = 0;
+  /* sum kappa^2 of the line with offsets z0 + tau (z1 - z0) */
+  double* ztmp = (double*)malloc((size_t)nz * sizeof(double));
+#define ROWI(r) ((r) < N ? (r) : (r) - N)
+  for (int outer = 0; outer <= n_outer; ++outer) {
+    for (int j = 0; j < n; ++j) {
+      const int jj = j >= np_ ? j - np_ : j;
+      cx[j] = cx0[jj] + zv[2 * jj];
+      cy[j] = cy0[jj] + zv[2 * jj + 1];
+    }
+    double k2 = 0.0;
+    for (int i = 0; i < N; ++i) {
+      double dx = 0, dy = 0, ddx = 0, ddy = 0;
+      for (int a = 0; a < K1; ++a) {
+        const int j = ell[i] - k + a;
+        dx += cx[j] * DD(1, a, i); dy += cy[j] * DD(1, a, i);
+        ddx += cx[j] * DD(2, a, i); ddy += cy[j] * DD(2, a, i);
+      }
+      const double s2 = dx * dx + dy * dy, inv3 = 1.0 / (s2 * sqrt(s2));
+      const double kp = (dx * ddy - dy * ddx) * inv3;
+      kap[i] = kp;
+      k2 += kp * kp;
+      /* d kappa / d(x', y', x'', y'') */
+      const double g1x = ddy * inv3 - 3.0 * kp * dx / s2, g1y = -ddx * inv3 - 3.0 * kp * dy / s2;
+      const double g2x = -dy * inv3, g2y = dx * inv3;
+      for (int a = 0; a < K1; ++a) {
+        G[(size_t)i * K2 + 2 * a] = g1x * DD(1, a, i) + g2x * DD(2, a, i);
+        G[(size_t)i * K2 + 2 * a + 1] = g1y * DD(1, a, i) + g2y * DD(2, a, i);
+      }
+    }
+    if (outer == 0) k2_first = k2;
+    k2_last = k2;
+    if (outer == n_outer) break;
+    memset(P, 0, (size_t)nz * nz * sizeof(double));
+    memset(qv, 0, (size_t)nz * sizeof(double));
+    for (int i = 0; i < N; ++i) {
+      double gz = 0.0;
+      for (int e = 0; e < K2; ++e) gz += G[(size_t)i * K2 + e] * zv[COL(i, e)];
+      for (int e = 0; e < K2; ++e) {
+        const int ce = COL(i, e);
+        qv[ce] += 2.0 * G[(size_t)i * K2 + e] * (kap[i] - gz);
+        for (int f = 0; f < K2; ++f) P[(size_t)ce * nz + COL(i, f)] += 2.0 * G[(size_t)i * K2 + e] * G[(size_t)i * K2 + f];
+      }
+    }
+    double tr = 0.0;
+    for (int j = 0; j < nz; ++j) tr += P[(size_t)j * nz + j];
+    const double sc = (double)nz / tr;
+    for (int j = 0; j < nz * nz; ++j) P[j] *= sc;
+    for (int j = 0; j < nz; ++j) { P[(size_t)j * nz + j] += 1e-9; qv[j] *= sc; }
+    memcpy(xv, zv, (size_t)nz * sizeof(double));
+    for (int r = 0; r < R; ++r) {
+      const int i = ROWI(r);
+      double ax = 0.0;
+      for (int e = 0; e < K2; ++e) ax += A[(size_t)r * K2 + e] * xv[COL(i, e)];
+      if (outer == 0) {
+        sl[r] = fmax(ax - lo[r], 1e-2); su[r] = fmax(hi[r] - ax, 1e-2); ll[r] = 1.0; lu[r] = 1.0;
+      } else {
+        sl[r] = fmax(sl[r], 1e-2); su[r] = fmax(su[r], 1e-2); ll[r] = fmax(ll[r], 1e-2); lu[r] = fmax(lu[r], 1e-2);
+      }
+    }
+    double qinf = 0.0;
+    for (int j = 0; j < nz; ++j) qinf = fmax(qinf, fabs(qv[j]));
+    for (int it = 0; it < 80; ++it) {
+      double mu = 0.0, rpmax = 0.0;
+      for (int j = 0; j < nz; ++j) {
+        double s = qv[j];
+        for (int q = 0; q < nz; ++q) s += P[(size_t)j * nz + q] * xv[q];
+        rd[j] = s;
+      }
+      for (int r = 0; r < R; ++r) {
+        const int i = ROWI(r);
+        double ax = 0.0;
+        for (int e = 0; e < K2; ++e) ax += A[(size_t)r * K2 + e] * xv[COL(i, e)];
+        const double rpl = ax - lo[r] - sl[r], rpu = hi[r] - ax - su[r];
+        rpmax = fmax(rpmax, fmax(fabs(rpl), fabs(rpu)));
+        mu += sl[r] * ll[r] + su[r] * lu[r];
+        for (int e = 0; e < K2; ++e) rd[COL(i, e)] += A[(size_t)r * K2 + e] * (lu[r] - ll[r]);
+      }
+      mu /= (double)(2 * R);
+      double rdmax = 0.0;
+      for (int j = 0; j < nz; ++j) rdmax = fmax(rdmax, fabs(rd[j]));
+      {
+        const int last_qp = outer + 1 >= n_outer;    /* same inexact intermediate solves as orc_global_mincurv */
+        if (fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : 1e-4) && mu < (last_qp ? 1e-10 : 1e-5)) break;
+      }
+      ++total_it;
+      memcpy(Kq, P, (size_t)nz * nz * sizeof(double));
+      for (int r = 0; r < R; ++r) {
+        const int i = ROWI(r);
+        const double dm = ll[r] / sl[r] + lu[r] / su[r];
+        for (int e = 0; e < K2; ++e)
+          for (int f = 0; f < K2; ++f)
+            Kq[(size_t)COL(i, e) * nz + COL(i, f)] += dm * A[(size_t)r * K2 + e] * A[(size_t)r * K2 + f];
+      }
+      spd_factor_dense(nz, Kq);
+      double alpha = 1.0, sigma = 0.0;
+      for (int pass = 0; pass < 2; ++pass) {
+        double* dxv = pass == 0 ? dxa : dxc;
+        for (int j = 0; j < nz; ++j) rhs[j] = -rd[j];
+        for (int r = 0; r < R; ++r) {
+          const int i = ROWI(r);
+          double ax = 0.0;
+          for (int e = 0; e < K2; ++e) ax += A[(size_t)r * K2 + e] * xv[COL(i, e)];
+          const double rpl = ax - lo[r] - sl[r], rpu = hi[r] - ax - su[r];
+          double rcl = sl[r] * ll[r], rcu = su[r] * lu[r];
+          if (pass == 1) { rcl += -sigma * mu + dsl[r] * dll[r]; rcu += -sigma * mu + dsu[r] * dlu[r]; }
+          const double wv = (-rcl - ll[r] * rpl) / sl[r] - (-rcu - lu[r] * rpu) / su[r];
+          for (int e = 0; e < K2; ++e) rhs[COL(i, e)] += A[(size_t)r * K2 + e] * wv;
+        }
+        memcpy(dxv, rhs, (size_t)nz * sizeof(double));
+        spd_solve_dense(nz, Kq, dxv);
+        double amin = 1.0, mu_aff = 0.0;
+        for (int r = 0; r < R; ++r) {
+          const int i = ROWI(r);
+          double ax = 0.0, adx = 0.0;
+          for (int e = 0; e < K2; ++e) { ax += A[(size_t)r * K2 + e] * xv[COL(i, e)]; adx += A[(size_t)r * K2 + e] * dxv[COL(i, e)]; }
+          const double rpl = ax - lo[r] - sl[r], rpu = hi[r] - ax - su[r];
+          double rcl = sl[r] * ll[r], rcu = su[r] * lu[r];
+          if (pass == 1) { rcl += -sigma * mu + dsl[r] * dll[r]; rcu += -sigma * mu + dsu[r] * dlu[r]; }
+          const double d_sl = adx + rpl, d_su = -adx + rpu;
+          const double d_ll = (-rcl - ll[r] * d_sl) / sl[r], d_lu = (-rcu - lu[r] * d_su) / su[r];
+          if (d_sl < 0.0) amin = fmin(amin, 0.995 * (-sl[r] / d_sl));
+          if (d_su < 0.0) amin = fmin(amin, 0.995 * (-su[r] / d_su));
+          if (d_ll < 0.0) amin = fmin(amin, 0.995 * (-ll[r] / d_ll));
+          if (d_lu < 0.0) amin = fmin(amin, 0.995 * (-lu[r] / d_lu));
+          dsl[r] = d_sl; dsu[r] = d_su; dll[r] = d_ll; dlu[r] = d_lu;
+        }
+        alpha = amin;
+        if (pass == 0) {
+          for (int r = 0; r < R; ++r)
+            mu_aff += (sl[r] + alpha * dsl[r]) * (ll[r] + alpha * dll[r]) + (su[r] + alpha * dsu[r]) * (lu[r] + alpha * dlu[r]);
+          mu_aff /= (double)(2 * R);
+          const double rr = mu_aff / mu;
+          sigma = rr * rr * rr;
+        }
+      }
+      for (int j = 0; j < nz; ++j) xv[j] += alpha * dxc[j];
+      for (int r = 0; r < R; ++r) {
+        sl[r] += alpha * dsl[r]; su[r] += alpha * dsu[r]; ll[r] += alpha * dll[r]; lu[r] += alpha * dlu[r];
+      }
+    }
+    /* whole step or half step: the smaller sum kappa^2 (ties: the whole step) */
+    double cost[2];
+    for (int h = 0; h < 2; ++h) {
+      const double tau = h == 0 ? 1.0 : 0.5;
+      for (int j = 0; j < nz; ++j) ztmp[j] = zv[j] + tau * (xv[j] - zv[j]);
+      double c2 = 0.0;
+      for (int i = 0; i < N; ++i) {
+        double dx = 0, dy = 0, ddx = 0, ddy = 0;
+        for (int a = 0; a < K1; ++a) {
+          const int j = ell[i] - k + a, jj = j >= np_ ? j - np_ : j;
+          const double px = cx0[jj] + ztmp[2 * jj], py = cy0[jj] + ztmp[2 * jj + 1];
+          dx += px * DD(1, a, i); dy += py * DD(1, a, i);
+          ddx += px * DD(2, a, i); ddy += py * DD(2, a, i);
+        }
+        const double s2 = dx * dx + dy * dy, kp = (dx * ddy - dy * ddx) / (s2 * sqrt(s2));
+        c2 += kp * kp;
+      }
+      cost[h] = c2;
+    }
+    const double tau = cost[1] < cost[0] ? 0.5 : 1.0;
+    if (tau != 1.0) ++n_halved;
+    last_step = 0.0;
+    for (int j = 0; j < nz; ++j) {
+      const double zn = zv[j] + tau * (xv[j] - zv[j]);
+      last_step = fmax(last_step, fabs(zn - zv[j]));
+      zv[j] = zn;
+    }
+  }
+  double viol = 0.0;
+  int act_lat = 0, act_lon = 0;
+  for (int i = 0; i < N; ++i) {
+    double x = 0, y = 0;
+    for (int a = 0; a < K1; ++a) { const int j = ell[i] - k + a; x += cx[j] * DD(0, a, i); y += cy[j] * DD(0, a, i); }
+    if (out_xy) { out_xy[2 * i] = x; out_xy[2 * i + 1] = y; }
+    const double ex = x - p0[4 * i], ey = y - p0[4 * i + 1];
+    const double lat = ex * p0[4 * i + 2] + ey * p0[4 * i + 3], lg = ex * p0[4 * i + 3] - ey * p0[4 * i + 2];
+    viol = fmax(viol, fmax(fmax(lo[i] - lat, lat - hi[i]), fabs(lg) - lon));
+    if (lat - lo[i] < 1e-6 || hi[i] - lat < 1e-6) ++act_lat;
+    if (lon - fabs(lg) < 1e-6) ++act_lon;
+  }
+  for (int j = 0; j < n; ++j) { out_cx[j] = cx[j]; out_cy[j] = cy[j]; }
+  if (out_z) memcpy(out_z, zv, (size_t)nz * sizeof(double));
+  if (stats) {
+    stats[0] = (double)total_it; stats[1] = k2_first; stats[2] = k2_last; stats[3] = viol; stats[4] = last_step;
+    stats[5] = (double)act_lat; stats[6] = (double)act_lon; stats[7] = (double)n_halved;
+  }
+#undef DD
+#undef JH
+#undef COL
+#undef ROWI
+  free(ztmp); free(cx); free(P); free(xv); free(zv); free(lo); free(kap); free(G); free(A); free(p0); free(D); free(ell);
+  return 0;
+}

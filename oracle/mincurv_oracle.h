@@ -144,6 +144,11 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
                        const double* w_left, const double* w_right, double margin, int n_outer,
                        double* out_cx, double* out_cy, double* out_xy, double* out_a, double* stats);
 
+/* The global QP with both coordinates of every control point free (lateral + longitudinal rows; comment at the definition). */
+int orc_global_mincurv_xy(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
+                          const double* w_left, const double* w_right, double margin, double lon, int n_outer,
+                          double* out_cx, double* out_cy, double* out_xy, double* out_z, double* stats);
+
 double orc_last_kappa(void);
 void orc_reset_kappa(void);
 

@@ -303,6 +303,23 @@ def global_mincurv(t, cx0, cy0, k, N, w_left, w_right, margin=0.0, n_outer=6):
     return cx, cy, xy, a, st
 
 
+def global_mincurv_xy(t, cx0, cy0, k, N, w_left, w_right, margin=0.0, lon=1.0, n_outer=6):
+    """The global QP with both coordinates of every control point free (lateral and +-`lon` m longitudinal rows per sample,
+    julia/spline_traj_opt.ipynb L247-281 with SURVEY App. A.6's corrections); returns (cx, cy, xy [N,2], z [n-k, 2],
+    stats[8]: ipm iterations, sum kappa^2 before / after, bound violation, last step, active lateral / longitudinal rows,
+    halved steps)."""
+    t, tp = _d(t); cx0, xp = _d(cx0); cy0, yp = _d(cy0); wl, lp = _d(w_left); wr, rp = _d(w_right)
+    n = len(cx0)
+    cx = np.zeros(n); cy = np.zeros(n); xy = np.zeros((N, 2)); z = np.zeros((n - k, 2)); st = np.zeros(8)
+    f = lib().orc_global_mincurv_xy
+    f.argtypes = [_dp, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double,
+                  ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
+    rc = f(tp, len(t), xp, yp, int(k), int(N), lp, rp, float(margin), float(lon), int(n_outer), cx.ctypes.data_as(_dp),
+           cy.ctypes.data_as(_dp), xy.ctypes.data_as(_dp), z.ctypes.data_as(_dp), st.ctypes.data_as(_dp))
+    assert rc == 0
+    return cx, cy, xy, z, st
+
+
 REPLAY_STRIDE = 20
 
 

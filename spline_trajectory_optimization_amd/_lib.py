@@ -90,6 +90,10 @@ _SIGNATURES = {
                                                     ctypes.c_int, _dp, _dp, _dp, _dp, ctypes.POINTER(Stats)]),
     "rl_qss_sim": (ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp, _dp,
                                   ctypes.c_int, _dp, _ip]),
+    "rl_mincurv_global_xy_batch_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                                      _vp, _vp, _vp, _vp, ctypes.POINTER(Stats)]),
+    "rl_mincurv_global_xy_batch_host": (ctypes.c_int, [_vp, _vp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                       ctypes.c_int, _dp, _dp, _dp, _dp, ctypes.POINTER(Stats)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

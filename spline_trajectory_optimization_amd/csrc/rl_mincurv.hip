@@ -19,6 +19,7 @@
 #include "rl_qss_df.hpp"
 #include "rl_global.hpp"
 #include "rl_global2.hpp"
+#include "rl_global_xy.hpp"
 #include "rl_dtrack.hpp"
 #include "rl_mintime.hpp"
 
@@ -245,6 +246,10 @@ struct rl_track {
   mutable DevBuf<int> gq2_chunk, gq2_span;  // chunks of <= gq2_rows rows (k_global_qp2), if they fit
   mutable int gq_nc = 0, gq2_nc = 0, gq2_rows = 0;  // gq2_rows = 0: the fast path does not fit
   mutable bool gq_valid = false;
+  // tables of the two-coordinate global QP (rl_global_xy.hpp)
+  mutable DevBuf<int> gxy_span;
+  mutable DevBuf<double> gxy_bbx;
+  mutable bool gxy_valid = false;
   rl::TrackDev dev() const {
     rl::TrackDev d;
     d.k = k; d.n = n; d.nt = nt; d.N = N;
@@ -681,6 +686,7 @@ int rl_track_set_control_points(rl_track* trk, const double* cx0, const double* 
   RL_HIP(hipGetLastError());
   RL_HIP(hipStreamSynchronize(ctx->stream));
   trk->gq_valid = false;
+  trk->gxy_valid = false;
   trk->strict_valid = false;
   return RL_OK;
 }
@@ -1060,8 +1066,104 @@ int global_common(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,
   return launch_global_t<5, 1024>(ctx, a, B, block, lds);
 }
 
+// ---- the two-coordinate formulation (rl_global_xy.hpp)
+int global_xy_tables(const rl_ctx* ctx, const rl_track* trk) {
+  if (trk->gxy_valid) return RL_OK;
+  const int k = trk->k, n = trk->n, N = trk->N, np = n - k;
+  if (np < 2 * (k + 1)) return fail(RL_ERR_UNSUPPORTED, "too few control points for the global QP");
+  if (2 * np > rl::kXYMaxNz) return fail(RL_ERR_UNSUPPORTED, "global QP (dof 2): more than 96 free control points");
+  std::vector<int> first(np + 1, 0);
+  const double step = 1.0 / (double)N;
+  int prev = -1;
+  for (int i = 0; i < N; ++i) {   // spans are consecutive sample ranges; empty spans get the next span's first sample
+    const int s = host_find_interval(trk->t_host, k, n, (double)i * step) - k;
+    for (int q = prev + 1; q <= s; ++q) first[q] = i;
+    prev = std::max(prev, s);
+  }
+  for (int q = prev + 1; q <= np; ++q) first[q] = N;
+  RL_HIP(trk->gxy_span.alloc(first.size()));
+  RL_HIP(hipMemcpyAsync(trk->gxy_span.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  const int K1 = k + 1;
+  RL_HIP(trk->gxy_bbx.alloc((size_t)N * (K1 * (K1 + 1) / 2 + K1)));
+  const rl::TrackDev td = trk->dev();
+  if (k == 3) hipLaunchKernelGGL(rl::k_global_xy_pairs<3>, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, td, trk->gxy_bbx.p);
+  else hipLaunchKernelGGL(rl::k_global_xy_pairs<5>, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, td, trk->gxy_bbx.p);
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipStreamSynchronize(ctx->stream));  // `first` is a host vector
+  trk->gxy_valid = true;
+  return RL_OK;
+}
+
+template <int K, int NT>
+int launch_global_xy_t(const rl_ctx* ctx, const rl::GlobalXYArgs& a, int B, size_t lds) {
+  auto kern = rl::k_global_xy<K, NT>;
+  RL_HIP(grant_dyn_lds(const_cast<rl_ctx*>(ctx), reinterpret_cast<const void*>(kern), lds));
+  hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, ctx->stream, a);
+  RL_HIP(hipGetLastError());
+  return RL_OK;
+}
+
+int global_xy_common(rl_ctx* ctx, const rl_track* trk, const double* widths, int B, double margin, double lon, int n_outer,
+                     double* out_ctrl, double* out_xy, double* out_z, double* out_stats, rl_stats* stats) {
+  if (!ctx || !trk || !widths || !out_ctrl || !out_stats) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
+  if (n_outer < 0 || n_outer > 64) return fail(RL_ERR_ARG, "n_outer out of range");
+  if (!(lon > 0.0)) return fail(RL_ERR_ARG, "the longitudinal bound must be positive");
+  if (!degree_supported(trk->k)) return fail(RL_ERR_UNSUPPORTED, "spline degree must be 3 or 5");
+  RL_HIP(hipSetDevice(ctx->device));
+  if (int rc = global_xy_tables(ctx, trk)) return rc;
+  rl::GlobalXYArgs a;
+  a.trk = trk->dev();
+  a.span_first = trk->gxy_span.p; a.bbx = trk->gxy_bbx.p; a.np = trk->n - trk->k;
+  a.widths = widths; a.margin = margin; a.lon = lon; a.n_outer = n_outer; a.max_ipm = 80;
+  a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_z = out_z; a.out_stats = out_stats;
+  const int block = trk->N <= 512 * rl::kXYRows ? 512 : 1024;
+  if (trk->N > block * rl::kXYRows) return fail(RL_ERR_UNSUPPORTED, "global QP (dof 2): more than 4096 samples");
+  const size_t lds = (size_t)rl::global_xy_layout(trk->k, trk->n, a.np, trk->N).total * sizeof(double);
+  if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "global QP (dof 2) does not fit LDS");
+  if (stats) { stats->lds_bytes = (int)lds; stats->block_threads = block; stats->rings_in_lds = 0; }
+  if (trk->k == 3) return block == 512 ? launch_global_xy_t<3, 512>(ctx, a, B, lds) : launch_global_xy_t<3, 1024>(ctx, a, B, lds);
+  return block == 512 ? launch_global_xy_t<5, 512>(ctx, a, B, lds) : launch_global_xy_t<5, 1024>(ctx, a, B, lds);
+}
+
 }  // namespace
 }  // extern "C++"
+
+int rl_mincurv_global_xy_batch_dev(rl_ctx* ctx, const rl_track* trk, const double* widths, int B, double margin, double lon,
+                                   int n_outer, double* out_ctrl, double* out_xy, double* out_z, double* out_stats,
+                                   rl_stats* stats) {
+  return global_xy_common(ctx, trk, widths, B, margin, lon, n_outer, out_ctrl, out_xy, out_z, out_stats, stats);
+}
+
+int rl_mincurv_global_xy_batch_host(rl_ctx* ctx, const rl_track* trk, const double* widths, int B, double margin, double lon,
+                                    int n_outer, double* out_ctrl, double* out_xy, double* out_z, double* out_stats,
+                                    rl_stats* stats) {
+  if (!ctx || !trk || !widths || !out_ctrl || !out_stats) return fail(RL_ERR_ARG, "null argument");
+  if (B <= 0) return fail(RL_ERR_ARG, "B <= 0");
+  RL_HIP(hipSetDevice(ctx->device));
+  const int n = trk->n, N = trk->N, np = n - trk->k;
+  PoolBuf<double> dw(ctx), dctrl(ctx), dxy(ctx), dz(ctx), dst(ctx);
+  RL_HIP(dw.alloc((size_t)B * N * 2)); RL_HIP(dctrl.alloc((size_t)B * n * 2));
+  if (out_xy) RL_HIP(dxy.alloc((size_t)B * N * 2));
+  if (out_z) RL_HIP(dz.alloc((size_t)B * np * 2));
+  RL_HIP(dst.alloc((size_t)B * 8));
+  RL_HIP(hipMemcpyAsync(dw.p, widths, dw.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = global_xy_tables(ctx, trk)) return rc;  // keeps the table build out of the timed region
+  RL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  if (int rc = global_xy_common(ctx, trk, dw.p, B, margin, lon, n_outer, dctrl.p, dxy.p, dz.p, dst.p, stats)) return rc;
+  RL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  RL_HIP(hipMemcpyAsync(out_ctrl, dctrl.p, dctrl.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_xy) RL_HIP(hipMemcpyAsync(out_xy, dxy.p, dxy.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_z) RL_HIP(hipMemcpyAsync(out_z, dz.p, dz.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipMemcpyAsync(out_stats, dst.p, dst.n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RL_HIP(hipStreamSynchronize(ctx->stream));
+  if (stats) {
+    float ms = 0.f;
+    RL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->kernel_ms = ms;
+  }
+  return RL_OK;
+}
 
 int rl_mincurv_global_batch_dev(rl_ctx* ctx, const rl_track* trk, const double* widths, int B,
                                 double margin, int n_outer, double* out_ctrl, double* out_xy,

@@ -189,14 +189,24 @@ def solve_batch_torch(track, bounds_form, bounds, i_start, search=_lib.SEARCH_WI
     return out
 
 
-def global_batch_host(track, widths, margin=0.0, n_outer=6, want_xy=True):
+def global_batch_host(track, widths, margin=0.0, n_outer=6, want_xy=True, dof=1, lon=1.0):
     """Global min-curvature QP (include/rl_mincurv.h: rl_mincurv_global_batch_host) for B width
     instances [B,N,2] = (w_left, w_right).  Returns (ctrl [B,n,2], xy [B,N,2] | None, a [B,n-k],
-    stats [B,8], rl_stats)."""
+    stats [B,8], rl_stats).  dof=2: both coordinates of every control point free, lateral and +-`lon` m longitudinal rows
+    (rl_mincurv_global_xy_batch_host; the third result is then z [B,n-k,2])."""
     ctx = track.ctx
     widths, wp = as_d(widths)
     B = widths.shape[0]
     assert widths.shape == (B, track.N, 2), widths.shape
+    if dof == 2:
+        ctrl = np.zeros((B, track.n, 2)); z = np.zeros((B, track.n - track.k, 2)); stats = np.zeros((B, 8))
+        xy = np.zeros((B, track.N, 2)) if want_xy else None
+        st = Stats()
+        check(ctx.lib.rl_mincurv_global_xy_batch_host(
+            ctx.h, track.h, wp, int(B), float(margin), float(lon), int(n_outer), ctrl.ctypes.data_as(_dp),
+            xy.ctypes.data_as(_dp) if want_xy else None, z.ctypes.data_as(_dp), stats.ctypes.data_as(_dp), ctypes.byref(st)))
+        return ctrl, xy, z, stats, st
+    assert dof == 1, dof
     ctrl = np.zeros((B, track.n, 2)); a = np.zeros((B, track.n - track.k)); stats = np.zeros((B, 8))
     xy = np.zeros((B, track.N, 2)) if want_xy else None
     st = Stats()
@@ -207,15 +217,32 @@ def global_batch_host(track, widths, margin=0.0, n_outer=6, want_xy=True):
     return ctrl, xy, a, stats, st
 
 
-def global_batch_torch(track, widths, margin=0.0, n_outer=6, out=None):
+def global_batch_torch(track, widths, margin=0.0, n_outer=6, out=None, dof=1, lon=1.0):
     """Same on DEVICE tensors: widths float64 cuda [B,N,2]; enqueues on torch's current stream, no
-    sync.  Returns dict(ctrl, xy, a, stats) of cuda tensors."""
+    sync.  Returns dict(ctrl, xy, a, stats) of cuda tensors (dof=2: `z` [B,n-k,2] instead of `a`)."""
     import torch
     ctx = track.ctx
     assert widths.is_cuda and widths.dtype == torch.float64 and widths.is_contiguous()
     B = widths.shape[0]
     assert tuple(widths.shape) == (B, track.N, 2)
     dev = widths.device
+    if dof == 2:
+        if out is None:
+            out = {
+                "ctrl": torch.empty((B, track.n, 2), dtype=torch.float64, device=dev),
+                "xy": torch.empty((B, track.N, 2), dtype=torch.float64, device=dev),
+                "z": torch.empty((B, track.n - track.k, 2), dtype=torch.float64, device=dev),
+                "stats": torch.empty((B, 8), dtype=torch.float64, device=dev),
+            }
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        st = Stats()
+        check(ctx.lib.rl_mincurv_global_xy_batch_dev(
+            ctx.h, track.h, ctypes.c_void_p(widths.data_ptr()), int(B), float(margin), float(lon), int(n_outer),
+            ctypes.c_void_p(out["ctrl"].data_ptr()), ctypes.c_void_p(out["xy"].data_ptr()),
+            ctypes.c_void_p(out["z"].data_ptr()), ctypes.c_void_p(out["stats"].data_ptr()), ctypes.byref(st)))
+        out["rl_stats"] = st
+        return out
+    assert dof == 1, dof
     if out is None:
         out = {
             "ctrl": torch.empty((B, track.n, 2), dtype=torch.float64, device=dev),
