@@ -35,6 +35,9 @@ namespace rl {
 
 constexpr int kXYRows = 4;     // samples per thread
 constexpr int kXYMaxNz = 192;  // unknowns: three rows per lane in the solves
+// interior-point tolerances of the linearisations before the last: tighter than kGLooseMu / kGLooseRes -- with both coordinates free
+// an under-converged iterate is a badly conditioned function of the data (measurement in the comment of the CPU twin)
+constexpr double kXYLooseMu = 1e-7, kXYLooseRes = 1e-6;
 
 struct GlobalXYArgs {
   TrackDev trk;
@@ -567,7 +570,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       }
       {
         const bool last_qp = outer + 1 >= a.n_outer;
-        if (fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : kGLooseRes) && mu < (last_qp ? 1e-10 : kGLooseMu)) break;
+        if (fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : kXYLooseRes) && mu < (last_qp ? 1e-10 : kXYLooseMu)) break;
       }
       ++total_it;
       // ---- affine direction

@@ -1,0 +1,235 @@
+"""The global min-curvature QP with BOTH coordinates of every control point free (second formulation;
+include/rl_mincurv.h: rl_mincurv_global_xy_batch_*): the unknowns and rows of the reference's Julia prototype
+(julia/spline_traj_opt.ipynb L247-281, L410-432) with the corrections of SURVEY.md App. A.6.
+
+The prototype does not converge in its own recorded output and Julia is not in this image, so there is no reference vector to
+match ("parity unpinned", as for the one-offset formulation).  What is checked instead:
+
+* CPU (not gpu): the oracle's twin `orc_global_mincurv_xy` against an INDEPENDENT numpy statement of the formulation --
+  Gauss-Newton rows by central differences of scipy's BSpline curvature in each coordinate of each control point, constraint
+  rows by moving one coordinate at a time -- through the KKT conditions of the QP (multipliers by non-negative least squares
+  on the active rows), feasibility of both row kinds, the step rule (whole or half step, whichever costs less).
+* GPU: the HIP kernel `k_global_xy` against that twin on the same inputs (equal interior-point
+  iteration counts and the same halving decisions; offsets and line to 2e-6 m), and size-independent properties on the benchmarked batch."""
+import numpy as np
+import pytest
+from scipy.interpolate import BSpline
+from scipy.optimize import nnls
+
+from conftest import golden, spline
+from oracle import oracle as orc
+from test_global_qp import MARGIN, monza_widths
+
+LON = 1.0   # the notebook's longitudinal bound [m]
+TOL = 2e-6  # [m] kernel against twin (the twin itself answers a 1e-9 m change of the widths with up to 3e-7 m: its comment)
+
+
+class NumpyGlobalXY:
+    """Independent statement of the formulation in include/rl_mincurv.h (rl_mincurv_global_xy_batch_*)."""
+
+    def __init__(self, t, cx, cy, k, u):
+        self.t, self.k, self.u = t, k, u
+        self.n = len(cx)
+        self.np = self.n - k
+        self.c0 = np.stack([cx, cy], 1)
+        sx, sy = BSpline(t, cx, k), BSpline(t, cy, k)
+        self.p0 = np.stack([sx(u), sy(u)], 1)
+        d0 = np.stack([sx(u, 1), sy(u, 1)], 1)
+        self.t0 = d0 / np.hypot(d0[:, 0], d0[:, 1])[:, None]
+        self.n0 = np.stack([-self.t0[:, 1], self.t0[:, 0]], 1)
+
+    def ctrl(self, z):           # z [np, 2]
+        c = self.c0.copy()
+        c[:self.np] += z
+        c[self.np:] = c[:self.k]
+        return c
+
+    def kappa(self, z):
+        c = self.ctrl(z)
+        bx, by = BSpline(self.t, c[:, 0], self.k), BSpline(self.t, c[:, 1], self.k)
+        dx, dy, ddx, ddy = bx(self.u, 1), by(self.u, 1), bx(self.u, 2), by(self.u, 2)
+        return (dx * ddy - dy * ddx) / (dx * dx + dy * dy) ** 1.5
+
+    def offsets(self, z):        # (lateral, longitudinal) of every sample
+        c = self.ctrl(z)
+        r = np.stack([BSpline(self.t, c[:, 0], self.k)(self.u), BSpline(self.t, c[:, 1], self.k)(self.u)], 1)
+        return ((r - self.p0) * self.n0).sum(1), ((r - self.p0) * self.t0).sum(1)
+
+    def qp_at(self, z, h=1e-3):
+        N, m = len(self.u), 2 * self.np
+        G = np.zeros((N, m))
+        A = np.zeros((2 * N, m))
+        for j in range(self.np):
+            for c in range(2):
+                e = np.zeros((self.np, 2))
+                e[j, c] = 1.0
+                G[:, 2 * j + c] = (self.kappa(z + h * e) - self.kappa(z - h * e)) / (2 * h)
+                lat, lon = self.offsets(e)
+                A[:N, 2 * j + c] = lat
+                A[N:, 2 * j + c] = lon
+        res = self.kappa(z) - G @ z.reshape(-1)
+        P = 2 * G.T @ G
+        q = 2 * G.T @ res
+        sc = m / np.trace(P)
+        return P * sc + 1e-9 * np.eye(m), q * sc, A
+
+
+@pytest.mark.parametrize("tag,N", [("c100", 500), ("c100", 2000)])
+def test_twin_solves_the_qp_kkt(fits, tag, N):
+    """One linearisation: the twin's interior-point answer satisfies the KKT conditions of the independently assembled QP
+    (the twin then takes the whole or the half step; the QP's answer is recovered from either)."""
+    t, cx, cy, k, u, wl, wr = monza_widths(fits, tag, N)
+    ocx, ocy, oxy, oz, st = orc.global_mincurv_xy(t, cx, cy, k, N, wl, wr, MARGIN, LON, 1)
+    ng = NumpyGlobalXY(t, cx, cy, k, u)
+    P, q, A = ng.qp_at(np.zeros((ng.np, 2)))
+    x = oz.reshape(-1) * (2.0 if st[7] == 1 else 1.0)       # the QP's solution (start z = 0: a halved step is x / 2)
+    lo = np.concatenate([-(wr - MARGIN), -LON * np.ones(N)])
+    hi = np.concatenate([wl - MARGIN, LON * np.ones(N)])
+    Ax = A @ x
+    assert (lo - Ax).max() <= 1e-8 and (Ax - hi).max() <= 1e-8           # primal feasibility, both row kinds
+    r = P @ x + q
+    au, al = np.where(hi - Ax < 1e-6)[0], np.where(Ax - lo < 1e-6)[0]
+    assert (au >= N).any() or (al >= N).any()                            # longitudinal rows do bind: the +-1 m matters
+    assert (au < N).any() or (al < N).any()                              # and so do the track bounds
+    lam, resid = nnls(np.concatenate([A[au].T, -A[al].T], 1), -r)
+    print(f"[global xy kkt {tag} N={N}] active {len(au)}+{len(al)} of {4 * N}, stationarity residual {resid:.2e} "
+          f"(|q|inf {np.abs(q).max():.2e}), ipm iterations {int(st[0])}, halved {int(st[7])}")
+    assert resid <= 1e-6 * np.abs(q).max()                               # stationarity with lambda >= 0
+    # the twin's bookkeeping agrees with the independent evaluation
+    assert st[1] == pytest.approx((ng.kappa(np.zeros((ng.np, 2))) ** 2).sum(), rel=1e-10)
+    assert st[2] == pytest.approx((ng.kappa(oz) ** 2).sum(), rel=1e-9)
+    assert np.abs(ng.ctrl(oz) - np.stack([ocx, ocy], 1)).max() <= 1e-9
+    lat, lon = ng.offsets(oz)
+    assert np.abs(lat - A[:N] @ oz.reshape(-1)).max() <= 1e-9 and np.abs(lon - A[N:] @ oz.reshape(-1)).max() <= 1e-9
+
+
+def test_twin_step_rule_and_convergence(fits):
+    """More linearisations: the line stays inside both row kinds, the cost never goes up (the whole or the half step, whichever
+    costs less -- plain Gauss-Newton 2-cycles on Monza's near-straights with 0.53 m between consecutive linearisations), at least
+    one step is halved, and the steps shrink."""
+    t, cx, cy, k, u, wl, wr = monza_widths(fits, "c100", 2000)
+    ng = NumpyGlobalXY(t, cx, cy, k, u)
+    cost, step, halved = [], [], []
+    for n_outer in (1, 2, 4, 6, 10):
+        _, _, oxy, oz, st = orc.global_mincurv_xy(t, cx, cy, k, 2000, wl, wr, MARGIN, LON, n_outer)
+        lat, lon = ng.offsets(oz)
+        assert (lat - (wl - MARGIN)).max() <= 1e-9 and (-(wr - MARGIN) - lat).max() <= 1e-9 and np.abs(lon).max() <= LON + 1e-9
+        assert st[3] <= 1e-9
+        cost.append(st[2]); step.append(st[4]); halved.append(st[7])
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(cost, cost[1:])), cost
+    assert cost[-1] < 0.6 * st[1]
+    assert halved[-1] >= 1
+    assert step[-1] < 0.05 and step[-1] < step[-2] < step[0], step       # < 5 cm control-point move on the 10th linearisation
+
+
+def test_twin_bounds_matter(fits):
+    t, cx, cy, k, u, wl, wr = monza_widths(fits, "c100", 500)
+    # a zero-width track pins the line laterally
+    z = np.full(500, 1e-3)
+    ng = NumpyGlobalXY(t, cx, cy, k, u)
+    _, _, _, oz, st = orc.global_mincurv_xy(t, cx, cy, k, 500, z, z, 0.0, LON, 2)
+    lat, lon = ng.offsets(oz)
+    assert np.abs(lat).max() <= 1e-3 + 1e-9 and np.abs(lon).max() <= LON + 1e-9
+    # a wider longitudinal bound gives a line that costs less; a wider margin one that costs more
+    _, _, _, _, s1 = orc.global_mincurv_xy(t, cx, cy, k, 500, wl, wr, MARGIN, 1.0, 3)
+    _, _, _, _, s3 = orc.global_mincurv_xy(t, cx, cy, k, 500, wl, wr, MARGIN, 3.0, 3)
+    _, _, _, _, sm = orc.global_mincurv_xy(t, cx, cy, k, 500, wl, wr, 1.0, 1.0, 3)
+    assert s3[2] < s1[2] < sm[2] and max(s1[3], s3[3], sm[3]) <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def rl():
+    from spline_trajectory_optimization_amd import _lib, batch, ops
+    _lib.Context.get(0)  # raises loudly when the HIP extension / device is missing
+
+    class NS:
+        pass
+    ns = NS()
+    ns.lib, ns.ops, ns.batch = _lib, ops, batch
+    return ns
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,N,n_outer,lon", [("c100", 500, 1, 1.0), ("c100", 500, 6, 1.0), ("c100", 2000, 3, 1.0),
+                                               ("c100", 2000, 6, 1.0), ("c100", 2000, 10, 1.0), ("c100", 1999, 3, 1.0),
+                                               ("c100", 1998, 6, 1.0), ("c100", 2300, 6, 1.0), ("c100", 2000, 4, 3.0),
+                                               ("c30", 2000, 3, 1.0), ("l10", 1000, 2, 1.0)])
+def test_kernel_vs_twin(rl, fits, tag, N, n_outer, lon):
+    """k_global_xy against orc_global_mincurv_xy: same formulation, different factorisation (folded band L D L' in LDS vs dense
+    Cholesky), different summation order, reciprocals instead of divisions in the step rule."""
+    if tag == "l10":  # degree-3 spline (the track boundary fit) with synthetic widths: half-bandwidth 7, 166 unknowns
+        t, cx, cy, k, L = spline(fits, tag)
+        wl = np.full(N, 4.0) + np.sin(np.arange(N) * 0.05)
+        wr = np.full(N, 3.0) + np.cos(np.arange(N) * 0.03)
+    else:
+        t, cx, cy, k, u, wl, wr = monza_widths(fits, tag, N)
+    ocx, ocy, oxy, oz, ost = orc.global_mincurv_xy(t, cx, cy, k, N, wl, wr, MARGIN, lon, n_outer)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    ctrl, xy, z, st, rs = rl.ops.global_batch_host(trk, np.stack([wl, wr], 1)[None], MARGIN, n_outer, dof=2, lon=lon)
+    dz, dxy = np.abs(z[0] - oz).max(), np.abs(xy[0] - oxy).max()
+    print(f"[global xy gpu {tag} N={N} outer={n_outer} lon={lon}] |dz| {dz:.2e} m |dxy| {dxy:.2e} m  ipm {int(st[0, 0])}/{int(ost[0])}"
+          f"  k2 {st[0, 1]:.5f}->{st[0, 2]:.5f}  viol {st[0, 3]:.1e}  halved {int(st[0, 7])}/{int(ost[7])}  {rs.kernel_ms:.2f} ms  "
+          f"lds {rs.lds_bytes}  block {rs.block_threads}")
+    assert dz <= TOL and dxy <= TOL
+    assert np.abs(ctrl[0] - np.stack([ocx, ocy], 1)).max() <= TOL
+    assert abs(int(st[0, 0]) - int(ost[0])) <= 1 and int(st[0, 7]) == int(ost[7])
+    assert st[0, 1] == pytest.approx(ost[1], rel=1e-9) and st[0, 2] == pytest.approx(ost[2], rel=1e-7)
+    assert st[0, 3] <= 1e-9
+
+
+@pytest.mark.gpu
+def test_batch_properties_full_size(rl, fits):
+    """BASELINE configs[1] shape (Monza N=2000, 1024 width-perturbed instances): properties that need no CPU run -- inside both
+    row kinds, cost decreased, bit-reproducible, independent of the position in the batch -- plus three instances against the twin."""
+    t, cx, cy, k, u, wl, wr = monza_widths(fits, "c100", 2000)
+    B = 1024
+    W = rl.batch.width_batch(wl, wr, B, seed=1234)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, 2000)
+    ctrl, xy, z, st, rs = rl.ops.global_batch_host(trk, W, MARGIN, 6, dof=2, lon=LON)
+    assert np.isfinite(xy).all() and np.isfinite(z).all()
+    assert (st[:, 3] <= 1e-9).all() and (st[:, 2] < 0.7 * st[:, 1]).all()
+    p0 = np.stack([BSpline(t, cx, k)(u), BSpline(t, cy, k)(u)], 1)
+    d0 = np.stack([BSpline(t, cx, k)(u, 1), BSpline(t, cy, k)(u, 1)], 1)
+    t0 = d0 / np.hypot(d0[:, 0], d0[:, 1])[:, None]
+    n0 = np.stack([-t0[:, 1], t0[:, 0]], 1)
+    lat, lon = ((xy - p0[None]) * n0[None]).sum(2), ((xy - p0[None]) * t0[None]).sum(2)
+    assert (lat - (W[:, :, 0] - MARGIN)).max() <= 1e-8 and (-(W[:, :, 1] - MARGIN) - lat).max() <= 1e-8
+    assert np.abs(lon).max() <= LON + 1e-8
+    ctrl2, xy2, z2, st2, _ = rl.ops.global_batch_host(trk, W, MARGIN, 6, dof=2, lon=LON)
+    assert np.array_equal(xy, xy2) and np.array_equal(z, z2) and np.array_equal(st, st2)
+    perm = np.random.default_rng(7).permutation(B)
+    _, xy3, z3, _, _ = rl.ops.global_batch_host(trk, W[perm], MARGIN, 6, dof=2, lon=LON)
+    assert np.array_equal(xy3, xy[perm]) and np.array_equal(z3, z[perm])
+    for b in (0, 511, 1023):
+        _, _, oxy, oz, ost = orc.global_mincurv_xy(t, cx, cy, k, 2000, W[b, :, 0], W[b, :, 1], MARGIN, LON, 6)
+        assert np.abs(xy[b] - oxy).max() <= TOL and abs(int(st[b, 0]) - int(ost[0])) <= 1 and int(st[b, 7]) == int(ost[7])
+    print(f"[global xy batch] {B} instances, {rs.kernel_ms:.2f} ms, {B / rs.kernel_ms * 1e3:.0f} 6-linearisation solves/s, "
+          f"ipm iterations {st[:, 0].min():.0f}..{st[:, 0].max():.0f}, sum kappa^2 {st[:, 1].mean():.4f} -> {st[:, 2].mean():.4f}, "
+          f"halved steps {st[:, 7].mean():.2f} per instance")
+
+
+@pytest.mark.gpu
+def test_torch_entry_and_errors(rl, fits):
+    import torch
+    t, cx, cy, k, u, wl, wr = monza_widths(fits, "c100", 500)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, 500)
+    W = rl.batch.width_batch(wl, wr, 8, seed=3)
+    ctrl, xy, z, st, _ = rl.ops.global_batch_host(trk, W, MARGIN, 3, dof=2)
+    out = rl.ops.global_batch_torch(trk, torch.from_numpy(W).cuda(), MARGIN, 3, dof=2)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["xy"].cpu().numpy(), xy) and np.array_equal(out["z"].cpu().numpy(), z)
+    # the one-offset formulation is unchanged by the new entry points
+    c1, xy1, a1, st1, _ = rl.ops.global_batch_host(trk, W, MARGIN, 3)
+    assert a1.shape == (8, len(cx) - k) and (st1[:, 2] < st[:, 2] * 1.5).all()
+    with pytest.raises(rl.lib.RlError):
+        rl.ops.global_batch_host(trk, W, MARGIN, 3, dof=2, lon=0.0)            # the longitudinal bound must be positive
+    with pytest.raises(rl.lib.RlError):
+        rl.ops.global_batch_host(trk, W, MARGIN, -1, dof=2)
+    t8, cx8, cy8, k8, _ = spline(fits, "c0p8")                                   # 169 free control points: 338 unknowns
+    trk8 = rl.lib.Track(rl.lib.Context.get(0), t8, cx8, cy8, k8, 500)
+    with pytest.raises(rl.lib.RlError):
+        rl.ops.global_batch_host(trk8, W, MARGIN, 1, dof=2)
+    trk4 = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, 4000)              # the per-instance state does not fit LDS
+    with pytest.raises(rl.lib.RlError):
+        rl.ops.global_batch_host(trk4, np.ones((1, 4000, 2)) * 5.0, MARGIN, 1, dof=2)
