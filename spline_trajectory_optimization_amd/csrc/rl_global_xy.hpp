@@ -91,6 +91,19 @@ __global__ void k_global_xy_pairs(TrackDev tr, double* __restrict__ bbx) {
   for (int a = 0; a < K1; ++a) bbx[(size_t)i * ROW + NE + a] = b[a];
 }
 
+// A zero the compiler cannot see through, re-made wherever it is called.  Added to the index of a table or LDS access it keeps
+// the address computation INSIDE the loop that uses it: hoisted out of the interior-point loop, the ~100 loop-invariant
+// addresses of this kernel (six basis rows x four samples x three tables, ...) are spilled to scratch and every load first
+// waits for its own address to come back from memory.
+__device__ __forceinline__ int xy_opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+__device__ __forceinline__ double xy_uniform(double v) {   // a wave-uniform value into scalar registers
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // position of cyclic unknown u in the folded order 0, nz-1, 1, nz-2, ... and back (nz even)
 __device__ __forceinline__ int xy_fold(int u, int nz) { return u < (nz >> 1) ? 2 * u : 2 * (nz - 1 - u) + 1; }
 __device__ __forceinline__ int xy_unfold(int r, int nz) { return (r & 1) ? nz - 1 - (r >> 1) : (r >> 1); }
@@ -202,25 +215,29 @@ __device__ __forceinline__ void xy_span_sums(const double* __restrict__ bbx, int
   for (int task = t0; task < np * NT_; task += nth) {
     const int sp = task / NT_, p = task - sp * NT_;
     const int e0 = sfirst[sp], e1 = sfirst[sp + 1];
-    const double* __restrict__ col = bbx + (MODE == 0 ? p : NE + p);
+    const int oz = xy_opaque_zero();
+    const double* __restrict__ col = bbx + ((MODE == 0 ? p : NE + p) + oz);
+    const double* wbo = wb + oz;
+    const double2* wb2o = wb2 + oz;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int base = e0; base < e1; base += U) {
+      // past the span: the last sample again, with a zero table value -- no branch in the batch, so that the U table loads
+      // are issued together
       double tv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) tv[u] = col[(size_t)min(base + u, e1 - 1) * ROW];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = base + u;
-        if (i < e1) {
-          if (MODE == 0) {
-            a0 = fma(tv[u], wb[i], a0); a1 = fma(tv[u], wb[N + i], a1); a2 = fma(tv[u], wb[2 * N + i], a2);
-          } else if (MODE == 1) {
-            const double2 v0 = wb2[i], v1 = wb2[N + i];
-            a0 = fma(tv[u], v0.x, a0); a1 = fma(tv[u], v0.y, a1); a2 = fma(tv[u], v1.x, a2); a3 = fma(tv[u], v1.y, a3);
-          } else {
-            const double2 v0 = wb2[i];
-            a0 = fma(tv[u], v0.x, a0); a1 = fma(tv[u], v0.y, a1);
-          }
+        const int i = min(base + u, e1 - 1);
+        const double t = base + u < e1 ? tv[u] : 0.0;
+        if (MODE == 0) {
+          a0 = fma(t, wbo[i], a0); a1 = fma(t, wbo[N + i], a1); a2 = fma(t, wbo[2 * N + i], a2);
+        } else if (MODE == 1) {
+          const double2 v0 = wb2o[i], v1 = wb2o[N + i];
+          a0 = fma(t, v0.x, a0); a1 = fma(t, v0.y, a1); a2 = fma(t, v1.x, a2); a3 = fma(t, v1.y, a3);
+        } else {
+          const double2 v0 = wb2o[i];
+          a0 = fma(t, v0.x, a0); a1 = fma(t, v0.y, a1);
         }
       }
     }
@@ -262,7 +279,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     double a1 = 0.0, a2 = 0.0, mx = -INFINITY, mn = INFINITY;
     for (int w = 0; w < nw; ++w) { a1 += red[w]; a2 += red[16 + w]; mx = fmax(mx, red[32 + w]); mn = fmin(mn, red[48 + w]); }
     __syncthreads();
-    s1 = a1; s2 = a2; vmax = mx; vmin = mn;
+    s1 = xy_uniform(a1); s2 = xy_uniform(a2); vmax = xy_uniform(mx); vmin = xy_uniform(mn);
   };
   auto wrap = [&](double2* v) {   // periodic copies of the first k control points; call between barriers
     if (tid < K) v[np + tid] = v[tid];
@@ -290,7 +307,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     }
   }
   auto lat_bounds = [&](int r, double& lo_, double& hi_) {   // (read where needed: two registers per sample less to keep)
-    const double2 w = reinterpret_cast<const double2*>(wid)[i0 + r];
+    const double2 w = reinterpret_cast<const double2*>(wid)[i0 + r + xy_opaque_zero()];
     lo_ = -(w.y - a.margin); hi_ = w.x - a.margin;
   };
   for (int j = tid; j < n; j += NT) {
@@ -315,11 +332,12 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
   // of LDS control-point pairs: (px, py) = sum_al b_al v[j0 + al]
   static_assert(R == 4, "load_b reads two double2 per basis function");
   auto load_b = [&](double (&bv)[K1][R]) {
+    const int oz = xy_opaque_zero();
 #pragma unroll
     for (int al = 0; al < K1; ++al) {
       double2 v0 = make_double2(0.0, 0.0), v1 = v0;
       if (i0 < N) {   // (a sample index past N - 1 reads the next row of the table: never used)
-        const double2* __restrict__ p = reinterpret_cast<const double2*>(D0 + (size_t)al * N + i0);
+        const double2* __restrict__ p = reinterpret_cast<const double2*>(D0 + ((size_t)al * N + i0 + oz));
         v0 = p[0]; v1 = p[1];
       }
       bv[al][0] = v0.x; bv[al][1] = v0.y; bv[al][2] = v1.x; bv[al][3] = v1.y;
@@ -327,9 +345,10 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
   };
   auto dot_b = [&](const double (&bv)[K1][R], int r, const double2* v, double& px, double& py) {
     px = 0.0; py = 0.0;
+    const double2* vo = v + xy_opaque_zero();
 #pragma unroll
     for (int al = 0; al < K1; ++al) {
-      const double2 x = v[j0[r] + al];
+      const double2 x = vo[j0[r] + al];
       px = fma(bv[al][r], x.x, px); py = fma(bv[al][r], x.y, py);
     }
   };
@@ -356,12 +375,13 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     for (int r = 0; r < R; ++r) {
       gres[r] = 0.0;
       if (ok[r]) {
-        const int i = i0 + r;
+        const int oz = xy_opaque_zero();
+        const int i = i0 + r + oz;
         double dx = 0, dy = 0, ddx = 0, ddy = 0, zdx = 0, zdy = 0, zddx = 0, zddy = 0;
 #pragma unroll
         for (int al = 0; al < K1; ++al) {
           const double b1 = D1[(size_t)al * N + i], b2 = D2[(size_t)al * N + i];
-          const double2 c = cs[j0[r] + al], z = zs[j0[r] + al];
+          const double2 c = cs[j0[r] + al + oz], z = zs[j0[r] + al + oz];
           dx = fma(c.x, b1, dx); dy = fma(c.y, b1, dy); ddx = fma(c.x, b2, ddx); ddy = fma(c.y, b2, ddy);
           zdx = fma(z.x, b1, zdx); zdy = fma(z.y, b1, zdy); zddx = fma(z.x, b2, zddx); zddy = fma(z.y, b2, zddy);
         }
@@ -389,8 +409,9 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       for (int al = d; al <= K; ++al) {
         int s = j1 - al; if (s < 0) s += np;
         const int be = al - d;
-        const double* __restrict__ p1a = D1 + (size_t)al * N; const double* __restrict__ p2a = D2 + (size_t)al * N;
-        const double* __restrict__ p1b = D1 + (size_t)be * N; const double* __restrict__ p2b = D2 + (size_t)be * N;
+        const int oz = xy_opaque_zero();
+        const double* __restrict__ p1a = D1 + ((size_t)al * N + oz); const double* __restrict__ p2a = D2 + ((size_t)al * N + oz);
+        const double* __restrict__ p1b = D1 + ((size_t)be * N + oz); const double* __restrict__ p2b = D2 + ((size_t)be * N + oz);
         const int e0 = sfirst[s], e1 = sfirst[s + 1];
 #pragma unroll 2
         for (int i = e0; i < e1; ++i) {
@@ -495,7 +516,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             mu += sl[kd][r] * ll[kd][r] + su[kd][r] * lu[kd][r];
             rpmax = fmax(rpmax, fmax(fabs(rpl[kd][r]), fabs(rpu[kd][r])));
           }
-          const int i = i0 + r;
+          const int i = i0 + r + xy_opaque_zero();
           const double x2 = nx[r] * nx[r], y2 = ny[r] * ny[r], xy = nx[r] * ny[r];
           wb[i] = dm[0] * x2 + dm[1] * y2;
           wb[N + i] = (dm[0] - dm[1]) * xy;
@@ -545,8 +566,9 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             const double ql = ll[kd][r] * frcp(sl[kd][r]), qu = lu[kd][r] * frcp(su[kd][r]);
             e[kd] = qu * rpu[kd][r] - ql * rpl[kd][r]; dl[kd] = lu[kd][r] - ll[kd][r];
           }
-          wb2[i0 + r] = make_double2(e[0] * nx[r] + e[1] * ny[r], e[0] * ny[r] - e[1] * nx[r]);
-          wb2[N + i0 + r] = make_double2(dl[0] * nx[r] + dl[1] * ny[r], dl[0] * ny[r] - dl[1] * nx[r]);
+          const int i = i0 + r + xy_opaque_zero();
+          wb2[i] = make_double2(e[0] * nx[r] + e[1] * ny[r], e[0] * ny[r] - e[1] * nx[r]);
+          wb2[N + i] = make_double2(dl[0] * nx[r] + dl[1] * ny[r], dl[0] * ny[r] - dl[1] * nx[r]);
         }
       }
       __syncthreads();
@@ -582,9 +604,13 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       // one row of the step equations: the affine step from A dx_aff (smu = 0, no second-order term), or the final step
       // from A dx with the second-order term of the affine one.  Everything is recomputed from the few numbers kept per row
       // (A dx_aff, A dx): keeping the deltas themselves would spill.
-      double adxa[2][R], adxc[2][R];
+      // A dx_aff lives in the upper half of the weight buffer (free after the vector sums), A dx in the lower half (free after
+      // the corrector's sums): 32 registers less across the row passes
+      double* adxa_l = wb + 2 * N;
+      double* adxc_l = wb;
       auto affine_row = [&](int kd, int r, double i_sl, double i_su, double& d_sl, double& d_su, double& d_ll, double& d_lu) {
-        d_sl = adxa[kd][r] + rpl[kd][r]; d_su = rpu[kd][r] - adxa[kd][r];
+        const double adx = adxa_l[kd * N + i0 + r + xy_opaque_zero()];
+        d_sl = adx + rpl[kd][r]; d_su = rpu[kd][r] - adx;
         d_ll = (-(sl[kd][r] * ll[kd][r]) - ll[kd][r] * d_sl) * i_sl;
         d_lu = (-(su[kd][r] * lu[kd][r]) - lu[kd][r] * d_su) * i_su;
       };
@@ -599,10 +625,12 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             dot_b(bv, r, dxs, px, py);
 #pragma unroll
             for (int kd = 0; kd < 2; ++kd) {
-              adxa[kd][r] = kd == 0 ? nx[r] * px + ny[r] * py : ny[r] * px - nx[r] * py;
+              const double adx = kd == 0 ? nx[r] * px + ny[r] * py : ny[r] * px - nx[r] * py;
+              adxa_l[kd * N + i0 + r] = adx;
               const double i_sl = frcp(sl[kd][r]), i_su = frcp(su[kd][r]);
-              double d_sl, d_su, d_ll, d_lu;
-              affine_row(kd, r, i_sl, i_su, d_sl, d_su, d_ll, d_lu);
+              const double d_sl = adx + rpl[kd][r], d_su = rpu[kd][r] - adx;
+              const double d_ll = (-(sl[kd][r] * ll[kd][r]) - ll[kd][r] * d_sl) * i_sl;
+              const double d_lu = (-(su[kd][r] * lu[kd][r]) - lu[kd][r] * d_su) * i_su;
               rmax = fmax(rmax, fmax(fmax(-d_sl * i_sl, -d_su * i_su),
                                      fmax(-d_ll * __builtin_amdgcn_rcp(ll[kd][r]), -d_lu * __builtin_amdgcn_rcp(lu[kd][r]))));
               c1 += sl[kd][r] * d_ll + ll[kd][r] * d_sl + su[kd][r] * d_lu + lu[kd][r] * d_su;
@@ -634,7 +662,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             const double rcl = sl[kd][r] * ll[kd][r] - smu + d_sl * d_ll, rcu = su[kd][r] * lu[kd][r] - smu + d_su * d_lu;
             wv[kd] = (-rcl - ll[kd][r] * rpl[kd][r]) * i_sl - (-rcu - lu[kd][r] * rpu[kd][r]) * i_su;
           }
-          wb2[i0 + r] = make_double2(wv[0] * nx[r] + wv[1] * ny[r], wv[0] * ny[r] - wv[1] * nx[r]);
+          wb2[i0 + r + xy_opaque_zero()] = make_double2(wv[0] * nx[r] + wv[1] * ny[r], wv[0] * ny[r] - wv[1] * nx[r]);
         }
       }
       __syncthreads();
@@ -655,7 +683,8 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
         double a_sl, a_su, a_ll, a_lu;
         affine_row(kd, r, i_sl, i_su, a_sl, a_su, a_ll, a_lu);
         const double rcl = sl[kd][r] * ll[kd][r] - smu + a_sl * a_ll, rcu = su[kd][r] * lu[kd][r] - smu + a_su * a_lu;
-        d_sl = adxc[kd][r] + rpl[kd][r]; d_su = rpu[kd][r] - adxc[kd][r];
+        const double adx = adxc_l[kd * N + i0 + r + xy_opaque_zero()];
+        d_sl = adx + rpl[kd][r]; d_su = rpu[kd][r] - adx;
         d_ll = (-rcl - ll[kd][r] * d_sl) * i_sl; d_lu = (-rcu - lu[kd][r] * d_su) * i_su;
       };
       rmax = 0.0;
@@ -669,7 +698,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             dot_b(bv, r, dxs, px, py);
 #pragma unroll
             for (int kd = 0; kd < 2; ++kd) {
-              adxc[kd][r] = kd == 0 ? nx[r] * px + ny[r] * py : ny[r] * px - nx[r] * py;
+              adxc_l[kd * N + i0 + r] = kd == 0 ? nx[r] * px + ny[r] * py : ny[r] * px - nx[r] * py;
               double d_sl, d_su, d_ll, d_lu, i_sl, i_su;
               final_row(kd, r, d_sl, d_su, d_ll, d_lu, i_sl, i_su);
               rmax = fmax(rmax, fmax(fmax(-d_sl * i_sl, -d_su * i_su),
@@ -707,12 +736,13 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (ok[r]) {
-        const int i = i0 + r;
+        const int oz = xy_opaque_zero();
+        const int i = i0 + r + oz;
         double dx = 0, dy = 0, ddx = 0, ddy = 0, sdx = 0, sdy = 0, sddx = 0, sddy = 0;
 #pragma unroll
         for (int al = 0; al < K1; ++al) {
           const double b1 = D1[(size_t)al * N + i], b2 = D2[(size_t)al * N + i];
-          const double2 c = cs[j0[r] + al], x = xs[j0[r] + al], z = zs[j0[r] + al];
+          const double2 c = cs[j0[r] + al + oz], x = xs[j0[r] + al + oz], z = zs[j0[r] + al + oz];
           const double ex = x.x - z.x, ey = x.y - z.y;
           dx = fma(c.x, b1, dx); dy = fma(c.y, b1, dy); ddx = fma(c.x, b2, ddx); ddy = fma(c.y, b2, ddy);
           sdx = fma(ex, b1, sdx); sdy = fma(ey, b1, sdy); sddx = fma(ex, b2, sddx); sddy = fma(ey, b2, sddy);
