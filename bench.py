@@ -301,7 +301,56 @@ def global_qp_leg(trk, d_widths, g, args, torch, with_cpu):
         assert dev_m < 1e-6, f"global QP deviates from its CPU twin: {dev_m}"
         leg["cpu_twin"] = {"instances_per_s": ninst / dt, "cores": 1, "sample": f"{ninst} instances, {dt:.2f} s",
                            "gpu_vs_twin_dev_m": dev_m}
+    leg["two_dof"] = global_qp_xy_block(trk, d_widths, g, args, torch, with_cpu)
     return leg
+
+
+GLOBAL_LON = 1.0   # [m] longitudinal bound of the two-coordinate formulation (julia/spline_traj_opt.ipynb L276-279)
+
+
+def global_qp_xy_block(trk, d_widths, g, args, torch, with_cpu):
+    """The same batch through the formulation with BOTH coordinates of every control point free (the Julia prototype's
+    unknowns and rows; rl_mincurv_global_xy_batch_dev, kernel k_global_xy): 4N bound rows, 2 (n-k) unknowns per QP."""
+    from spline_trajectory_optimization_amd import ops
+    out = ops.global_batch_torch(trk, d_widths, GLOBAL_MARGIN, GLOBAL_OUTER, dof=2, lon=GLOBAL_LON)
+    torch.cuda.synchronize()
+    steps = max(3, min(args.steps, 10))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        ops.global_batch_torch(trk, d_widths, GLOBAL_MARGIN, GLOBAL_OUTER, out=out, dof=2, lon=GLOBAL_LON)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    st = out["stats"].cpu().numpy()
+    B = d_widths.shape[0]
+    assert np.isfinite(st).all() and (st[:, 3] <= 1e-8).all(), "global QP (two coordinates): a line left its bounds"
+    blk = {"metric": "global min-curvature QPs/sec, both coordinates of every control point free (N=2000: 4N bound rows, "
+                     "122 unknowns per QP; lateral bounds from the widths, longitudinal +-1 m)",
+           "value": B * GLOBAL_OUTER / ms * 1e3, "unit": "QPs/s", "instances_per_s": B / ms * 1e3, "kernel_ms": ms,
+           "timed_launches": steps, "linearisations": GLOBAL_OUTER, "ipm_iterations_mean": float(st[:, 0].mean()),
+           "ipm_iterations_max": float(st[:, 0].max()), "sum_kappa2_before_after": [float(st[:, 1].mean()), float(st[:, 2].mean())],
+           "halved_steps_mean": float(st[:, 7].mean()), "max_bound_violation_m": float(st[:, 3].max()),
+           "block_threads": int(out["rl_stats"].block_threads), "lds_bytes_per_workgroup": int(out["rl_stats"].lds_bytes),
+           "kernel": "k_global_xy",
+           "actual_limiter": "register file: the interior-point state of 4 samples x 2 rows per thread (96 registers) plus the row "
+                             "passes exceed 256 VGPRs -- 169 spilled registers (DESIGN.md 3b); then the one factorising wave"}
+    if with_cpu:
+        from oracle import oracle as orc
+        ninst = 2
+        t0 = time.perf_counter()
+        dev_m = 0.0
+        xy = out["xy"][:ninst].cpu().numpy()
+        for b in range(ninst):
+            r = orc.global_mincurv_xy(g["t"], g["cx"], g["cy"], g["k"], N_WAYPOINTS, g["widths"][b, :, 0], g["widths"][b, :, 1],
+                                      GLOBAL_MARGIN, GLOBAL_LON, GLOBAL_OUTER)
+            dev_m = max(dev_m, float(np.abs(r[2] - xy[b]).max()))
+            assert abs(int(r[4][0]) - int(st[b, 0])) <= 1, "global QP (two coordinates): iteration count differs from the twin"
+        dt = time.perf_counter() - t0
+        assert dev_m < 2e-6, f"global QP (two coordinates) deviates from its CPU twin: {dev_m}"
+        blk["cpu_twin"] = {"instances_per_s": ninst / dt, "cores": 1, "sample": f"{ninst} instances, {dt:.2f} s",
+                           "gpu_vs_twin_dev_m": dev_m}
+    return blk
 
 
 MFMA_F64_PEAK_GFLOPS = 78600.0  # v_mfma_f64_16x16x4_f64 runs at the FP64 vector rate on gfx950 (DESIGN.md 3d: 64 cycles per 2048 flops per SIMD)
