@@ -330,17 +330,13 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
 
   // the basis values of the thread's samples (coalesced: sample index fastest in the table) and their products with a vector
   // of LDS control-point pairs: (px, py) = sum_al b_al v[j0 + al]
-  static_assert(R == 4, "load_b reads two double2 per basis function");
   auto load_b = [&](double (&bv)[K1][R]) {
     const int oz = xy_opaque_zero();
 #pragma unroll
     for (int al = 0; al < K1; ++al) {
-      double2 v0 = make_double2(0.0, 0.0), v1 = v0;
-      if (i0 < N) {   // (a sample index past N - 1 reads the next row of the table: never used)
-        const double2* __restrict__ p = reinterpret_cast<const double2*>(D0 + ((size_t)al * N + i0 + oz));
-        v0 = p[0]; v1 = p[1];
-      }
-      bv[al][0] = v0.x; bv[al][1] = v0.y; bv[al][2] = v1.x; bv[al][3] = v1.y;
+#pragma unroll
+      for (int r = 0; r < R; ++r) bv[al][r] = D0[(size_t)al * N + min(i0 + r, N - 1) + oz];   // (8-byte loads: 16-byte ones want
+                                                                                               //  aligned register pairs -- 60 more spills)
     }
   };
   auto dot_b = [&](const double (&bv)[K1][R], int r, const double2* v, double& px, double& py) {
