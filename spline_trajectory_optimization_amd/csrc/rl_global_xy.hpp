@@ -154,44 +154,59 @@ __device__ __forceinline__ void fband_factor(double* LT, double* dinv, int nz, i
 
 // (L D L') x = rhs with the factor above.  ONE wave; folded row r = lane + 64 q in registers (NG groups); rhs and out in
 // CYCLIC order.  Per column: one readlane pair, and per row group one subtract, one unsigned minimum (rows outside the
-// band land on the column's zero), one LDS read, one fma.
+// band land on the column's zero), one LDS read, one fma.  The factor's entries of the NEXT column are read while the current
+// one is applied: the addresses do not depend on the solution, and a step that waits for its own LDS read costs 185 cycles
+// instead of ~60 (measured: 45 k -> see DESIGN.md 3b cycles per solve).
 template <int HB, int NG>
 __device__ __forceinline__ void fband_solve(const double* LT, const double* dinv, int nz, int lane, const double* rhs, double* out) {
   constexpr int CW = HB + 2;
-  double y[NG];
+  double y[NG], ln[NG];
+  int rcl[NG];
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
     const int r = lane + kWave * q;
     y[q] = r < nz ? rhs[xy_unfold(r, nz)] : 0.0;
+    rcl[q] = min(r, nz) * CW;          // (rows past the matrix: a zero column)
   }
   // L y = rhs: y_r -= L[r][c] y_c, L[r][c] = LT[c CW + (r - c - 1)]
+  auto fetch_f = [&](int c) {
+    const double* col = LT + c * CW;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) ln[q] = col[min((unsigned)(lane + kWave * q - c - 1), (unsigned)HB)];
+  };
+  fetch_f(0);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int c1 = min(nz - 1, kWave * (g + 1));
     for (int c = kWave * g; c < c1; ++c) {
-      const double yc = lane_bcast(y[g], c - kWave * g);
-      const double* col = LT + c * CW;
+      double lc[NG];
 #pragma unroll
-      for (int q = g; q < NG; ++q) {
-        const unsigned idx = min((unsigned)(lane + kWave * q - c - 1), (unsigned)HB);
-        y[q] = fma(-col[idx], yc, y[q]);
-      }
+      for (int q = 0; q < NG; ++q) lc[q] = ln[q];
+      fetch_f(c + 1);                    // (column nz - 1 has no rows below: its entries are zeros)
+      const double yc = lane_bcast(y[g], c - kWave * g);
+#pragma unroll
+      for (int q = 0; q < NG; ++q) y[q] = fma(-lc[q], yc, y[q]);
     }
   }
 #pragma unroll
   for (int q = 0; q < NG; ++q) { const int r = lane + kWave * q; if (r < nz) y[q] *= dinv[r]; }
   // L' x = y: x_r -= L[c][r] x_c, L[c][r] = LT[r CW + (c - r - 1)]
+  auto fetch_b = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < NG; ++q) ln[q] = LT[rcl[q] + min((unsigned)(c - lane - kWave * q - 1), (unsigned)HB)];
+  };
+  fetch_b(nz - 1);
 #pragma unroll
   for (int g = NG - 1; g >= 0; --g) {
     const int c0 = max(1, kWave * g);
     for (int c = min(nz, kWave * (g + 1)) - 1; c >= c0; --c) {
+      double lc[NG];
+#pragma unroll
+      for (int q = 0; q < NG; ++q) lc[q] = ln[q];
+      fetch_b(c - 1);                    // (c - 1 = 0: nothing above row 0, zeros)
       const double xc = lane_bcast(y[g], c - kWave * g);
 #pragma unroll
-      for (int q = 0; q <= g; ++q) {
-        const int r = lane + kWave * q;
-        const unsigned idx = min((unsigned)(c - r - 1), (unsigned)HB);
-        y[q] = fma(-LT[min(r, nz) * CW + idx], xc, y[q]);      // (rows past the matrix: a zero column)
-      }
+      for (int q = 0; q < NG; ++q) y[q] = fma(-lc[q], xc, y[q]);
     }
   }
 #pragma unroll
@@ -212,6 +227,51 @@ __device__ __forceinline__ void xy_span_sums(const double* __restrict__ bbx, int
                                              double* sums, int t0, int nth) {
   constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, ROW = NE + K1, NT_ = MODE == 0 ? NE : K1, U = kXYBatch;
   const double2* wb2 = reinterpret_cast<const double2*>(wb);
+  if (MODE == 0) {
+    // a task = three basis pairs of one span (adjacent table columns): the three weights of a sample are read from LDS once
+    // for nine products, and one round of tasks covers the track (np (NE / 3) <= threads).  With one pair per task the serial
+    // LDS round trips of the weights were most of the 118 k cycles this pass took per interior-point iteration.
+    constexpr int PM = 3, NGR = (NE + PM - 1) / PM, US = 4;
+    for (int task = t0; task < np * NGR; task += nth) {
+      const int sp = task / NGR, g = task - sp * NGR;
+      const int p0 = g * PM, cnt = min(PM, NE - p0);
+      const int e0 = sfirst[sp], e1 = sfirst[sp + 1];
+      const int oz = xy_opaque_zero();
+      const double* __restrict__ col = bbx + (p0 + oz);
+      const double* wbo = wb + oz;
+      double acc[PM][3];
+#pragma unroll
+      for (int q = 0; q < PM; ++q) { acc[q][0] = 0.0; acc[q][1] = 0.0; acc[q][2] = 0.0; }
+      for (int base = e0; base < e1; base += US) {
+        double tv[US][PM], wv[US][3];
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+          const double* __restrict__ row = col + (size_t)min(base + u, e1 - 1) * ROW;
+#pragma unroll
+          for (int q = 0; q < PM; ++q) tv[u][q] = row[q < cnt ? q : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+          const int i = min(base + u, e1 - 1);
+          wv[u][0] = wbo[i]; wv[u][1] = wbo[N + i]; wv[u][2] = wbo[2 * N + i];
+        }
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+          const bool in = base + u < e1;     // past the span: zero weights
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const double w = in ? wv[u][c] : 0.0;
+#pragma unroll
+            for (int q = 0; q < PM; ++q) acc[q][c] = fma(tv[u][q], w, acc[q][c]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < PM; ++q)
+        if (q < cnt) { double* o = sums + (sp * NE + p0 + q) * 3; o[0] = acc[q][0]; o[1] = acc[q][1]; o[2] = acc[q][2]; }
+    }
+    return;
+  }
   for (int task = t0; task < np * NT_; task += nth) {
     const int sp = task / NT_, p = task - sp * NT_;
     const int e0 = sfirst[sp], e1 = sfirst[sp + 1];
