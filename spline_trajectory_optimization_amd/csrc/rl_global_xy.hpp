@@ -193,7 +193,10 @@ __device__ __forceinline__ void fband_solve(const double* LT, const double* dinv
   // L' x = y: x_r -= L[c][r] x_c, L[c][r] = LT[r CW + (c - r - 1)]
   auto fetch_b = [&](int c) {
 #pragma unroll
-    for (int q = 0; q < NG; ++q) ln[q] = LT[rcl[q] + min((unsigned)(c - lane - kWave * q - 1), (unsigned)HB)];
+    for (int q = 0; q < NG; ++q) {     // (rows outside the band read ONE zero: their own pads lie 24 doubles apart -- bank conflicts)
+      const unsigned idx = (unsigned)(c - lane - kWave * q - 1);
+      ln[q] = LT[idx < (unsigned)HB ? rcl[q] + idx : HB];
+    }
   };
   fetch_b(nz - 1);
 #pragma unroll
@@ -352,13 +355,15 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
   const double* __restrict__ wid = a.widths + (size_t)b * N * 2;
 
   // ---- this thread's samples
-  const int i0 = tid * R;
+  // sample r of this thread.  (tid + r NT -- a wave holding consecutive samples -- was measured too: 64.8 against 63.4 ms, within
+  // the box-to-box spread; the spills, not the access pattern, are what the row passes wait for.)
+#define XY_SMP(r) (tid * R + (r))
   bool ok[R];
   int j0[R];
   double nx[R], ny[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = i0 + r;
+    const int i = XY_SMP(r);
     ok[r] = i < N;
     j0[r] = 0; nx[r] = 0.0; ny[r] = 1.0;
     if (ok[r]) {
@@ -367,7 +372,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     }
   }
   auto lat_bounds = [&](int r, double& lo_, double& hi_) {   // (read where needed: two registers per sample less to keep)
-    const double2 w = reinterpret_cast<const double2*>(wid)[i0 + r + xy_opaque_zero()];
+    const double2 w = reinterpret_cast<const double2*>(wid)[XY_SMP(r) + xy_opaque_zero()];
     lo_ = -(w.y - a.margin); hi_ = w.x - a.margin;
   };
   for (int j = tid; j < n; j += NT) {
@@ -395,8 +400,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
 #pragma unroll
     for (int al = 0; al < K1; ++al) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) bv[al][r] = D0[(size_t)al * N + min(i0 + r, N - 1) + oz];   // (8-byte loads: 16-byte ones want
-                                                                                               //  aligned register pairs -- 60 more spills)
+      for (int r = 0; r < R; ++r) bv[al][r] = D0[(size_t)al * N + min(XY_SMP(r), N - 1) + oz];
     }
   };
   auto dot_b = [&](const double (&bv)[K1][R], int r, const double2* v, double& px, double& py) {
@@ -432,7 +436,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       gres[r] = 0.0;
       if (ok[r]) {
         const int oz = xy_opaque_zero();
-        const int i = i0 + r + oz;
+        const int i = XY_SMP(r) + oz;
         double dx = 0, dy = 0, ddx = 0, ddy = 0, zdx = 0, zdy = 0, zddx = 0, zddy = 0;
 #pragma unroll
         for (int al = 0; al < K1; ++al) {
@@ -488,7 +492,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (ok[r]) {
-        const int i = i0 + r;
+        const int i = XY_SMP(r);
         double2 gx = wb2[i], gy = wb2[N + i];
         gx.x *= gres[r]; gx.y *= gres[r]; gy.x *= gres[r]; gy.y *= gres[r];
         wb2[i] = gx; wb2[N + i] = gy;
@@ -572,7 +576,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             mu += sl[kd][r] * ll[kd][r] + su[kd][r] * lu[kd][r];
             rpmax = fmax(rpmax, fmax(fabs(rpl[kd][r]), fabs(rpu[kd][r])));
           }
-          const int i = i0 + r + xy_opaque_zero();
+          const int i = XY_SMP(r) + xy_opaque_zero();
           const double x2 = nx[r] * nx[r], y2 = ny[r] * ny[r], xy = nx[r] * ny[r];
           wb[i] = dm[0] * x2 + dm[1] * y2;
           wb[N + i] = (dm[0] - dm[1]) * xy;
@@ -622,7 +626,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             const double ql = ll[kd][r] * frcp(sl[kd][r]), qu = lu[kd][r] * frcp(su[kd][r]);
             e[kd] = qu * rpu[kd][r] - ql * rpl[kd][r]; dl[kd] = lu[kd][r] - ll[kd][r];
           }
-          const int i = i0 + r + xy_opaque_zero();
+          const int i = XY_SMP(r) + xy_opaque_zero();
           wb2[i] = make_double2(e[0] * nx[r] + e[1] * ny[r], e[0] * ny[r] - e[1] * nx[r]);
           wb2[N + i] = make_double2(dl[0] * nx[r] + dl[1] * ny[r], dl[0] * ny[r] - dl[1] * nx[r]);
         }
@@ -665,7 +669,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       double* adxa_l = wb + 2 * N;
       double* adxc_l = wb;
       auto affine_row = [&](int kd, int r, double i_sl, double i_su, double& d_sl, double& d_su, double& d_ll, double& d_lu) {
-        const double adx = adxa_l[kd * N + i0 + r + xy_opaque_zero()];
+        const double adx = adxa_l[kd * N + XY_SMP(r) + xy_opaque_zero()];
         d_sl = adx + rpl[kd][r]; d_su = rpu[kd][r] - adx;
         d_ll = (-(sl[kd][r] * ll[kd][r]) - ll[kd][r] * d_sl) * i_sl;
         d_lu = (-(su[kd][r] * lu[kd][r]) - lu[kd][r] * d_su) * i_su;
@@ -682,7 +686,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
 #pragma unroll
             for (int kd = 0; kd < 2; ++kd) {
               const double adx = kd == 0 ? nx[r] * px + ny[r] * py : ny[r] * px - nx[r] * py;
-              adxa_l[kd * N + i0 + r] = adx;
+              adxa_l[kd * N + XY_SMP(r)] = adx;
               const double i_sl = frcp(sl[kd][r]), i_su = frcp(su[kd][r]);
               const double d_sl = adx + rpl[kd][r], d_su = rpu[kd][r] - adx;
               const double d_ll = (-(sl[kd][r] * ll[kd][r]) - ll[kd][r] * d_sl) * i_sl;
@@ -718,7 +722,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             const double rcl = sl[kd][r] * ll[kd][r] - smu + d_sl * d_ll, rcu = su[kd][r] * lu[kd][r] - smu + d_su * d_lu;
             wv[kd] = (-rcl - ll[kd][r] * rpl[kd][r]) * i_sl - (-rcu - lu[kd][r] * rpu[kd][r]) * i_su;
           }
-          wb2[i0 + r + xy_opaque_zero()] = make_double2(wv[0] * nx[r] + wv[1] * ny[r], wv[0] * ny[r] - wv[1] * nx[r]);
+          wb2[XY_SMP(r) + xy_opaque_zero()] = make_double2(wv[0] * nx[r] + wv[1] * ny[r], wv[0] * ny[r] - wv[1] * nx[r]);
         }
       }
       __syncthreads();
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
         double a_sl, a_su, a_ll, a_lu;
         affine_row(kd, r, i_sl, i_su, a_sl, a_su, a_ll, a_lu);
         const double rcl = sl[kd][r] * ll[kd][r] - smu + a_sl * a_ll, rcu = su[kd][r] * lu[kd][r] - smu + a_su * a_lu;
-        const double adx = adxc_l[kd * N + i0 + r + xy_opaque_zero()];
+        const double adx = adxc_l[kd * N + XY_SMP(r) + xy_opaque_zero()];
         d_sl = adx + rpl[kd][r]; d_su = rpu[kd][r] - adx;
         d_ll = (-rcl - ll[kd][r] * d_sl) * i_sl; d_lu = (-rcu - lu[kd][r] * d_su) * i_su;
       };
@@ -754,7 +758,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
             dot_b(bv, r, dxs, px, py);
 #pragma unroll
             for (int kd = 0; kd < 2; ++kd) {
-              adxc_l[kd * N + i0 + r] = kd == 0 ? nx[r] * px + ny[r] * py : ny[r] * px - nx[r] * py;
+              adxc_l[kd * N + XY_SMP(r)] = kd == 0 ? nx[r] * px + ny[r] * py : ny[r] * px - nx[r] * py;
               double d_sl, d_su, d_ll, d_lu, i_sl, i_su;
               final_row(kd, r, d_sl, d_su, d_ll, d_lu, i_sl, i_su);
               rmax = fmax(rmax, fmax(fmax(-d_sl * i_sl, -d_su * i_su),
@@ -793,7 +797,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     for (int r = 0; r < R; ++r) {
       if (ok[r]) {
         const int oz = xy_opaque_zero();
-        const int i = i0 + r + oz;
+        const int i = XY_SMP(r) + oz;
         double dx = 0, dy = 0, ddx = 0, ddy = 0, sdx = 0, sdy = 0, sddx = 0, sddy = 0;
 #pragma unroll
         for (int al = 0; al < K1; ++al) {
@@ -846,7 +850,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (ok[r]) {
-      const int i = i0 + r;
+      const int i = XY_SMP(r);
       double x, y;
       dot_b(bvo, r, cs, x, y);
       if (a.out_xy) reinterpret_cast<double2*>(a.out_xy)[(size_t)b * N + i] = make_double2(x, y);

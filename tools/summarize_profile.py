@@ -74,7 +74,7 @@ kernels = {}
 # k_sweep<K, BLOCK, RINGS_LDS, JOINT, DUMP, SIGMA_LDS, STRICT, RAISE, LITE>: told apart by the last three arguments
 for name, pat in (("k_sweep", "k_sweep<|false, false, false"), ("k_sweep_reference_order", "k_sweep<|true, false, false"),
                   ("k_sweep_reference_order_raise", "k_sweep<|true, true, false"), ("k_sweep_branch", "k_sweep<|true, false, true"),
-                  ("k_global_qp", "k_global_qp")):
+                  ("k_global_qp", "k_global_qp"), ("k_global_xy", "k_global_xy<")):
     k = per_kernel(pat)
     if k:
         kernels[name] = k
