@@ -135,20 +135,28 @@ __device__ __forceinline__ void fband_factor(double* LT, double* dinv, int nz, i
       o1[q] = HB; o2[q] = HB; oo[q] = CW + HB;                                    // zeros: 0 - 0 * 0
     }
   }
-  const int ocol = lane < HB ? lane : HB;
+  // per-lane pointers that advance by one column per step (an index plus the column's base costs an extra add per access, and
+  // this wave is alone on its SIMD: every instruction is ~8 cycles)
+  double* pc = LT + (lane < HB ? lane : HB);
+  double *p1[EPL], *p2[EPL], *po[EPL];
+#pragma unroll
+  for (int q = 0; q < EPL; ++q) { p1[q] = LT + o1[q]; p2[q] = LT + o2[q]; po[q] = LT + oo[q]; }
+  const double* pd = LT + HB + 1;
   for (int c = 0; c < nz; ++c) {
-    double* base = LT + c * CW;
-    const double inv = frcp(base[HB + 1]);
-    const double uc = base[ocol];
+    const double inv = frcp(*pd);
+    const double uc = *pc;
     double u1[EPL], u2[EPL], own[EPL];
 #pragma unroll
-    for (int q = 0; q < EPL; ++q) { u1[q] = base[o1[q]]; u2[q] = base[o2[q]]; own[q] = base[oo[q]]; }
+    for (int q = 0; q < EPL; ++q) { u1[q] = *p1[q]; u2[q] = *p2[q]; own[q] = *po[q]; }
     wave_lds_fence();
 #pragma unroll
-    for (int q = 0; q < EPL; ++q) base[oo[q]] = fma(-u1[q], u2[q] * inv, own[q]);
-    base[ocol] = uc * inv;
+    for (int q = 0; q < EPL; ++q) *po[q] = fma(-u1[q], u2[q] * inv, own[q]);
+    *pc = uc * inv;
     if (lane == 0) dinv[c] = inv;
     wave_lds_fence();
+    pd += CW; pc += CW;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) { p1[q] += CW; p2[q] += CW; po[q] += CW; }
   }
 }
 
