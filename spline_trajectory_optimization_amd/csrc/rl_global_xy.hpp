@@ -42,6 +42,10 @@ constexpr double kXYLooseMu = 1e-7, kXYLooseRes = 1e-6;
 struct GlobalXYArgs {
   TrackDev trk;
   const int* span_first;   // [np+1] first sample of knot span s (control points s .. s+k); span_first[np] = N
+  const int* chunk_first;  // [nch+1] the samples of a span cut into CHUNKS of bounded length (Monza, N = 2000: one span has 281
+                           //         samples, the mean is 33 -- a task per span waits for that one): first sample of chunk j
+  const int* span_chunk0;  // [np+1] first chunk of span s (chunks of a span are consecutive; an empty span has none)
+  int nch;
   const double* bbx;       // [N][NE + K1]: basis products D0[a][i] D0[b][i] (a >= b, column a (a+1)/2 + b), then D0[a][i]
   int np;
   const double* widths;    // [B][N][2] (w_left, w_right)
@@ -54,10 +58,10 @@ struct GlobalXYArgs {
 };
 
 struct GlobalXYLayout {  // offsets in doubles
-  int xs, zs, dxs, cs, c0s, qv, rdP, rd, rhs, dinv, Pc, Lf, sums, wbuf, red, sfirst, total;
+  int xs, zs, dxs, cs, c0s, qv, rdP, rd, rhs, dinv, Pc, Lf, sums, wbuf, red, sfirst, cfirst, sch0, total;
 };
 
-__host__ __device__ inline GlobalXYLayout global_xy_layout(int k, int n, int np, int N) {
+__host__ __device__ inline GlobalXYLayout global_xy_layout(int k, int n, int np, int N, int nch) {
   const int K1 = k + 1, NE = K1 * (K1 + 1) / 2, H1 = 2 * k + 2, HB = 2 * (2 * k + 1), CW = HB + 2, nz = 2 * np;
   GlobalXYLayout L;
   int o = 0;
@@ -65,11 +69,13 @@ __host__ __device__ inline GlobalXYLayout global_xy_layout(int k, int n, int np,
   L.xs = take(2 * n); L.zs = take(2 * n); L.dxs = take(2 * n); L.cs = take(2 * n); L.c0s = take(2 * n);
   L.qv = take(nz); L.rdP = take(nz); L.rd = take(nz); L.rhs = take(nz); L.dinv = take(nz);
   L.Pc = take(nz * H1); L.Lf = take((nz + HB + 1) * CW);
-  const int ssum = np * NE * 3, part = np * K1 * 4;
-  L.sums = take(ssum > part ? ssum : part);      // span sums of the matrix / of the vectors (never live together)
+  const int ssum = nch * NE * 3, part = nch * K1 * 4;
+  L.sums = take(ssum > part ? ssum : part);      // chunk sums of the matrix / of the vectors (never live together)
   L.wbuf = take(4 * N);
   L.red = take(64);
   L.sfirst = take((np + 2) / 2 + 1);
+  L.cfirst = take((nch + 2) / 2 + 1);
+  L.sch0 = take((np + 2) / 2 + 1);
   L.total = o;
   return L;
 }
@@ -231,11 +237,12 @@ __device__ __forceinline__ void fband_solve(const double* LT, const double* dinv
 // interior-point iteration when each term waited for its own load).
 //   MODE 0:  sums[(s NE + p) 3 + c] = sum_i bb_p(i) w_c(i),  c < 3, weights at wb[c N + i]
 //   MODE 1/2: sums[(s K1 + a) 4 + n] = sum_i b_a(i) v_n(i),  n < 4 / n < 2, the 2-vectors at wb2[i], wb2[N + i]
+// "Span" here is a CHUNK of a span (GlobalXYArgs::chunk_first): the callers add the chunks of a span in order.
 // Tasks t0, t0 + nth, ... of this thread.
 constexpr int kXYBatch = 12;
 template <int K, int MODE>
 __device__ __forceinline__ void xy_span_sums(const double* __restrict__ bbx, int N, int np, const int* sfirst, const double* wb,
-                                             double* sums, int t0, int nth) {
+                                             double* sums, int t0, int nth) {   // (np, sfirst: the CHUNKS and their first samples)
   constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, ROW = NE + K1, NT_ = MODE == 0 ? NE : K1, U = kXYBatch;
   const double2* wb2 = reinterpret_cast<const double2*>(wb);
   if (MODE == 0) {
@@ -328,7 +335,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
   constexpr int nw = NT >> 6;
   const int b = blockIdx.x;
   const int N = a.trk.N, n = a.trk.n, np = a.np, nz = 2 * np;
-  const GlobalXYLayout L = global_xy_layout(K, n, np, N);
+  const GlobalXYLayout L = global_xy_layout(K, n, np, N, a.nch);
   double2* xs = reinterpret_cast<double2*>(lds + L.xs);
   double2* zs = reinterpret_cast<double2*>(lds + L.zs);
   double2* dxs = reinterpret_cast<double2*>(lds + L.dxs);
@@ -338,6 +345,9 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
   double *Pc = lds + L.Pc, *Lf = lds + L.Lf, *sums = lds + L.sums, *wb = lds + L.wbuf, *red = lds + L.red;
   double2* wb2 = reinterpret_cast<double2*>(wb);
   int* sfirst = reinterpret_cast<int*>(lds + L.sfirst);
+  int* cfirst = reinterpret_cast<int*>(lds + L.cfirst);
+  int* sch0 = reinterpret_cast<int*>(lds + L.sch0);
+  const int nch = a.nch;
   double* xsf = reinterpret_cast<double*>(xs);     // flat views: unknown 2 j + c
   double* dxf = reinterpret_cast<double*>(dxs);
   double* zsf = reinterpret_cast<double*>(zs);
@@ -387,7 +397,8 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     c0s[j] = make_double2(a.trk.c0[j], a.trk.c0[n + j]);
     zs[j] = make_double2(0.0, 0.0);
   }
-  for (int j = tid; j <= np; j += NT) sfirst[j] = a.span_first[j];
+  for (int j = tid; j <= np; j += NT) { sfirst[j] = a.span_first[j]; sch0[j] = a.span_chunk0[j]; }
+  for (int j = tid; j <= nch; j += NT) cfirst[j] = a.chunk_first[j];
   __syncthreads();
 
 #ifdef RL_XY_PROFILE   // diagnostic build: out_z[b][0..11] = cycles (s_memtime) per phase, summed over the solve
@@ -426,7 +437,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
 #pragma unroll
     for (int al = 0; al < K1; ++al) {
       int sp = j - al; if (sp < 0) sp += np;
-      s += sums[(sp * K1 + al) * 4 + 2 * q + c];
+      for (int ch = sch0[sp]; ch < sch0[sp + 1]; ++ch) s += sums[(ch * K1 + al) * 4 + 2 * q + c];
     }
     return s;
   };
@@ -507,11 +518,11 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       }
     }
     __syncthreads();
-    for (int task = tid; task < np * K1; task += NT) {
+    for (int task = tid; task < nch * K1; task += NT) {
       const int s = task / K1, al = task - s * K1;
       const double* __restrict__ p1 = D1 + (size_t)al * N; const double* __restrict__ p2 = D2 + (size_t)al * N;
       double a0 = 0.0, a1 = 0.0;
-      const int e0 = sfirst[s], e1 = sfirst[s + 1];
+      const int e0 = cfirst[s], e1 = cfirst[s + 1];
 #pragma unroll 4
       for (int i = e0; i < e1; ++i) {
         const double2 gx = wb2[i], gy = wb2[N + i];
@@ -599,7 +610,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       mu /= (double)(4 * N);
       XY_STAMP(1)
       // ---- span sums of  b_a b_b M
-      xy_span_sums<K, 0>(bbx, N, np, sfirst, wb, sums, tid, NT);
+      xy_span_sums<K, 0>(bbx, N, nch, cfirst, wb, sums, tid, NT);
       __syncthreads();
       XY_STAMP(2)
       // ---- 2x2 blocks of  P + A'DA  into the folded band
@@ -610,8 +621,10 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
         for (int al = 0; al <= K; ++al) {
           if (al >= d) {
             int s = j1 - al; if (s < 0) s += np;
-            const double* sp = sums + (s * NE + al * (al + 1) / 2 + (al - d)) * 3;
-            axx += sp[0]; axy += sp[1]; ayy += sp[2];
+            for (int ch = sch0[s]; ch < sch0[s + 1]; ++ch) {
+              const double* sp = sums + (ch * NE + al * (al + 1) / 2 + (al - d)) * 3;
+              axx += sp[0]; axy += sp[1]; ayy += sp[2];
+            }
           }
         }
         int j2 = j1 - d; if (j2 < 0) j2 += np;
@@ -643,7 +656,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       XY_STAMP(3)
       // ---- wave 0 factorises while the others form the span sums of the two vectors
       if (wave == 0) fband_factor<HB>(Lf, dinv, nz, lane);
-      else xy_span_sums<K, 1>(bbx, N, np, sfirst, wb, sums, tid - kWave, NT - kWave);
+      else xy_span_sums<K, 1>(bbx, N, nch, cfirst, wb, sums, tid - kWave, NT - kWave);
       __syncthreads();
       XY_STAMP(4)
       double rdmax = 0.0;
@@ -735,7 +748,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
       }
       __syncthreads();
       XY_STAMP(11)
-      xy_span_sums<K, 2>(bbx, N, np, sfirst, wb, sums, tid, NT);
+      xy_span_sums<K, 2>(bbx, N, nch, cfirst, wb, sums, tid, NT);
       __syncthreads();
       for (int u = tid; u < nz; u += NT) rhs[u] = gathered(u >> 1, u & 1, 0) - rd[u];
       __syncthreads();

@@ -247,7 +247,8 @@ struct rl_track {
   mutable int gq_nc = 0, gq2_nc = 0, gq2_rows = 0;  // gq2_rows = 0: the fast path does not fit
   mutable bool gq_valid = false;
   // tables of the two-coordinate global QP (rl_global_xy.hpp)
-  mutable DevBuf<int> gxy_span;
+  mutable DevBuf<int> gxy_span, gxy_chunk, gxy_sch0;
+  mutable int gxy_nch = 0;
   mutable DevBuf<double> gxy_bbx;
   mutable bool gxy_valid = false;
   rl::TrackDev dev() const {
@@ -1083,13 +1084,31 @@ int global_xy_tables(const rl_ctx* ctx, const rl_track* trk) {
   for (int q = prev + 1; q <= np; ++q) first[q] = N;
   RL_HIP(trk->gxy_span.alloc(first.size()));
   RL_HIP(hipMemcpyAsync(trk->gxy_span.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  // chunks: the samples of a span in pieces of <= CL samples.  The adaptive knots give spans of very different lengths (Monza
+  // s = 100, N = 2000: 2 .. 281 samples), and a task per span waits for the longest.  The shortest CL whose chunk sums fit LDS.
+  std::vector<int> cf, sc0(np + 1, 0);
+  for (int CL = 32;; CL += CL / 2) {
+    cf.clear();
+    for (int s = 0; s < np; ++s) {
+      sc0[s] = (int)cf.size();
+      for (int m = first[s]; m < first[s + 1]; m += CL) cf.push_back(m);
+    }
+    sc0[np] = (int)cf.size();
+    cf.push_back(N);
+    const size_t lds = (size_t)rl::global_xy_layout(k, n, np, N, sc0[np]).total * sizeof(double);
+    if (lds <= (size_t)ctx->max_lds || CL >= N) break;
+  }
+  trk->gxy_nch = sc0[np];
+  RL_HIP(trk->gxy_chunk.alloc(cf.size())); RL_HIP(trk->gxy_sch0.alloc(sc0.size()));
+  RL_HIP(hipMemcpyAsync(trk->gxy_chunk.p, cf.data(), cf.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  RL_HIP(hipMemcpyAsync(trk->gxy_sch0.p, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   const int K1 = k + 1;
   RL_HIP(trk->gxy_bbx.alloc((size_t)N * (K1 * (K1 + 1) / 2 + K1)));
   const rl::TrackDev td = trk->dev();
   if (k == 3) hipLaunchKernelGGL(rl::k_global_xy_pairs<3>, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, td, trk->gxy_bbx.p);
   else hipLaunchKernelGGL(rl::k_global_xy_pairs<5>, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, td, trk->gxy_bbx.p);
   RL_HIP(hipGetLastError());
-  RL_HIP(hipStreamSynchronize(ctx->stream));  // `first` is a host vector
+  RL_HIP(hipStreamSynchronize(ctx->stream));  // `first`, `cf`, `sc0` are host vectors
   trk->gxy_valid = true;
   return RL_OK;
 }
@@ -1114,12 +1133,13 @@ int global_xy_common(rl_ctx* ctx, const rl_track* trk, const double* widths, int
   if (int rc = global_xy_tables(ctx, trk)) return rc;
   rl::GlobalXYArgs a;
   a.trk = trk->dev();
-  a.span_first = trk->gxy_span.p; a.bbx = trk->gxy_bbx.p; a.np = trk->n - trk->k;
+  a.span_first = trk->gxy_span.p; a.chunk_first = trk->gxy_chunk.p; a.span_chunk0 = trk->gxy_sch0.p; a.nch = trk->gxy_nch;
+  a.bbx = trk->gxy_bbx.p; a.np = trk->n - trk->k;
   a.widths = widths; a.margin = margin; a.lon = lon; a.n_outer = n_outer; a.max_ipm = 80;
   a.out_ctrl = out_ctrl; a.out_xy = out_xy; a.out_z = out_z; a.out_stats = out_stats;
   const int block = trk->N <= 512 * rl::kXYRows ? 512 : 1024;
   if (trk->N > block * rl::kXYRows) return fail(RL_ERR_UNSUPPORTED, "global QP (dof 2): more than 4096 samples");
-  const size_t lds = (size_t)rl::global_xy_layout(trk->k, trk->n, a.np, trk->N).total * sizeof(double);
+  const size_t lds = (size_t)rl::global_xy_layout(trk->k, trk->n, a.np, trk->N, a.nch).total * sizeof(double);
   if (lds > (size_t)ctx->max_lds) return fail(RL_ERR_UNSUPPORTED, "global QP (dof 2) does not fit LDS");
   if (stats) { stats->lds_bytes = (int)lds; stats->block_threads = block; stats->rings_in_lds = 0; }
   if (trk->k == 3) return block == 512 ? launch_global_xy_t<3, 512>(ctx, a, B, lds) : launch_global_xy_t<3, 1024>(ctx, a, B, lds);
