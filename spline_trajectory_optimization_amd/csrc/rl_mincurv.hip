@@ -1087,7 +1087,7 @@ int global_xy_tables(const rl_ctx* ctx, const rl_track* trk) {
   // chunks: the samples of a span in pieces of <= CL samples.  The adaptive knots give spans of very different lengths (Monza
   // s = 100, N = 2000: 2 .. 281 samples), and a task per span waits for the longest.  The shortest CL whose chunk sums fit LDS.
   std::vector<int> cf, sc0(np + 1, 0);
-  for (int CL = 32;; CL += CL / 2) {
+  for (int CL = 33;; CL = (CL + CL / 2) | 1) {   // (odd: the chunks of a long span then start on different LDS banks)
     cf.clear();
     for (int s = 0; s < np; ++s) {
       sc0[s] = (int)cf.size();
