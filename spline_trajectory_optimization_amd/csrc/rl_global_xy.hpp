@@ -14,7 +14,7 @@
 //   QP         the Mehrotra predictor-corrector iteration of rl_global.hpp, 4N bound rows
 //
 // Mapping to the machine (one workgroup = one instance)
-//   * thread = kXYRows consecutive samples; the interior-point state of their 2 x kXYRows rows stays in registers.
+//   * thread = kXYRows samples (tid, tid + NT, ...); the interior-point state of their 2 x kXYRows rows stays in registers.
 //   * what a sample contributes to the normal matrix and to the right-hand sides is a handful of WEIGHTS (3 for the matrix,
 //     2 per vector), written to LDS.  The sums over the samples of a knot span,  S[a][b] = sum_i b_a(i) b_b(i) w_i  and
 //     s[a] = sum_i b_a(i) v_i,  are formed by (span, table column) tasks that read the weights from LDS and the
@@ -62,14 +62,14 @@ struct GlobalXYLayout {  // offsets in doubles
 };
 
 __host__ __device__ inline GlobalXYLayout global_xy_layout(int k, int n, int np, int N, int nch) {
-  const int K1 = k + 1, NE = K1 * (K1 + 1) / 2, H1 = 2 * k + 2, HB = 2 * (2 * k + 1), CW = HB + 3, nz = 2 * np;
+  const int K1 = k + 1, NE = K1 * (K1 + 1) / 2, H1 = 2 * k + 3, HB = 2 * (2 * k + 1), CW = HB + 3, nz = 2 * np;   // (H1, CW odd: LDS banks)
   GlobalXYLayout L;
   int o = 0;
   auto take = [&](int c) { const int r = o; o += (c + 1) & ~1; return r; };   // 16-byte aligned pieces
   L.xs = take(2 * n); L.zs = take(2 * n); L.dxs = take(2 * n); L.cs = take(2 * n); L.c0s = take(2 * n);
   L.qv = take(nz); L.rdP = take(nz); L.rd = take(nz); L.rhs = take(nz); L.dinv = take(nz);
   L.Pc = take(nz * H1); L.Lf = take((nz + HB + 1) * CW);
-  const int ssum = nch * NE * 3, part = nch * K1 * 4;
+  const int ssum = nch * NE * 3, part = 4 * ((nch * K1) | 1);
   L.sums = take(ssum > part ? ssum : part);      // chunk sums of the matrix / of the vectors (never live together)
   L.wbuf = take(4 * N);
   L.red = take(64);
@@ -237,7 +237,8 @@ __device__ __forceinline__ void fband_solve(const double* LT, const double* dinv
 // kXYBatch samples are requested together -- the loop is bound by the L2 latency otherwise (measured: 380 k cycles per
 // interior-point iteration when each term waited for its own load).
 //   MODE 0:  sums[(s NE + p) 3 + c] = sum_i bb_p(i) w_c(i),  c < 3, weights at wb[c N + i]
-//   MODE 1/2: sums[(s K1 + a) 4 + n] = sum_i b_a(i) v_n(i),  n < 4 / n < 2, the 2-vectors at wb2[i], wb2[N + i]
+//   MODE 1/2: sums[n VP + s K1 + a] = sum_i b_a(i) v_n(i),  n < 4 / n < 2, the 2-vectors at wb2[i], wb2[N + i];
+//            VP = (np K1) | 1: component planes -- consecutive tasks write consecutive words
 // "Span" here is a CHUNK of a span (GlobalXYArgs::chunk_first): the callers add the chunks of a span in order.
 // Tasks t0, t0 + nth, ... of this thread.
 constexpr int kXYBatch = 12;
@@ -321,14 +322,14 @@ __device__ __forceinline__ void xy_span_sums(const double* __restrict__ bbx, int
       }
     }
     if (MODE == 0) { double* o = sums + task * 3; o[0] = a0; o[1] = a1; o[2] = a2; }
-    else { double* o = sums + task * 4; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; }
+    else { const int VP = (np * K1) | 1; double* o = sums + task; o[0] = a0; o[VP] = a1; o[2 * VP] = a2; o[3 * VP] = a3; }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 template <int K, int NT>
 __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
-  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, HC = 2 * K + 1, H1 = HC + 1, HB = 2 * HC, CW = HB + 3;
+  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, HC = 2 * K + 1, H1 = HC + 2, HB = 2 * HC, CW = HB + 3;   // H1: row stride of Pc (odd; HC + 1 slots used)
   constexpr int R = kXYRows;
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -374,9 +375,9 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
   const double* __restrict__ wid = a.widths + (size_t)b * N * 2;
 
   // ---- this thread's samples
-  // sample r of this thread.  (tid + r NT -- a wave holding consecutive samples -- was measured too: 64.8 against 63.4 ms, within
-  // the box-to-box spread; the spills, not the access pattern, are what the row passes wait for.)
-#define XY_SMP(r) (tid * R + (r))
+  // sample r of this thread: the lanes of a wave hold CONSECUTIVE samples, so that everything indexed by the sample -- table
+  // reads, weights, A dx in LDS -- is coalesced / conflict-free (R consecutive samples per thread: 8-way LDS bank conflicts)
+#define XY_SMP(r) (tid + (r) * NT)
   bool ok[R];
   int j0[R];
   double nx[R], ny[R];
@@ -433,12 +434,13 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     }
   };
   // gathered(j, c, q) = sum_al sums[((j - al) K1 + al) 4 + 2 q + c]: the k+1 spans that contain control point j
+  const int vplane = (nch * K1) | 1;      // xy_span_sums: plane stride of the vector sums
   auto gathered = [&](int j, int c, int q) {
     double s = 0.0;
 #pragma unroll
     for (int al = 0; al < K1; ++al) {
       int sp = j - al; if (sp < 0) sp += np;
-      for (int ch = sch0[sp]; ch < sch0[sp + 1]; ++ch) s += sums[(ch * K1 + al) * 4 + 2 * q + c];
+      for (int ch = sch0[sp]; ch < sch0[sp + 1]; ++ch) s += sums[(2 * q + c) * vplane + ch * K1 + al];
     }
     return s;
   };
@@ -483,6 +485,8 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     k2_last = k2p;
     if (outer == a.n_outer) break;
     // ---- P = 2 G'G as a cyclic band: Pc[(2 j1 + c1) H1 + dd] = P[2 j1 + c1][2 j1 + c1 - dd]
+    // (a task per block runs over whole spans; split into thirds of each span it was 8 k cycles shorter here and 17 k longer
+    // in the row passes -- the register allocation of this kernel is at its limit)
     for (int task = tid; task < np * K1; task += NT) {
       const int j1 = task / K1, d = task - j1 * K1;
       double sxx = 0.0, sxy = 0.0, syx = 0.0, syy = 0.0;
@@ -530,7 +534,7 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
         const double b1 = p1[i], b2 = p2[i];
         a0 += fma(gx.x, b1, gx.y * b2); a1 += fma(gy.x, b1, gy.y * b2);
       }
-      sums[task * 4] = a0; sums[task * 4 + 1] = a1;
+      sums[task] = a0; sums[vplane + task] = a1;
     }
     __syncthreads();
     for (int u = tid; u < nz; u += NT) qv[u] = 2.0 * gathered(u >> 1, u & 1, 0);
