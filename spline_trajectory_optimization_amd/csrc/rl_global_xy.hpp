@@ -62,7 +62,7 @@ struct GlobalXYLayout {  // offsets in doubles
 };
 
 __host__ __device__ inline GlobalXYLayout global_xy_layout(int k, int n, int np, int N, int nch) {
-  const int K1 = k + 1, NE = K1 * (K1 + 1) / 2, H1 = 2 * k + 3, HB = 2 * (2 * k + 1), CW = HB + 3, nz = 2 * np;   // (H1, CW odd: LDS banks)
+  const int K1 = k + 1, NE = K1 * (K1 + 1) / 2, H1 = 2 * k + 3, HB = 2 * (2 * k + 1), CW = HB + 2, nz = 2 * np;   // (H1 odd: LDS banks)
   GlobalXYLayout L;
   int o = 0;
   auto take = [&](int c) { const int r = o; o += (c + 1) & ~1; return r; };   // 16-byte aligned pieces
@@ -114,12 +114,13 @@ __device__ __forceinline__ double xy_uniform(double v) {   // a wave-uniform val
 __device__ __forceinline__ int xy_fold(int u, int nz) { return u < (nz >> 1) ? 2 * u : 2 * (nz - 1 - u) + 1; }
 __device__ __forceinline__ int xy_unfold(int r, int nz) { return (r & 1) ? nz - 1 - (r >> 1) : (r >> 1); }
 
-// Column-major band: column c occupies CW = HB + 3 doubles (an ODD number: with the 24 of HB + 2 the columns lie 48 LDS words
-// apart and the lanes of a trailing update fall on four bank groups),  LT[c CW + d - 1] = K[c+d][c] (d = 1..HB),
-// LT[c CW + HB] = 0,  LT[c CW + HB + 1] = K[c][c].  HB + 1 zero columns follow the nz real ones: rows past the matrix read zeros.
+// Column-major band: column c occupies CW = HB + 2 doubles,  LT[c CW + d - 1] = K[c+d][c] (d = 1..HB),  LT[c CW + HB] = 0,
+// LT[c CW + HB + 1] = K[c][c].  HB + 1 zero columns follow the nz real ones, so rows past the matrix read as zeros.
+// (CW even on purpose: the lanes of a trailing update and of the backward solve step by CW - 1 doubles, which must be odd
+// for the LDS banks.)
 template <int HB>
 __device__ __forceinline__ double* xy_entry(double* LT, int r, int c) {   // r >= c
-  return LT + c * (HB + 3) + (r == c ? HB + 1 : r - c - 1);
+  return LT + c * (HB + 2) + (r == c ? HB + 1 : r - c - 1);
 }
 
 // In-place L D L'.  Afterwards the sub-diagonal slots hold L, the diagonal slots D, dinv[c] = 1/D_c.  ONE wave; lane = EPL
@@ -127,7 +128,7 @@ __device__ __forceinline__ double* xy_entry(double* LT, int r, int c) {   // r >
 // No predication: entries whose rows lie past the matrix have a zero multiplier and rewrite zeros.
 template <int HB>
 __device__ __forceinline__ void fband_factor(double* LT, double* dinv, int nz, int lane) {
-  constexpr int CW = HB + 3, NENT = HB * (HB + 1) / 2, EPL = (NENT + kWave - 1) / kWave;
+  constexpr int CW = HB + 2, NENT = HB * (HB + 1) / 2, EPL = (NENT + kWave - 1) / kWave;
   int o1[EPL], o2[EPL], oo[EPL];
 #pragma unroll
   for (int q = 0; q < EPL; ++q) {
@@ -174,7 +175,7 @@ __device__ __forceinline__ void fband_factor(double* LT, double* dinv, int nz, i
 // instead of ~60 (measured: 45 k -> see DESIGN.md 3b cycles per solve).
 template <int HB, int NG>
 __device__ __forceinline__ void fband_solve(const double* LT, const double* dinv, int nz, int lane, const double* rhs, double* out) {
-  constexpr int CW = HB + 3;
+  constexpr int CW = HB + 2;
   double y[NG], ln[NG];
   int rcl[NG];
 #pragma unroll
@@ -329,7 +330,7 @@ __device__ __forceinline__ void xy_span_sums(const double* __restrict__ bbx, int
 // ------------------------------------------------------------------------------------------------
 template <int K, int NT>
 __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
-  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, HC = 2 * K + 1, H1 = HC + 2, HB = 2 * HC, CW = HB + 3;   // H1: row stride of Pc (odd; HC + 1 slots used)
+  constexpr int K1 = K + 1, NE = K1 * (K1 + 1) / 2, HC = 2 * K + 1, H1 = HC + 2, HB = 2 * HC, CW = HB + 2;   // H1: row stride of Pc (odd; HC + 1 slots used)
   constexpr int R = kXYRows;
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
