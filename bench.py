@@ -334,7 +334,7 @@ def global_qp_xy_block(trk, d_widths, g, args, torch, with_cpu):
            "block_threads": int(out["rl_stats"].block_threads), "lds_bytes_per_workgroup": int(out["rl_stats"].lds_bytes),
            "kernel": "k_global_xy",
            "actual_limiter": "register file: the interior-point state of 4 samples x 2 rows per thread (96 registers) plus the row "
-                             "passes exceed 256 VGPRs -- 108 spilled registers (DESIGN.md 3b); then the one factorising wave"}
+                             "passes exceed 256 VGPRs -- 139 spilled registers, 6 GB of scratch writes per launch (DESIGN.md 3b); then the one factorising wave"}
     if with_cpu:
         from oracle import oracle as orc
         ninst = 2
