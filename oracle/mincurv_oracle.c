@@ -1693,6 +1693,7 @@ int orc_global_mincurv_xy(const double* t, int nt, const double* cx0, const doub
     }
     double qinf = 0.0;
     for (int j = 0; j < nz; ++j) qinf = fmax(qinf, fabs(qv[j]));
+    double res_prev = INFINITY;
     for (int it = 0; it < 80; ++it) {
       double mu = 0.0, rpmax = 0.0;
       for (int j = 0; j < nz; ++j) {
@@ -1719,8 +1720,13 @@ int orc_global_mincurv_xy(const double* t, int nt, const double* cx0, const doub
          * widths changed by 1e-9 m, 3 and 6 linearisations): the result moves by up to 1e-2 m with 1e-5 / 1e-4, by at most
          * 3e-7 m with 1e-7 / 1e-6 (same as with exact solves), for 101-104 instead of 86-88 iterations (exact: 110-112).
          * Same constants as csrc/rl_global_xy.hpp kXYLooseMu / kXYLooseRes. */
+        /* converged -- or the complementarity is there and the residual has stopped falling within 100 x its tolerance
+         * (going on only drives mu down and the residual up with the normal matrix's conditioning: csrc/rl_global_xy.hpp) */
         const int last_qp = outer + 1 >= n_outer;
-        if (fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : 1e-6) && mu < (last_qp ? 1e-10 : 1e-7)) break;
+        const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : 1e-6;
+        const int done = mu < (last_qp ? 1e-10 : 1e-7) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));
+        res_prev = res;
+        if (done) break;
       }
       ++total_it;
       memcpy(Kq, P, (size_t)nz * nz * sizeof(double));

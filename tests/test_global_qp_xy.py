@@ -210,6 +210,33 @@ def test_batch_properties_full_size(rl, fits):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dof", [1, 2])
+def test_batch_sample_against_the_twin_two_tier(rl, fits, dof):
+    """64 instances of the benchmarked batch (every 16th) against the twins, both formulations.  Kernel and twin are two
+    implementations of an iteration with tolerance-based exits from INEXACT intermediate QPs: on a few per cent of the instances one
+    of them leaves an intermediate QP one iteration earlier, the lines then differ by up to ~1e-3 m at equal cost (9 digits) and
+    come together again as the Gauss-Newton iteration converges (tools/global_outlier_trace.py; the whole batch:
+    profiles/r05_global_full_batch_vs_twin.json -- 992 / 1002 of 1024 within 1e-6 m, largest 6.8e-4 / 1.4e-4 m).  So: every
+    instance within 2e-3 m with the cost equal to 1e-7 and the iteration count within 5; at least 90 % within 2e-6 m."""
+    t, cx, cy, k, u, wl, wr = monza_widths(fits, "c100", 2000)
+    W = rl.batch.width_batch(wl, wr, 1024, seed=1234)[::16]
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, 2000)
+    ctrl, xy, a, st, rs = rl.ops.global_batch_host(trk, W, MARGIN, 6, dof=dof, lon=LON)
+    dev, dits = [], []
+    for b in range(len(W)):
+        if dof == 1:
+            r = orc.global_mincurv(t, cx, cy, k, 2000, W[b, :, 0], W[b, :, 1], MARGIN, 6)
+        else:
+            r = orc.global_mincurv_xy(t, cx, cy, k, 2000, W[b, :, 0], W[b, :, 1], MARGIN, LON, 6)
+        dev.append(np.abs(xy[b] - r[2]).max()); dits.append(abs(int(st[b, 0]) - int(r[4][0])))
+        assert st[b, 2] == pytest.approx(r[4][2], rel=1e-7)
+    dev = np.array(dev)
+    print(f"[global dof={dof}, 64 instances vs twin] within 2e-6 m: {(dev <= TOL).sum()}, largest {dev.max():.2e} m, median {np.median(dev):.2e} m, "
+          f"largest iteration-count difference {max(dits)}")
+    assert dev.max() <= 2e-3 and max(dits) <= 5 and (dev <= TOL).mean() >= 0.9
+
+
+@pytest.mark.gpu
 def test_torch_entry_and_errors(rl, fits):
     import torch
     t, cx, cy, k, u, wl, wr = monza_widths(fits, "c100", 500)
