@@ -910,6 +910,8 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     if (a.out_z) for (int q = 0; q < 12; ++q) a.out_z[(size_t)b * np * 2 + q] = (double)pt[q];
 #endif
   }
+#undef XY_SMP
+#undef XY_STAMP
 }
 
 }  // namespace rl
