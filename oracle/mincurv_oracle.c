@@ -1453,6 +1453,7 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
     }
     double qinf = 0.0;
     for (int j = 0; j < np_; ++j) qinf = fmax(qinf, fabs(qv[j]));
+    double res_prev = INFINITY;
     for (int it = 0; it < 80; ++it) {
       /* residuals */
       double mu = 0.0, rpmax = 0.0;
@@ -1475,7 +1476,11 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
       { /* all but the last linearisation are solved inexactly (complementarity 1e-5, residuals 1e-4): the next
          * Gauss-Newton step moves the line by decimetres; same constants as csrc/rl_global.hpp kGLooseMu / kGLooseRes */
         const int last_qp = outer + 1 >= n_outer;
-        if (fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : 1e-4) && mu < (last_qp ? 1e-10 : 1e-5)) break;
+        const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : 1e-4;
+        /* ... or mu is converged and the residual, within 100 x its tolerance, has stopped falling (csrc/rl_global_xy.hpp) */
+        const int done = mu < (last_qp ? 1e-10 : 1e-5) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));
+        res_prev = res;
+        if (done) break;
       }
       ++total_it;
       /* normal matrix */

@@ -400,6 +400,7 @@ __global__ void __launch_bounds__(MAXB) k_global_qp(GlobalArgs a) {
         }
       }
     }
+    double res_prev = INFINITY;
     for (int it = 0; it < a.max_ipm; ++it) {
       // ---- residuals, complementarity, and the span sums of A'DA, A'e, A'(lu - ll)
       for (int j = tid; j < np; j += nt) {
@@ -472,7 +473,10 @@ __global__ void __launch_bounds__(MAXB) k_global_qp(GlobalArgs a) {
       reduce3(d0, rdmax, d1);
       {   // inexact solves of all but the last linearisation (see k_global_qp2; twin: orc_global_mincurv)
         const bool last_qp = outer + 1 >= a.n_outer;
-        if (fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : kGLooseRes) && mu < (last_qp ? 1e-10 : kGLooseMu)) break;
+        const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : kGLooseRes;
+        const bool done = mu < (last_qp ? 1e-10 : kGLooseMu) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));   // (stagnation
+        res_prev = res;                                                                                      //  clause: k_global_qp2)
+        if (done) break;
       }
       ++total_it;
       // ---- factor, affine direction

@@ -1081,6 +1081,7 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
       }
       __syncthreads();
       double *xc = xsA, *xn = xsB;
+      double res_prev = INFINITY;
       for (int it = 0; it < a.max_ipm; ++it) {
         // [I1]  rdP = P x + q
         for (int j = lane; j < np; j += kWave) {
@@ -1119,7 +1120,11 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
           // Gauss-Newton step moves the line by decimetres, so their last digits buy nothing (92.7 -> 73 interior-point
           // iterations on the benchmarked batch, same final sum kappa^2; rl_global.hpp: kGLooseMu; twin: orc_global_mincurv)
           const bool last_qp = outer + 1 >= a.n_outer;
-          conv = fmax(rdmax / (1.0 + qinf), rpmax) < (last_qp ? 1e-9 : kGLooseRes) && mu < (last_qp ? 1e-10 : kGLooseMu);
+          // ... or the complementarity is there and the residual, within 100 x its tolerance, has stopped falling: going on only
+          // drives mu down and the residual up with the conditioning (found on k_global_xy, rl_global_xy.hpp; same rule in the twin)
+          const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : kGLooseRes;
+          conv = mu < (last_qp ? 1e-10 : kGLooseMu) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));
+          res_prev = res;
           if (lane == 0) ctl[0] = conv ? 1.0 : 0.0;
         }
         double bx[G];
