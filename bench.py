@@ -335,6 +335,14 @@ def global_qp_xy_block(trk, d_widths, g, args, torch, with_cpu):
            "kernel": "k_global_xy",
            "actual_limiter": "register file: the interior-point state of 4 samples x 2 rows per thread (96 registers) plus the row "
                              "passes exceed 256 VGPRs -- 139 spilled registers, 6 GB of scratch writes per launch (DESIGN.md 3b); then the one factorising wave"}
+    prof = profile_block("k_global_xy")
+    if prof:   # committed rocprofv3 counters of the same kernel (profiles/counters_latest.json), not measured in this run
+        c = prof["counters_per_launch"]
+        blk["counters"] = {"source": prof["source"], "measured_in_run": False, "kernel_ms_under_rocprof": prof["avg_ms"],
+                           "wave_cycles_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in c else None,
+                           "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if "SQ_LDS_IDX_ACTIVE" in c else None,
+                           "vmem_read_wave_insts": c.get("SQ_INSTS_VMEM_RD"), "hbm_write_bytes": c.get("WRITE_SIZE", 0.0) * 1024.0,
+                           "hbm_fetch_bytes": c.get("FETCH_SIZE", 0.0) * 1024.0, "valu": valu_block(prof, ms)}
     if with_cpu:
         from oracle import oracle as orc
         ninst = 2
