@@ -228,5 +228,159 @@ RL_CR_FN Heading heading(double x, double y, const double (*tab)[2] = kAtanTab) 
   return o;
 }
 
+// ---- two-stage evaluation (round 6) ------------------------------------------------------------------------------------
+// heading() above costs ~600 instructions per sample because every intermediate is a full double-double.  Almost always a
+// much cheaper evaluation DECIDES the five roundings: heading_fast() computes theta = atan2(y, x) and the four direction
+// components to about 2^-72 (absolute; far better near an axis) together with a rigorous bound on its own error, and
+// returns true only if, for every output, the two ends of the error interval round to the same double (Ziv's rounding
+// test).  Then the outputs ARE the correctly rounded values.  Otherwise (about 1 sample in 10^4; always for tangents on or
+// extremely near an axis, non-finite or of extreme magnitude) it returns false and the caller evaluates heading().
+//
+// Method.  theta: the same reduction w = (num - c den) / (den + c num), c = j/64, with numerator and denominator exact as
+// double-doubles; the quotient as w = wh + wl through ONE reciprocal (float seed + a Newton step, relative error rho <=
+// 2^-44): wh = fl(nh R), wl = (nh - wh dh + nl - wh dl) R, error <= 2^-88 |w| + 2^-96; atan w = w + corr with
+// corr = w^3 P(w^2) in plain double (|corr| <= 2^-22.6, relative error <= 5 ulp: the term that sets the bound);
+// theta = K +- (T_j + w + corr) with sloppy double-double additions (errors ~2^-105).
+//     |theta_true - (th.hi + th.lo)| <= e_th = 2^-50 |corr| + 2^-85 |w| + 2^-100.
+// (cos, sin) theta = (x, y) / sqrt(x^2 + y^2): x^2 + y^2 as a double-double, reciprocal square root y1 from a float seed and
+// one Newton step in double, the residual e = 1 - s y1^2 formed to ~2^-104, rinv = y1 + y1 e/2; relative error < 2^-100.
+// The four outputs are  sin / cos (theta + eta)  with the same eta as in heading(), |eta| < 2^-51, known to e_th:
+//     |V_true - (vh + vl)| <= e_th |other component| + 2^-98 |this component|.
+// The seeds are the only place where host and device differ (v_rcp_f32 / v_rsq_f32, 1 ulp, against 1.0f / x and
+// 1.0f / sqrtf(x)); the bounds hold for any seed within 2^-22 and tests/crmath_check.cpp perturbs the seeds by that much.
+#if defined(RL_CR_SEED_PERTURB)
+static double g_seed_perturb = 1.0;   // host tests only: multiplies both seeds (1 +- 2^-22.5)
+#define RL_CR_PERTURB(v) ((v) * g_seed_perturb)
+#else
+#define RL_CR_PERTURB(v) (v)
+#endif
+// The three parts of heading_fast (direction, angle, roundings) are independent until the end; left alone, the scheduler
+// interleaves them and the kernel that inlines it runs out of its 128 registers.  Device only: keep them in source order.
+#ifndef RL_X_HSEQ
+#define RL_X_HSEQ 1
+#endif
+#ifndef RL_X_POLY
+#define RL_X_POLY 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && RL_X_HSEQ
+#define RL_CR_SEQ() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RL_CR_SEQ() do { } while (0)
+#endif
+RL_CR_FN double seed_rcp(double d) {      // 1 / d within 2^-22, d in the float range
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (double)__builtin_amdgcn_rcpf((float)d);
+#else
+  return RL_CR_PERTURB((double)(1.0f / (float)d));
+#endif
+}
+RL_CR_FN double seed_rsqrt(double d) {    // 1 / sqrt(d) within 2^-22, d in the float range
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (double)__builtin_amdgcn_rsqf((float)d);
+#else
+  return RL_CR_PERTURB((double)(1.0f / sqrtf((float)d)));
+#endif
+}
+
+// diag (host tests): [0,1] th.hi, th.lo  [2] e_th  [3 + 3 q .. ] vh, vl, E of output q = cl, sl, cr, sr (before the sign)
+RL_CR_FN bool heading_fast(double x, double y, Heading& o, const double (*tab)[2] = kAtanTab, double* diag = nullptr) {
+  RL_CR_STRICT
+  const double kPio2Hi = 0x1.921fb54442d18p+0, kPio2Lo = 0x1.1a62633145c07p-54;
+  const double kPiHi = 0x1.921fb54442d18p+1, kPiLo = 0x1.1a62633145c07p-53;
+  const double ax = fabs(x), ay = fabs(y);
+  const bool swap = ay > ax;
+  const double den = swap ? ay : ax, num = swap ? ax : ay;
+  // ordinary tangents only: finite, not on an axis, |min / max| >= 2^-40, max component within 2^+-60
+  // (no early return: anything else flows through as garbage or NaN and is rejected at the end, without a divergent branch)
+  const bool ordinary = den >= 0x1p-60 && den <= 0x1p+60 && num >= den * 0x1p-40;
+  // ---- (cos, sin) theta
+  const dd dd2 = two_prod(den, den), nn2 = two_prod(num, num);
+  const dd s2 = fast_two_sum(dd2.hi, nn2.hi);
+  const double s2l = s2.lo + (dd2.lo + nn2.lo);
+  const double y0 = seed_rsqrt(s2.hi);
+  const double e0 = fma(-(s2.hi * y0), y0, 1.0);
+  const double y1 = fma(y0, e0 * fma(0.375, e0, 0.5), y0);
+  const dd yy = two_prod(y1, y1);
+  const double mh = s2.hi * yy.hi;
+  const double ml = fma(s2.hi, yy.hi, -mh) + fma(s2l, yy.hi, s2.hi * yy.lo);
+  const double e = (1.0 - mh) - ml;                          // 1 - s2 y1^2
+  const double rl = y1 * (0.5 * e);
+  const double cth = y1 * x, ctl = fma(rl, x, fma(y1, x, -cth));
+  const double sth = y1 * y, stl = fma(rl, y, fma(y1, y, -sth));
+  RL_CR_SEQ();
+  // ---- theta
+  const float qf = (float)num * (float)seed_rcp(den);
+  int j = (int)rintf(qf * 64.0f);
+  j = j < 0 ? 0 : (j > 64 ? 64 : j);
+  const double c = (double)j * 0.015625;
+  const dd p = two_prod(c, den);
+  const dd h = two_sum(num, -p.hi);
+  const dd nn = two_sum(h.hi, h.lo - p.lo);                 // num - c den, exact
+  const dd p2 = two_prod(c, num);
+  const dd sd = fast_two_sum(den, p2.hi);
+  const double dh = sd.hi, dl = sd.lo + p2.lo;              // den + c num
+  const double r0 = seed_rcp(dh);
+  const double R = fma(r0, fma(-dh, r0, 1.0), r0);
+  const double wh0 = nn.hi * R;
+  const double rr = fma(-wh0, dh, nn.hi);
+  const double wl0 = fma(-wh0, dl, rr + nn.lo) * R;
+  const dd w = fast_two_sum(wh0, wl0);
+  const double u2 = w.hi * w.hi;
+#if RL_X_POLY
+  // atan w - w = -(w^3 / 3) (1 - 3/5 w^2 (1 - 5/7 w^2 (1 - 7/9 w^2 (1 - 9/11 w^2)))): every addend is the inline constant 1.0
+  const double q4 = fma(u2 * (-9.0 / 11.0), 1.0, 1.0);
+  const double q3 = fma(u2 * (-7.0 / 9.0), q4, 1.0);
+  const double q2 = fma(u2 * (-5.0 / 7.0), q3, 1.0);
+  const double q1 = fma(u2 * (-3.0 / 5.0), q2, 1.0);
+  const double corr = ((w.hi * u2) * (-1.0 / 3.0)) * q1;
+#else
+  const double P = fma(u2, fma(u2, fma(u2, fma(u2, -1.0 / 11.0, 1.0 / 9.0), -1.0 / 7.0), 0.2), -1.0 / 3.0);
+  const double corr = (w.hi * u2) * P;
+#endif
+  const dd a0 = fast_two_sum(tab[j][0], w.hi);              // T_j >= |w| for j >= 1, T_0 = 0
+  const dd a1 = fast_two_sum(a0.hi, corr);
+  dd th = fast_two_sum(a1.hi, a1.lo + (a0.lo + (tab[j][1] + w.lo)));
+  // theta = sign(y) (K + sigma th):  (0, +) | x < 0: (pi, -) | swapped: (pi/2, -) | swapped and x < 0: (pi/2, +)
+  const bool xneg = x < 0.0;
+  const double Kh = swap ? kPio2Hi : (xneg ? kPiHi : 0.0), Kl = swap ? kPio2Lo : (xneg ? kPiLo : 0.0);
+  const bool minus = swap != xneg;
+  const dd qd = fast_two_sum(Kh, minus ? -th.hi : th.hi);
+  th = fast_two_sum(qd.hi, qd.lo + (Kl + (minus ? -th.lo : th.lo)));
+  if (y < 0.0) th = dd_neg(th);
+  const double e_th = fma(0x1p-50, fabs(corr), fma(0x1p-85, fabs(w.hi), 0x1p-100));
+  const double yaw_m = th.hi + (th.lo - e_th), yaw_p = th.hi + (th.lo + e_th);
+  bool ok = yaw_m == yaw_p;
+  o.yaw = yaw_m;
+  const double delta = (th.hi - yaw_m) + th.lo;             // theta - yaw
+  RL_CR_SEQ();
+  // ---- the four components:  xL = fl(yaw + fl(pi/2)) = theta + pi/2 + etaL,  xR = fl(yaw - fl(pi/2)) = theta - pi/2 + etaR
+  const dd aL = two_sum(yaw_m, kPio2Hi), aR = two_sum(yaw_m, -kPio2Hi);
+  const double etaL = (-delta - kPio2Lo) - aL.lo;
+  const double etaR = (-delta + kPio2Lo) - aR.lo;
+  auto decide = [&](double hi, double lo, double other, double eta, double& out, int slot) {
+    const dd v = fast_two_sum(hi, fma(eta, other, lo));     // sin / cos (theta + eta) = this + eta * other - ...
+    const double E = fma(e_th, fabs(other), 0x1p-98 * fabs(hi));
+    const double r_m = v.hi + (v.lo - E), r_p = v.hi + (v.lo + E);
+    out = r_m;
+    if (diag) { diag[3 + 3 * slot] = v.hi; diag[4 + 3 * slot] = v.lo; diag[5 + 3 * slot] = E; }
+    return r_m == r_p;
+  };
+  double sL, cL, sR, cR;
+  ok = decide(sth, stl, cth, etaL, sL, 0) && ok;            // cos xL = -sin(theta + etaL)
+  ok = decide(cth, ctl, sth, -etaL, cL, 1) && ok;           // sin xL =  cos(theta + etaL)
+  ok = decide(sth, stl, cth, etaR, sR, 2) && ok;            // cos xR =  sin(theta + etaR)
+  ok = decide(cth, ctl, sth, -etaR, cR, 3) && ok;           // sin xR = -cos(theta + etaR)
+  o.cl = -sL; o.sl = cL; o.cr = sR; o.sr = -cR;
+  if (diag) { diag[0] = th.hi; diag[1] = th.lo; diag[2] = ordinary ? e_th : 0.0; }
+  return ok && ordinary;
+}
+
+// the product's entry point: the cheap stage, the full one where it cannot decide
+RL_CR_FN Heading heading2(double x, double y, const double (*tab)[2] = kAtanTab) {
+  Heading o;
+  if (!heading_fast(x, y, o, tab)) o = heading(x, y, tab);
+  return o;
+}
+
 }  // namespace cr
 }  // namespace rl

@@ -117,6 +117,15 @@ __device__ __forceinline__ void scaled_normal(double dx, double dy, double max_d
 // ---------------------------------------------------------------------------------------------
 // Closest crossing of the normal segment p + s*d, s in [-1,1], with a closed polyline.
 // Semantics of Trajectory.fill_bounds (models/trajectory.py:84-129); arithmetic identical to
+// A zero the compiler cannot see through, re-made wherever it is called (one scalar move).  Added to a thread or lane index it
+// keeps the address arithmetic that hangs on that index INSIDE the loop that uses it: hoisted out of a long loop, such per-lane
+// addresses fill the register file and come back from scratch memory, one memory round trip in front of every access.
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+
 // oracle/mincurv_oracle.c: closest_hit.  Returns the signed parameter s of the closest hit,
 // 0 when there is none (bound = the waypoint itself, trajectory.py:127).
 struct Hit {

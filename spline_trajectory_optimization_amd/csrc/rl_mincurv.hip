@@ -332,6 +332,10 @@ int launch_sweep_t(const rl_ctx* ctx, const rl::SweepArgs& a, size_t lds) {
 int launch_sweep(const rl_ctx* ctx, int k, const SweepPlan& p, const rl::SweepArgs& a, bool joint = false, bool strict = false,
                  bool lite = false) {
   if (strict) {   // RL_ARITH_REFERENCE / _BRANCH: degree-5 splines (the reference's wrap is written for k = 5, optimizer.py:281-285)
+#ifdef RL_STAMPS
+    if (k == 5 && !joint && !lite && !p.rings_in_lds)   // diagnostic build: the plain reference-order kernel with its phase stamps in a.dbg
+      return launch_sweep_t<5, 256, false, false, false, false, true>(ctx, a, p.lds_bytes);
+#endif
     if (k != 5 || a.dbg || (joint && lite)) return fail(RL_ERR_UNSUPPORTED, "reference-order / branch arithmetic: degree-5 splines, no step dump; the sliding-window driver in the reference-order arithmetic only");
     if (joint)    // run_joint_min_curvature_qp in the reference-order arithmetic
       return p.rings_in_lds ? launch_sweep_t<5, 256, true, true, false, true, true>(ctx, a, p.lds_bytes)
@@ -827,7 +831,12 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
 #ifdef RL_ABLATION
   if (const char* dbg = getenv("RL_DEBUG_FLAGS")) a.debug = atoi(dbg);
 #endif
-  if (g_dbg_instances > 0 && (joint || k == 5) && !strict) {
+#ifdef RL_STAMPS
+  const bool dbg_ok = true;
+#else
+  const bool dbg_ok = !strict;
+#endif
+  if (g_dbg_instances > 0 && (joint || k == 5) && dbg_ok) {
     const int ninst = std::min(g_dbg_instances, B);
     size_t need = joint ? (size_t)max_iter * (size_t)(i_max - i_min) * (48 + 9 * rl::kJointRowsPerThread * 256 + 2 * n)
                         : (size_t)ninst * max_iter * 2 * (size_t)(i_max - i_min) * (rl::kSweepDumpHead + 2 * n);

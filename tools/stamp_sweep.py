@@ -15,18 +15,19 @@ centre, left, right = batch.load_monza(); line = batch.monza_centerline(100.0, 5
 tg = RaceTrack("Monza", left, right, centre); traj = line.sample_along(ts=np.linspace(0, 1, 2000, endpoint=False)); tg.fill_trajectory_boundaries(traj)
 wl, wr = batch.half_widths_from_bounds(traj.points)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+ARITH = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 0 fast, 1 reference-order
 W = batch.width_batch(wl, wr, B, seed=1234); ist = batch.default_i_start(len(cx), k, 5, seed=0)
 trk = _lib.Track(ctx, t, cx, cy, k, 2000)
 lib = _lib.load()
 _lib.check(lib.rl_debug_dump_enable(1))
 for _ in range(2):
-    out = ops.solve_batch_host(trk, _lib.BOUNDS_WIDTHS, W, ist)
+    out = ops.solve_batch_host(trk, _lib.BOUNDS_WIDTHS, W, ist, arith=ARITH)
 buf = np.zeros(B * 4 * 16)
 _lib.check(lib.rl_debug_read(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(buf)))
 s = buf.reshape(B, 4, 16)
 tot = s[:, :, 6]
 names = ["phase 1 (cost + constraints + reductions)", "barrier A", "phase 2 (QP, wave 0)", "barrier B", "phase 3 (refresh)", "barrier C"]
-res = {"kernel_ms": out[4].kernel_ms, "B": B, "cycles_per_wave_mean": float(tot.mean())}
+res = {"kernel_ms": out[4].kernel_ms, "B": B, "arith": ARITH, "cycles_per_wave_mean": float(tot.mean())}
 for q, nm in enumerate(names):
     res[nm] = {"share_all_waves": float((s[:, :, q] / tot).mean()), "share_wave0": float((s[:, 0, q] / tot[:, 0]).mean()),
                "cycles_per_step_mean": float(s[:, :, q].mean() / 610)}
@@ -34,4 +35,8 @@ fine = ["refresh: curve evaluation + normal", "refresh: left ring search", "refr
         "  of the two searches: window scan (loads, sign pass, exact tests)"]
 for q, nm in zip((0, 1, 2, 3, 4), fine):
     res[nm] = {"share_wave0": float((s[:, 0, 8 + q] / tot[:, 0]).mean()), "cycles_per_step_wave0": float(s[:, 0, 8 + q].mean() / 610)}
+if ARITH == 1:   # reference-order loop: slots 0 terms, 1 barrier, 2 in-order sums + QP, 3 barrier, 4 refresh, 5 barrier
+    res["note"] = "reference-order loop: phase 1 = cost terms and rows; phase 2 = the six in-order sums (wave 0) + QP + derivative window"
+    res["refresh: heading (inside evaluation)"] = {"share_wave0": float((s[:, 0, 13] / tot[:, 0]).mean()), "cycles_per_step_wave0": float(s[:, 0, 13].mean() / 610)}
+    res["tiles that took the full heading, per instance (all waves)"] = float(s[:, :, 14].sum(axis=1).mean())
 print(json.dumps(res, indent=1))
