@@ -126,6 +126,14 @@ __device__ __forceinline__ int opaque_zero() {
   return z;
 }
 
+// A workgroup barrier that orders LDS traffic only: __syncthreads() also waits until the wave's GLOBAL stores have completed
+// (s_waitcnt vmcnt(0)), a memory round trip in front of the barrier.  Where everything the other waves read next lives in
+// LDS -- and the next reader of the global data sits behind a full __syncthreads() anyway -- that wait can ride along there.
+// (Written as instructions: with LDS-DMA in the kernel the compiler's own address-space-restricted fence still waits for vmcnt.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // oracle/mincurv_oracle.c: closest_hit.  Returns the signed parameter s of the closest hit,
 // 0 when there is none (bound = the waypoint itself, trajectory.py:127).
 struct Hit {
@@ -254,10 +262,18 @@ constexpr int kWinBatch = 8;
 template <int BATCH = kWinBatch, bool ST = false, typename RingPtr>
 __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo_edge, double px, double py,
                                             double dx, double dy, Hit& h) {
-  unsigned cand = 0u;
+  // Pass 1 per vertex: its side value e, then TWO bookkeeping instructions -- the sign bit of e shifted into a 25-bit word
+  // (v_alignbit) and a running minimum of |e|.  Edge q is a candidate when the signs of its two vertices differ; a vertex
+  // exactly ON the line (e == +-0, seen as a zero minimum) makes every edge of the window a candidate.  That is a superset of
+  // the edges on which edge_hit() records a crossing (it needs e_a e_b <= 0 with a sign change or a zero: same-sign pairs whose
+  // product merely underflows, and NaNs, never give one), and pass 2 runs the exact test on the candidates.  (Until round 6:
+  // `!(e_a * e_b > 0)` per edge -- a multiplication, a comparison, a select and an or.)
+  unsigned cand;
   {
     double2 v = ring[lo];
-    double ea = edge_side<ST>(v.x - px, v.y - py, dx, dy);
+    const double e0 = edge_side<ST>(v.x - px, v.y - py, dx, dy);
+    unsigned signs = (unsigned)__double2hiint(e0) >> 31;   // vertex k of the window ends up in bit 24 - k
+    double emin = fabs(e0);
 #pragma unroll
     for (int q0 = 0; q0 < kWinEdges; q0 += BATCH) {
       double2 w[BATCH];
@@ -266,13 +282,16 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         const double eb = edge_side<ST>(w[u].x - px, w[u].y - py, dx, dy);
-        if (!(ea * eb > 0.0)) cand |= 1u << (q0 + u);
-        ea = eb;
+        signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(eb), 31);   // (signs << 1) | sign(eb)
+        emin = fmin(emin, fabs(eb));
       }
       if constexpr (BATCH != kWinBatch) __builtin_amdgcn_sched_barrier(0);   // staged scan: keep the next batch's LDS reads behind this batch's arithmetic (registers)
     }
+    // sign change across edge q <-> bits 24 - q and 23 - q of `signs` differ <-> bit 23 - q of signs ^ (signs >> 1); reversed: bit q
+    cand = __builtin_bitreverse32((signs ^ (signs >> 1)) & 0xFFFFFFu) >> 8;
+    if (emin == 0.0) cand = 0xFFFFFFu;
   }
-  static_assert(kWinEdges % BATCH == 0, "window scan is unrolled in whole batches");
+  static_assert(kWinEdges == 24 && kWinEdges % BATCH == 0, "window scan is unrolled in whole batches; the candidate word holds 24 edges");
   while (__any(cand != 0u)) {
     if (cand != 0u) {
       const int q = __ffs((int)cand) - 1;
