@@ -87,6 +87,12 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------------
+SWEEP_LIMITER = ("VALU instruction issue: across the arithmetic modes and builds of rounds 5-6 the kernel time is 2.9 ps per executed "
+                 "VALU wave-instruction (1024 SIMDs, ~58 % of their cycles issuing, the rest the stalls of the steps' dependent chains "
+                 "at 4 workgroups per CU); the solver state is on chip: the HBM roofline is the one north_star designates, the kernel "
+                 "is not HBM bound (DESIGN.md section 3)")
+
+
 def profile_block(kernel):
     """Counter-derived figures of `kernel` from the committed rocprofv3 summary (profiles/): NOT measured in
     this run -- PMC collection needs its own rocprofv3 passes (tools/profile_bench.sh)."""
@@ -147,13 +153,29 @@ def cpu_legs(groups, i_starts, xy_gpu, ninst_total):
 
 
 def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref_run, fast_ns_all=None):
-    """The same batch through the sweep's REFERENCE-ORDER arithmetic (RL_ARITH_REFERENCE, include/rl_mincurv.h): the
-    reference's operations in the reference's order, which returns the oracle's bits.  Timed like the headline (events on
-    the launch stream around each of `steps` launches after a warm-up); compared, on the cpu_baseline sample, with the
-    oracle's build whose atan2 / cos / sin are the correctly rounded ones (bit for bit), with the strict oracle on the
-    platform libm (the headline leg's comparison) and with the reference's own runs of instances 0 and 3 (fixture G7b)."""
+    """The same batch through the sweep's REFERENCE-ORDER arithmetic (RL_ARITH_REFERENCE, include/rl_mincurv.h, the default
+    since round 6): the reference's operations in the reference's order, which returns the oracle's bits.  Timed like the
+    headline (events on the launch stream around each of `steps` launches after a warm-up); compared, on the cpu_baseline
+    sample, with the oracle's build whose atan2 / cos / sin are the correctly rounded ones (bit for bit), with the strict
+    oracle on the platform libm and with the reference's own runs (fixtures G7b, G7d).  The fast and the branch arithmetic are
+    timed here too and laid beside it on the WHOLE batch (fast_xy None: the headline ran in the reference-order arithmetic)."""
     from oracle import oracle as orc
     from spline_trajectory_optimization_amd import _lib, ops
+
+    def timed(arith_):
+        o_ = ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search, arith=arith_)
+        torch.cuda.synchronize()
+        ev_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a_, b_ in ev_:
+            a_.record()
+            ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search, out=o_, arith=arith_)
+            b_.record()
+        torch.cuda.synchronize()
+        return o_, float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev_]))
+
+    if fast_xy is None:
+        fo, fast_kernel_ms = timed(_lib.ARITH_FAST)
+        fast_xy, fast_ns_all = fo["xy"].cpu().numpy(), fo["n_success"].cpu().numpy()
     out = ops.solve_batch_torch(g["trk"], _lib.BOUNDS_WIDTHS, g["d_widths"], g["i_start"], search=search, arith=_lib.ARITH_REFERENCE)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -170,17 +192,16 @@ def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref
     leg = {"what": "the headline batch in RL_ARITH_REFERENCE: unfused de Boor recurrences and sums, splder derivative splines in the "
                    "cost, sequential cost sums, unfused cross products, correctly rounded atan2 / cos / sin (csrc/rl_crmath.hpp)",
            "kernel": "k_sweep<..., STRICT>", "kernel_ms": ms, "solves_per_s": B / ms * 1e3, "steps": args.steps,
-           "cost_vs_fast": ms / fast_kernel_ms,
-           "default": "fast (the reference-order mode costs more than 10 %): rl_ctx_set_arith(ctx, RL_ARITH_REFERENCE) / RL_ARITH=reference / "
-                      "bench.py --arith reference select it",
+           "cost_vs_fast": ms / fast_kernel_ms, "fast_kernel_ms": fast_kernel_ms, "fast_solves_per_s": B / fast_kernel_ms * 1e3,
+           "default": "reference-order (round 6): rl_ctx_create, RL_ARITH unset and bench.py --arith all start there; "
+                      "rl_ctx_set_arith(ctx, RL_ARITH_FAST) / RL_ARITH=fast / bench.py --arith fast select the fast arithmetic",
            "lds_bytes_per_workgroup": int(out["stats"].lds_bytes)}
     prof = profile_block("k_sweep_reference_order")
     ach = (BYTES_PER_SOLVE * B) / (ms * 1e-3) / 1e9
     leg["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                        "traffic": prof.get("hbm_bytes_fetch_x2") if prof else None, "traffic_source": prof.get("source") if prof else None,
                        "traffic_measured_in_run": False, "kernel_ms": ms, "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
-                       "actual_limiter": "as the fast kernel (latency of a step's dependent chain at four workgroups per CU), with 46 % more VALU "
-                                         "instructions per step: the double-double heading, IEEE divisions and unfused sums (DESIGN.md 5b)",
+                       "actual_limiter": SWEEP_LIMITER,
                        "valu": valu_block(prof, ms)}
     if po is not None:
         m = po.xy0.shape[0]
@@ -551,6 +572,12 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     exit_code = 0
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    # test hooks of tests/test_host_cpu.py::test_spawn_ranks_propagates_a_failed_rank (no GPU needed up to here): one rank fails at
+    # once, the others would sit for a while -- spawn_ranks has to end them and hand the failing rank's code on
+    if os.environ.get("RL_BENCH_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    if os.environ.get("RL_BENCH_HOLD_S"):
+        time.sleep(float(os.environ["RL_BENCH_HOLD_S"]))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
     if args.share_gpu:
@@ -734,7 +761,8 @@ def run_rank(args):
         qp_per_solve = [2 * MAX_ITER * (g["n"] - g["k"]) for g in groups]
         qps_per_step = sum(q * g["widths"].shape[0] for q, g in zip(qp_per_solve, groups))
         achieved = (BYTES_PER_SOLVE * B) / (kernel_ms * 1e-3) / 1e9
-        prof = profile_block("k_sweep") if args.workload == "monza" and args.arith == "fast" else None
+        prof = profile_block({"fast": "k_sweep", "reference": "k_sweep_reference_order", "branch": "k_sweep_branch"}[args.arith]) \
+            if args.workload == "monza" else None
         wl_text = (f"Monza N={N_WAYPOINTS}, batch={B} width-perturbed instances per GPU (BASELINE configs[1])"
                    if args.workload == "monza" else
                    f"mixed: {groups[0]['widths'].shape[0]} Monza + {groups[1]['widths'].shape[0]} rotated-oval "
@@ -755,7 +783,8 @@ def run_rank(args):
                 "control_point_qps_per_s": qps_per_step * world * args.steps / elapsed, "search": args.search,
                 "arith": args.arith + (" (fma, rsqrt normal, tree sums: a legal rounding of the reference's arithmetic; the reference-order "
                                        "mode is the `reference_order` leg)" if args.arith == "fast" else
-                                       (" (RL_ARITH_REFERENCE: the reference's operations in the reference's order)" if args.arith == "reference" else
+                                       (" (RL_ARITH_REFERENCE, the default: the reference's operations in the reference's order -- the CPU oracle's bits; "
+                                        "the fast arithmetic is timed in the `reference_order` leg)" if args.arith == "reference" else
                                         " (RL_ARITH_BRANCH: positions, crossings, bound points and rows in the reference's order, the rest fast)")),
                 "parallelism": f"{world} rank(s) x independent instances"
                                + (f", 1 gather to rank 0 per step and group over torch.distributed backend "
@@ -769,10 +798,7 @@ def run_rank(args):
                          "traffic_source": prof.get("source") if prof else None, "traffic_measured_in_run": False,
                          "kernel": {"fast": "k_sweep", "reference": "k_sweep<..., STRICT>", "branch": "k_sweep<..., STRICT, LITE>"}[args.arith], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
-                         "actual_limiter": "latency of one step's dependent chain at the occupancy the batch allows (4 "
-                                           "workgroups per CU; VALU ~59 % active, 61 % of wave cycles waiting); the solver "
-                                           "state is on chip: the HBM roofline is the one north_star designates, the kernel "
-                                           "is not HBM bound (DESIGN.md section 3)",
+                         "actual_limiter": SWEEP_LIMITER,
                          "valu": valu_block(prof, kernel_ms)},
         }
         if gather_check is not None:
@@ -793,10 +819,12 @@ def run_rank(args):
                 res["cpu_baseline"], pos = cpu_legs(groups, [g["i_start"] for g in groups], xy_gpu, min(args.cpu_instances, B))
             except Exception as e:
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and args.workload == "monza" and args.arith == "fast" and not args.no_reference_order:
+        if world == 1 and args.workload == "monza" and args.arith in ("fast", "reference") and not args.no_reference_order:
             try:
-                res["reference_order"] = reference_order_leg(groups[0], args, torch, search, kernel_ms, xy_gpu[0],
-                                                             pos[0] if pos else None, ref_run, fast_ns_all=ns_gpu[0])
+                fast_head = args.arith == "fast"
+                res["reference_order"] = reference_order_leg(groups[0], args, torch, search, kernel_ms if fast_head else None,
+                                                             xy_gpu[0] if fast_head else None, pos[0] if pos else None, ref_run,
+                                                             fast_ns_all=ns_gpu[0] if fast_head else None)
             except Exception as e:
                 res["reference_order"] = {"error": f"{type(e).__name__}: {e}"}
         if ref_run:
@@ -829,6 +857,31 @@ def run_rank(args):
             if ro:
                 res["parity"]["reference_order_bit_identical"] = f"{ro['bit_identical_to_the_correctly_rounded_oracle']} of {ro['sample']}"
                 res["parity"]["ok"] = bool(res["parity"]["ok"] and ro["bit_identical_to_the_correctly_rounded_oracle"] == ro["sample"])
+        # every leg's headline number, compact, as the LAST key of the line (the driver keeps the tail of the line): README / DESIGN
+        # quote these
+        ro_ = res.get("reference_order", {}) if isinstance(res.get("reference_order"), dict) else {}
+        gq_ = res.get("global_qp", {}) if isinstance(res.get("global_qp"), dict) else {}
+        mt_ = res.get("mintime_nlp", {}) if isinstance(res.get("mintime_nlp"), dict) else {}
+        qs_ = res.get("qss_sim", {}) if isinstance(res.get("qss_sim"), dict) else {}
+        wb_ = ro_.get("whole_batch_vs_reference_order", {})
+        r3 = lambda v: None if v is None else round(float(v), 3)   # noqa: E731
+        summary = {
+            "sweep_reference_ms": r3(kernel_ms if args.arith == "reference" else ro_.get("kernel_ms")),
+            "sweep_fast_ms": r3(kernel_ms if args.arith == "fast" else ro_.get("fast_kernel_ms")),
+            "sweep_branch_ms": r3(wb_.get("branch", {}).get("kernel_ms")),
+            "reference_bit_identical": res.get("parity", {}).get("reference_order_bit_identical"),
+            "fast_beyond_1e-4_m": wb_.get("fast", {}).get("instances_beyond_1e-4_m"),
+            "global_qp_ms": r3(gq_.get("kernel_ms")), "global_xy_ms": r3(gq_.get("two_dof", {}).get("kernel_ms")),
+            "global_qp_vs_twin_m": gq_.get("cpu_twin", {}).get("gpu_vs_twin_dev_m"),
+            "mintime_nlp_per_s": r3(mt_.get("value")),
+            "qss_b1_ms": r3(qs_.get("single", {}).get("ms")), "qss_b256_ms": r3(qs_.get("batch", {}).get("ms")),
+            "qss_b1024_ms": r3(qs_.get("batch_1024", {}).get("ms")),
+            "n_gpus": world, "collective": (gather_check or {}).get("collective"),
+            "parity_ok": res.get("parity", {}).get("ok"),
+        }
+        res["config"]["sweep_reference_ms"] = summary["sweep_reference_ms"]
+        res["config"]["sweep_fast_ms"] = summary["sweep_fast_ms"]
+        res["summary"] = summary
         print(json.dumps(res), flush=True)
         # a line whose parity check failed, or one of whose legs crashed, must not pass for a measurement
         # ... for the legs the parity statement rests on; a crash of the independent min-time / simulator legs stays in the line
@@ -857,8 +910,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--workload", choices=["monza", "mixed"], default="monza")
     ap.add_argument("--search", choices=["windowed", "culled", "brute"], default="windowed")
-    ap.add_argument("--arith", choices=["fast", "reference", "branch"], default="fast",
-                    help="arithmetic of the headline's launches (include/rl_mincurv.h: RL_ARITH_*)")
+    ap.add_argument("--arith", choices=["fast", "reference", "branch"], default="reference",
+                    help="arithmetic of the headline's launches (include/rl_mincurv.h: RL_ARITH_*); reference = the library's default")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the reference-order leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-global", action="store_true", help="skip the global-QP leg")

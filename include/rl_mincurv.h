@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 102          /* 0.1.2: rl_mincurv_global_xy_batch_* (0.1.1: rl_ctx_set_arith) */
+#define RL_VERSION 103          /* 0.1.3: RL_ARITH_DEFAULT = reference-order where it exists (0.1.2: rl_mincurv_global_xy_batch_*; 0.1.1: rl_ctx_set_arith) */
 #define RL_NCOL 19              /* Trajectory columns, models/trajectory.py:26-44 */
 #define RL_MAX_ITER 32          /* max outer iterations per sweep call */
 #define RL_MAX_DEGREE 5
@@ -60,8 +60,11 @@ enum {
  * chunk-circle guard (the fast one) */
 enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1, RL_SEARCH_WINDOWED = 2 };
 
-/* Arithmetic of the sweep (rl_mincurv_sweep, rl_mincurv_solve_batch_*), per context (rl_ctx_set_arith; RL_ARITH=reference
- * in the environment sets the default of new contexts):
+/* Arithmetic of the sweep (rl_mincurv_sweep, rl_mincurv_solve_batch_*), per context (rl_ctx_set_arith; RL_ARITH=fast |
+ * reference | branch in the environment chooses for new contexts).  A context on which nothing was chosen (RL_ARITH_DEFAULT)
+ * runs the REFERENCE-ORDER arithmetic wherever it exists -- degree-5 splines, no step dump -- and the fast one elsewhere
+ * (since round 6; until then the fast one); a chosen arithmetic is taken literally and fails with RL_ERR_UNSUPPORTED where it
+ * does not exist.  rl_stats.reserved[0] names the arithmetic a call ran in.
  *   RL_ARITH_FAST       fma throughout, normal from a reciprocal square root, tree sums -- a legal rounding of the
  *                       reference's arithmetic, within the nearest-branch rule of DESIGN.md section 5;
  *   RL_ARITH_REFERENCE  the reference's operations in the reference's order (numpy / scipy: unfused de Boor
@@ -73,7 +76,7 @@ enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1, RL_SEARCH_WINDOWED = 2 };
  *   RL_ARITH_BRANCH     the reference-order kernel without what is expensive and does not decide the branch: positions, ring
  *                       crossings, bound points and rows in the reference's order; normals from a reciprocal square root, cost
  *                       sums from the fast tables in a tree.  Not the oracle's bits: the oracle's BRANCH. */
-enum { RL_ARITH_FAST = 0, RL_ARITH_REFERENCE = 1, RL_ARITH_BRANCH = 2 };
+enum { RL_ARITH_DEFAULT = -1, RL_ARITH_FAST = 0, RL_ARITH_REFERENCE = 1, RL_ARITH_BRANCH = 2 };
 
 typedef struct rl_stats {
   float kernel_ms;       /* duration of the sweep kernel of the last *_host call (hipEvent)  */
@@ -101,7 +104,8 @@ void rl_ctx_destroy(rl_ctx* ctx);
 /* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
 int rl_ctx_set_stream(rl_ctx* ctx, void* hip_stream);
 int rl_ctx_synchronize(rl_ctx* ctx);
-/* arithmetic of the sweep entry points of this context: RL_ARITH_FAST (default) or RL_ARITH_REFERENCE */
+/* arithmetic of the sweep entry points of this context: RL_ARITH_DEFAULT (back to "nothing chosen"), RL_ARITH_FAST,
+ * RL_ARITH_REFERENCE or RL_ARITH_BRANCH; rl_ctx_get_arith returns RL_ARITH_DEFAULT while nothing was chosen */
 int rl_ctx_set_arith(rl_ctx* ctx, int arith);
 int rl_ctx_get_arith(const rl_ctx* ctx);
 /* RL_ARITH_REFERENCE only: numpy's error state when the driver starts.  The reference's simulator switches

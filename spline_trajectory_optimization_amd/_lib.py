@@ -16,7 +16,7 @@ NCOL = 19
 MAX_ITER = 32
 BOUNDS_SHARED_RINGS, BOUNDS_WIDTHS, BOUNDS_POINTS = 0, 1, 2
 SEARCH_BRUTE, SEARCH_CULLED, SEARCH_WINDOWED = 0, 1, 2
-ARITH_FAST, ARITH_REFERENCE, ARITH_BRANCH = 0, 1, 2   # include/rl_mincurv.h: RL_ARITH_*
+ARITH_DEFAULT, ARITH_FAST, ARITH_REFERENCE, ARITH_BRANCH = -1, 0, 1, 2   # include/rl_mincurv.h: RL_ARITH_*
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -178,8 +178,9 @@ class Context:
         check(self.lib.rl_ctx_synchronize(self.h))
 
     def set_arith(self, arith):
-        """ARITH_FAST (default) or ARITH_REFERENCE: the reference's operations in the reference's order
-        (include/rl_mincurv.h).  Returns the previous setting."""
+        """ARITH_DEFAULT (nothing chosen: the reference-order arithmetic wherever it exists, the fast one elsewhere), ARITH_FAST,
+        ARITH_REFERENCE (the reference's operations in the reference's order) or ARITH_BRANCH (include/rl_mincurv.h).
+        Returns the previous setting (ARITH_DEFAULT while nothing was chosen)."""
         old = self.lib.rl_ctx_get_arith(self.h)
         check(self.lib.rl_ctx_set_arith(self.h, int(arith)))
         return old

@@ -171,8 +171,9 @@ def gather_to_root(tensor, rank, world, dist, total=None, out=None, async_op=Fal
     gather then runs on the process group's own stream, ordered after what is already enqueued on the
     current stream, and overlaps with whatever the caller enqueues next (bench.py: the next launch).
     `method`: "gather" = dist.gather; "p2p" = the same transfer as one batch of grouped isend / irecv; "auto" =
-    dist.gather, and from the first time it raises on this backend (every rank raises alike: an unsupported
-    collective is refused before anything is sent) the grouped form for the rest of the process."""
+    dist.gather, and from the first time the backend REFUSES it (NotImplementedError / "not supported": every rank is
+    refused alike, before anything is sent) the grouped form for the rest of the process; any other exception is re-raised.
+    RL_GATHER=p2p decides for the grouped form up front."""
     import torch
     if world == 1:
         return None if async_op else tensor
@@ -198,7 +199,12 @@ def gather_to_root(tensor, rank, world, dist, total=None, out=None, async_op=Fal
         try:
             work = dist.gather(pad, bufs, dst=0, async_op=async_op)
         except (RuntimeError, NotImplementedError) as e:
-            if method != "auto":
+            # only a REFUSED collective switches forms: a backend that does not implement gather says so on every rank alike,
+            # before anything is sent.  Any other failure (a shape error on one rank, out of memory, a communicator error)
+            # is that rank's alone -- falling back there would leave it in send / receive while the others sit in gather.
+            refused = isinstance(e, NotImplementedError) or any(
+                w in str(e).lower() for w in ("not support", "unsupported", "not implemented", "no backend type"))
+            if method != "auto" or not refused:
                 raise
             print(f"gather_to_root: dist.gather raised on backend '{dist.get_backend()}' ({type(e).__name__}: {e}); "
                   f"using grouped isend / irecv from here on", flush=True)

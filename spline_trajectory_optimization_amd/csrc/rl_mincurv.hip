@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,14 +74,14 @@ struct rl_ctx {
   int max_lds = 65536;
   int num_cu = 0;
   bool force_global_v1 = false;  // test hook: RL_GLOBAL_V1=1 keeps the generic kernel
-  int arith = RL_ARITH_FAST;     // rl_ctx_set_arith: arithmetic of the sweep (RL_ARITH_FAST / RL_ARITH_REFERENCE)
+  int arith = RL_ARITH_REFERENCE;   // rl_ctx_set_arith: arithmetic of the sweep; the reference-order arithmetic since round 6
+  bool arith_explicit = false;      // set by rl_ctx_set_arith / RL_ARITH: an explicit choice fails where it does not exist, the default follows
   int np_raise_at_start = 0;     // rl_ctx_set_numpy_raise: the reference-order sweep starts with np.seterr(all='raise') in effect
   // test hooks of the QSS simulator (rl_ctx_set_option; defaults from RL_QSS_DF / RL_QSS_V1 / RL_QSS_DF_WAVES / RL_QSS_DF_BAIL_AT, read
   // once in rl_ctx_create): which kernel (-1 = by the rounds the batch takes, 0 = list order, 1 = dataflow), waves per instance of
   // the dataflow kernel, the iteration at which it hands every instance back (0 = never)
   int qss_kernel = -1, qss_df_waves = 4, qss_df_bail_at = 0;
   // largest dynamic-LDS size already granted per kernel (hipFuncSetAttribute is issued only when a call needs more)
-  std::vector<std::pair<const void*, int>> dyn_lds;
   // Device scratch owned by the context (grow-only): the *_dev entry points of the QSS simulator and the
   // min-time solve carve their work arrays out of it, so that steady-state calls allocate nothing.
   void* arena = nullptr;
@@ -113,17 +114,23 @@ struct rl_ctx {
 };
 
 namespace {
-// hipFuncAttributeMaxDynamicSharedMemorySize, once per (context, kernel, size class) instead of once per call
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION on a device, shared by every context of the
+// process: one process-wide table per (device, kernel) that only ever raises the value, instead of one call per launch
+// (a per-context cache would go stale as soon as a second context asked for less).
 hipError_t grant_dyn_lds(rl_ctx* ctx, const void* fn, size_t bytes) {
-  for (auto& e : ctx->dyn_lds)
-    if (e.first == fn) {
-      if ((size_t)e.second >= bytes) return hipSuccess;
+  static std::mutex mu;
+  static std::vector<std::pair<std::pair<int, const void*>, size_t>> granted;
+  std::lock_guard<std::mutex> lock(mu);
+  const std::pair<int, const void*> key(ctx->device, fn);
+  for (auto& e : granted)
+    if (e.first == key) {
+      if (e.second >= bytes) return hipSuccess;
       const hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      if (r == hipSuccess) e.second = (int)bytes;
+      if (r == hipSuccess) e.second = bytes;
       return r;
     }
   const hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (r == hipSuccess) ctx->dyn_lds.emplace_back(fn, (int)bytes);
+  if (r == hipSuccess) granted.emplace_back(key, bytes);
   return r;
 }
 // per-call device staging of the host-pointer entry points, from the context's pool (every such entry point ends
@@ -390,6 +397,9 @@ int ensure_strict_tables(const rl_ctx* ctx, const rl_track* trk) {
   hipLaunchKernelGGL(rl::k_build_tables_strict<5>, grid, block, 0, ctx->stream, trk->t.p, trk->nt, trk->c0.p, N,
                      trk->Ds.p, trk->base_s.p);
   RL_HIP(hipGetLastError());
+  // like the other table builders: complete (and known to have succeeded) before the tables count as valid -- a later call
+  // may arrive on another stream (rl_ctx_set_stream), with no event ordering it behind this launch
+  RL_HIP(hipStreamSynchronize(ctx->stream));
   trk->strict_valid = true;
   return RL_OK;
 }
@@ -438,7 +448,10 @@ int rl_ctx_create(int device_id, rl_ctx** out) {
   }
   c->num_cu = prop.multiProcessorCount;
   if (const char* v = getenv("RL_GLOBAL_V1")) c->force_global_v1 = v[0] == '1';
-  if (const char* v = getenv("RL_ARITH")) c->arith = (v[0] == 'r' || v[0] == '1') ? RL_ARITH_REFERENCE : ((v[0] == 'b' || v[0] == '2') ? RL_ARITH_BRANCH : RL_ARITH_FAST);
+  if (const char* v = getenv("RL_ARITH")) {
+    c->arith = (v[0] == 'r' || v[0] == '1') ? RL_ARITH_REFERENCE : ((v[0] == 'b' || v[0] == '2') ? RL_ARITH_BRANCH : RL_ARITH_FAST);
+    c->arith_explicit = true;
+  }
   if (const char* v = getenv("RL_QSS_DF")) if (v[0] == '0' || v[0] == '1') c->qss_kernel = v[0] - '0';
   if (const char* v = getenv("RL_QSS_V1")) if (v[0] == '1') c->qss_kernel = 0;
   if (const char* v = getenv("RL_QSS_DF_WAVES")) { const int w = atoi(v); if (w == 1 || w == 2 || w == 4) c->qss_df_waves = w; }
@@ -483,13 +496,15 @@ int rl_ctx_set_stream(rl_ctx* ctx, void* hip_stream) {
 
 int rl_ctx_set_arith(rl_ctx* ctx, int arith) {
   if (!ctx) return fail(RL_ERR_ARG, "ctx is null");
+  if (arith == RL_ARITH_DEFAULT) { ctx->arith = RL_ARITH_REFERENCE; ctx->arith_explicit = false; return RL_OK; }
   if (arith != RL_ARITH_FAST && arith != RL_ARITH_REFERENCE && arith != RL_ARITH_BRANCH)
-    return fail(RL_ERR_ARG, "arith must be RL_ARITH_FAST, RL_ARITH_REFERENCE or RL_ARITH_BRANCH");
+    return fail(RL_ERR_ARG, "arith must be RL_ARITH_DEFAULT, RL_ARITH_FAST, RL_ARITH_REFERENCE or RL_ARITH_BRANCH");
   ctx->arith = arith;
+  ctx->arith_explicit = true;
   return RL_OK;
 }
 
-int rl_ctx_get_arith(const rl_ctx* ctx) { return ctx ? ctx->arith : RL_ERR_ARG; }
+int rl_ctx_get_arith(const rl_ctx* ctx) { return ctx ? (ctx->arith_explicit ? ctx->arith : RL_ARITH_DEFAULT) : RL_ERR_ARG; }
 
 int rl_ctx_set_option(rl_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(RL_ERR_ARG, "null argument");
@@ -800,8 +815,13 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     if (widest > rl::kJointRowsPerThread * 256)
       return fail(RL_ERR_UNSUPPORTED, "sliding-window variant: a window spans more than 768 samples");
   }
-  const bool lite = ctx->arith == RL_ARITH_BRANCH;
-  const bool strict = ctx->arith == RL_ARITH_REFERENCE || lite;    // the branch mode shares the reference-order kernel's tables and state
+  // the DEFAULT arithmetic is the reference-order one where it exists (degree-5 splines, no step dump) and the fast one
+  // elsewhere; an arithmetic chosen with rl_ctx_set_arith / RL_ARITH is taken literally (and fails where it does not exist).
+  // rl_stats.reserved[0] names the arithmetic that ran.
+  int arith = ctx->arith;
+  if (!ctx->arith_explicit && arith == RL_ARITH_REFERENCE && (k != 5 || g_dbg_instances > 0)) arith = RL_ARITH_FAST;
+  const bool lite = arith == RL_ARITH_BRANCH;
+  const bool strict = arith == RL_ARITH_REFERENCE || lite;    // the branch mode shares the reference-order kernel's tables and state
   if (strict) {
     if (joint && lite) return fail(RL_ERR_UNSUPPORTED, "the branch arithmetic (rl_ctx_set_arith) covers run_min_curvature_qp; the sliding-window driver exists in the fast and in the reference-order arithmetic");
     RL_HIP(hipSetDevice(ctx->device));
@@ -883,7 +903,7 @@ static int solve_batch_common(rl_ctx* ctx, const rl_track* trk, int form, const 
     stats->lds_bytes = (int)p.lds_bytes;
     stats->block_threads = p.block;
     stats->rings_in_lds = p.rings_in_lds ? 1 : (p.sigma_in_lds ? 2 : 0);
-    stats->reserved[0] = ctx->arith;
+    stats->reserved[0] = arith;
   }
   if (plan_out) *plan_out = p;
   return launch_sweep(ctx, k, p, a, joint, strict, lite);

@@ -14,8 +14,8 @@ Differences from the reference, all additive and keyword-only:
   * ARITHMETIC.  This class is the drop-in for the reference's, so by default it answers in the REFERENCE-ORDER arithmetic
     (`TrajectoryOptimizer.arith = _lib.ARITH_REFERENCE`: the reference's operations in numpy's / scipy's order, the CPU oracle's
     bits; include/rl_mincurv.h) wherever that exists (degree-5 splines: both drivers and the four assembly methods).  Set
-    `optm.arith = _lib.ARITH_FAST` (or pass `arith=` to a driver) for the fast arithmetic of the batched entry points; a
-    single solve costs about 6 ms in either.
+    `optm.arith = _lib.ARITH_FAST` (or pass `arith=` to a driver) for the fast arithmetic; a single solve costs about
+    6 ms in either.  (Since round 6 the batched entry points default to the reference-order arithmetic too.)
   * `run_global_min_curvature_qp` is NEW (no reference counterpart that works: the Julia notebook
     prototype): the whole line as ONE banded QP per linearisation, solved by the
     interior-point kernel (include/rl_mincurv.h: rl_mincurv_global_batch_*).
@@ -30,7 +30,7 @@ from ..simulator.simulator import Simulator
 
 
 class TrajectoryOptimizer:
-    arith = _lib.ARITH_REFERENCE     # see the module docstring; the batched ops default to the context's (fast) arithmetic
+    arith = _lib.ARITH_REFERENCE     # see the module docstring; the batched ops' default (ARITH_DEFAULT) is the same arithmetic since round 6
 
     def _scope(self, k, arith=None):
         """The arithmetic the calls inside run in: `arith` if given, else this object's; the fast one where the
@@ -139,9 +139,10 @@ class TrajectoryOptimizer:
 
         simulate=True reproduces what the reference prints: the simulator runs on the table after EVERY outer iteration
         ("Iteration j" + the result, :333-336; its speeds never feed back into the spline) and once more at the end
-        (:338-339).  The sweep is then launched once per outer iteration, each launch continuing from the control points
-        of the one before -- the same bits as the single launch, since every launch re-derives the table from the
-        control points.  arith: _lib.ARITH_FAST / ARITH_REFERENCE for this call (None = this object's `arith`: the reference-order arithmetic unless changed)."""
+        (:338-339).  The table after outer iteration j is that of a launch over the first j + 1 iterations FROM THE START
+        (max_iter launches of growing length): every launch is then a prefix of the one real run, so numpy's error state (raise
+        mode from the end of iteration 0 on, simulator.py:164) and a stale table carry over exactly as in the single launch --
+        continuing launch by launch from the control points would lose both (fixture G12).  arith: _lib.ARITH_FAST / ARITH_REFERENCE for this call (None = this object's `arith`: the reference-order arithmetic unless changed)."""
         traj_out_s = traj_in_s.copy()
         n = len(traj_out_s._spl_x.c)
         k = traj_out_s._spl_x.k
@@ -166,11 +167,12 @@ class TrajectoryOptimizer:
         if simulate:
             ns_all = []
             self.last_sim_results = []
+            cx0, cy0 = cx, cy
             for j in range(max_iter):
-                cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx, cy, i_start[j:j + 1], want_points=True, arith=arith_)
-                ns_all.append(ns[0])
-                print(f"Forward pass: number of control points successfully updated: {ns[0, 0]}")
-                print(f"Backward pass: number of control points successfully updated: {ns[0, 1]}")
+                cx, cy, pts, ns, stats = ops.mincurv_sweep(trk, cx0, cy0, i_start[:j + 1], want_points=True, arith=arith_)
+                ns_all.append(ns[j])
+                print(f"Forward pass: number of control points successfully updated: {ns[j, 0]}")
+                print(f"Backward pass: number of control points successfully updated: {ns[j, 1]}")
                 sim_result = self.sim.run_simulation(table(pts), enable_vis=False)          # :333
                 print(f"Iteration {j+1}")
                 print(sim_result)

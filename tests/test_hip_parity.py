@@ -35,7 +35,11 @@ def rl():
         pass
     ns = NS()
     ns.lib, ns.ops, ns.batch = _lib, ops, batch
-    return ns
+    # this module pins the FAST arithmetic (its tolerances, dumps and replays are statements about it); the library's default --
+    # the reference-order arithmetic since round 6 -- is the subject of tests/test_reference_order.py
+    _lib.Context.get(0).set_arith(_lib.ARITH_FAST)
+    yield ns
+    _lib.Context.get(0).set_arith(_lib.ARITH_DEFAULT)
 
 
 def test_native_library_is_the_one_loaded(rl):
@@ -1134,9 +1138,12 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     res = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                   "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py")] + tail, root)
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
-    assert res["value"] > 0 and res["roofline"]["kernel"] == "k_sweep" and "cpu_baseline" not in res
-    res = _bench([sys.executable, os.path.join(root, "bench.py")] + tail, root)
+    assert res["value"] > 0 and res["roofline"]["kernel"] == "k_sweep<..., STRICT>" and "cpu_baseline" not in res   # the default arithmetic
+    assert list(res)[-1] == "summary" and res["summary"]["n_gpus"] == 2 and res["summary"]["collective"] == res["gather_check"]["collective"]
+    assert res["summary"]["sweep_reference_ms"] == res["config"]["sweep_reference_ms"] > 0
+    res = _bench([sys.executable, os.path.join(root, "bench.py")] + tail + ["--arith", "fast"], root)
     assert res["n_gpus"] == 2 and res["value"] > 0 and "world size 2" in res["config"]["parallelism"]
+    assert res["roofline"]["kernel"] == "k_sweep" and res["summary"]["sweep_fast_ms"] > 0
 
 
 def test_bench_mixed_workload_two_ranks(tmp_path):

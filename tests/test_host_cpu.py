@@ -351,3 +351,20 @@ def test_qss_dataflow_schedule_model():
     out = subprocess.run([sys.executable, os.path.join(here, "qss_schedule_model.py"), "1", "24", "small", "0"], capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0 and "no violation" in out.stdout and out.stdout.count("case ") >= 1, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_spawn_ranks_propagates_a_failed_rank():
+    """`python bench.py --gpus N` starts its own ranks (bench.py: spawn_ranks).  A rank that exits non-zero must end the run:
+    the other ranks are terminated and the failing rank's exit code is the parent's, well inside the deadline -- not a hang
+    until the 50-minute limit, and not a zero exit with a missing JSON line."""
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, RL_BENCH_FAIL_RANK="1", RL_BENCH_HOLD_S="600")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert p.returncode == 7, (p.returncode, p.stdout[-500:], p.stderr[-500:])
+    assert took < 200, took              # rank 0 was holding for 600 s: it was terminated, not waited for
+    assert p.stdout.strip() == ""        # no line was printed

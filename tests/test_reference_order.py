@@ -233,9 +233,32 @@ def test_benchmarked_batch_sample_bitwise(rl, fits, rings):
     perm = rng.permutation(B)
     ctrl2, xy2, ns2, _, _ = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths[perm], i_start, arith=REF)
     np.testing.assert_array_equal(ctrl2, ctrl[perm]); np.testing.assert_array_equal(ns2, ns[perm])
-    fast = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)
+    fast = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, arith=rl.lib.ARITH_FAST)
     d = np.hypot(*(fast[1][sample] - xy[sample]).transpose(2, 0, 1)).max(axis=1)
     print(f"fast arithmetic: kernel ms {fast[4].kernel_ms:.3f}; fast vs reference-order on the sample [m]: median {np.median(d):.2e} max {d.max():.2e}")
+
+
+def test_the_default_arithmetic_is_the_reference_order_one(rl, fits, rings):
+    """Round 6: a context on which nothing was chosen (RL_ARITH_DEFAULT) runs the reference-order arithmetic wherever it exists
+    (degree-5 splines) -- the batched entry points return the oracle's bits without being asked -- and the fast arithmetic
+    where it does not (degree 3), instead of failing."""
+    ctx = rl.lib.Context.get(0)
+    assert ctx.lib.rl_ctx_get_arith(ctx.h) == rl.lib.ARITH_DEFAULT
+    t, cx, cy, k, length = spline(fits, "c100")
+    N, B = 300, 3
+    i_start = rl.batch.default_i_start(len(cx), k, 2, seed=4)
+    widths = widths_like_monza(rl, fits, rings, "c100", N, B, seed=11)
+    trk = rl.lib.Track(ctx, t, cx, cy, k, N)
+    ctrl, xy, ns, status, st = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start)     # no arith= anywhere
+    assert st.reserved[0] == REF
+    with orc.cr_variant():
+        octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, length, N, widths, i_start)
+    np.testing.assert_array_equal(ctrl, octrl); np.testing.assert_array_equal(xy, oxy); np.testing.assert_array_equal(ns, ons)
+    t3, cx3, cy3, k3, _ = spline(fits, "l10")     # degree 3: only the fast kernels exist; the DEFAULT follows, an explicit choice fails (below)
+    trk3 = rl.lib.Track(ctx, t3, cx3, cy3, k3, 200)
+    out3 = rl.ops.solve_batch_host(trk3, rl.lib.BOUNDS_WIDTHS, np.full((1, 200, 2), 5.0), np.array([3]))
+    assert out3[4].reserved[0] == rl.lib.ARITH_FAST and np.isfinite(out3[1]).all()
+    assert ctx.lib.rl_ctx_get_arith(ctx.h) == rl.lib.ARITH_DEFAULT
 
 
 def test_reference_order_refuses_what_it_does_not_cover(rl, fits, rings):
@@ -246,7 +269,7 @@ def test_reference_order_refuses_what_it_does_not_cover(rl, fits, rings):
     with ctx.arith(rl.lib.ARITH_BRANCH):          # the sliding-window driver: fast and reference-order arithmetic only
         with pytest.raises(rl.lib.RlError):
             rl.ops.mincurv_sweep_joint(trk, cx, cy, np.array([10]))
-    assert ctx.lib.rl_ctx_get_arith(ctx.h) == 0
+    assert ctx.lib.rl_ctx_get_arith(ctx.h) == rl.lib.ARITH_DEFAULT    # the scope restored "nothing chosen"
     t3, cx3, cy3, k3, _ = spline(fits, "l10")     # degree 3: the reference's wrap is written for k = 5
     trk3 = rl.lib.Track(ctx, t3, cx3, cy3, k3, 200)
     w = np.full((1, 200, 2), 5.0)
@@ -325,6 +348,49 @@ def test_numpy_raise_semantics_g12(rl):
     np.testing.assert_array_equal(ns2[0], pns)
     np.testing.assert_array_equal(ctrl2[0, :, 0], pcx); np.testing.assert_array_equal(ctrl2[0, :, 1], pcy)
     assert not np.array_equal(pns, ons)
+
+
+def test_simulate_true_equals_the_single_launch_g12(rl):
+    """The drop-in class with simulate=True (the reference's per-iteration simulator calls, optimizer.py:333-339) on the track
+    of fixture G12 -- samples of exactly zero curvature, so that from the end of outer iteration 0 on numpy's raise mode
+    decides which steps count and the table goes stale: the launches are prefixes of the one real run, hence the same bits
+    and counts as simulate=False and as the oracle (advisor, round 5: launch-by-launch continuation lost that state)."""
+    import types
+    from scipy import interpolate
+    from spline_trajectory_optimization_amd.models.trajectory import BSplineTrajectory, Trajectory
+    from spline_trajectory_optimization_amd.optimization.optimizer import TrajectoryOptimizer
+    g = golden("G12_numpy_raise_semantics.npz")
+    t, cx, cy, k, length = g["t"], g["cx"], g["cy"], int(g["k"]), float(g["length"])
+    N = 300
+    i_start = g["sweep_N300_i_start"]
+    spl = object.__new__(BSplineTrajectory)
+    spl._spl_x = interpolate.BSpline(t, cx.copy(), k); spl._spl_y = interpolate.BSpline(t, cy.copy(), k); spl._length = length
+    track = types.SimpleNamespace(left_s=None, right_s=None, left_r=g["ringL"], right_r=g["ringR"])
+    optm = object.__new__(TrajectoryOptimizer)
+    optm.track, optm.center_line, optm.vehicle, optm._trk_cache = track, spl, None, {}
+    calls = []
+    optm.sim = types.SimpleNamespace(run_simulation=lambda tab, enable_vis=False: (calls.append(tab.points[:, :2].copy()),
+                                                                                  types.SimpleNamespace(trajectory=tab))[1])
+    table = Trajectory(N)
+    ctx = rl.lib.Context.get(0)
+    for raise_at_start in (False, True):   # numpy's default state at the start / the reference's own test: simulated before it optimises
+        calls.clear()
+        ctx.set_numpy_raise(raise_at_start)
+        try:
+            a = optm.run_min_curvature_qp(spl, table, max_iter=len(i_start), i_start=i_start)
+            ns_a = optm.last_n_success.copy()
+            b = optm.run_min_curvature_qp(spl, table, max_iter=len(i_start), i_start=i_start, simulate=True)
+        finally:
+            ctx.set_numpy_raise(False)
+        np.testing.assert_array_equal(a._spl_x.c, b._spl_x.c); np.testing.assert_array_equal(a._spl_y.c, b._spl_y.c)
+        np.testing.assert_array_equal(ns_a, optm.last_n_success)
+        assert len(calls) == len(i_start) + 1 and not np.array_equal(calls[0], calls[-1])
+        with orc.cr_variant():
+            pcx, pcy, _, pns = orc.run_min_curvature_qp(t, cx, cy, k, length, N, g["ringL"], g["ringR"], i_start,
+                                                       numpy_raise=raise_at_start)
+            assert (orc.last_raised() > 0) or not raise_at_start
+        np.testing.assert_array_equal(b._spl_x.c, pcx); np.testing.assert_array_equal(b._spl_y.c, pcy)
+        np.testing.assert_array_equal(optm.last_n_success, pns)
 
 
 @pytest.mark.parametrize("tag,N,B,max_iter", [("c100", 200, 24, 2), ("c100", 500, 16, 2), ("c30", 333, 16, 1)])

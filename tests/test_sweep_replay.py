@@ -54,7 +54,11 @@ def rl():
         pass
     ns = NS()
     ns.lib, ns.ops, ns.batch = _lib, ops, batch
-    return ns
+    # this module pins the FAST arithmetic (its tolerances, dumps and replays are statements about it); the library's default --
+    # the reference-order arithmetic since round 6 -- is the subject of tests/test_reference_order.py
+    _lib.Context.get(0).set_arith(_lib.ARITH_FAST)
+    yield ns
+    _lib.Context.get(0).set_arith(_lib.ARITH_DEFAULT)
 
 
 def check_steps(rec, rep, n, label):
