@@ -1330,6 +1330,13 @@ static void spd_solve_dense(int n, const double* Lm, double* b) {
   }
 }
 
+/* Exit rule of the interior-point iterations of both global QPs -- the twin of csrc/rl_device.hpp: ipm_done, same constants (the
+ * measurements behind them are in its comment): the complementarity mu alone, below tol_mid for every linearisation before the
+ * last (1e-7 with one offset per control point, 1e-9 with both coordinates free), below 1e-10 for the last.  No residual clause:
+ * going on past the complementarity drives the residual UP with the conditioning and breaks down within a few iterations. */
+static const double kIpmTolOneOffset = 1e-7, kIpmTolTwoCoords = 1e-9;
+static int ipm_done(double tol_mid, int last_qp, double mu) { return mu < (last_qp ? 1e-10 : tol_mid); }
+
 int orc_global_mincurv(const double* t, int nt, const double* cx0, const double* cy0, int k, int N,
                        const double* w_left, const double* w_right, double margin, int n_outer,
                        double* out_cx, double* out_cy, double* out_xy, double* out_a, double* stats) {
@@ -1453,7 +1460,6 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
     }
     double qinf = 0.0;
     for (int j = 0; j < np_; ++j) qinf = fmax(qinf, fabs(qv[j]));
-    double res_prev = INFINITY;
     for (int it = 0; it < 80; ++it) {
       /* residuals */
       double mu = 0.0, rpmax = 0.0;
@@ -1473,15 +1479,8 @@ int orc_global_mincurv(const double* t, int nt, const double* cx0, const double*
       mu /= (double)(2 * N);
       double rdmax = 0.0;
       for (int j = 0; j < np_; ++j) rdmax = fmax(rdmax, fabs(rd[j]));
-      { /* all but the last linearisation are solved inexactly (complementarity 1e-5, residuals 1e-4): the next
-         * Gauss-Newton step moves the line by decimetres; same constants as csrc/rl_global.hpp kGLooseMu / kGLooseRes */
-        const int last_qp = outer + 1 >= n_outer;
-        const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : 1e-4;
-        /* ... or mu is converged and the residual, within 100 x its tolerance, has stopped falling (csrc/rl_global_xy.hpp) */
-        const int done = mu < (last_qp ? 1e-10 : 1e-5) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));
-        res_prev = res;
-        if (done) break;
-      }
+      (void)rdmax; (void)rpmax; (void)qinf;
+      if (ipm_done(kIpmTolOneOffset, outer + 1 >= n_outer, mu)) break;
       ++total_it;
       /* normal matrix */
       memcpy(Kq, P, (size_t)np_ * np_ * sizeof(double));
@@ -1698,7 +1697,6 @@ int orc_global_mincurv_xy(const double* t, int nt, const double* cx0, const doub
     }
     double qinf = 0.0;
     for (int j = 0; j < nz; ++j) qinf = fmax(qinf, fabs(qv[j]));
-    double res_prev = INFINITY;
     for (int it = 0; it < 80; ++it) {
       double mu = 0.0, rpmax = 0.0;
       for (int j = 0; j < nz; ++j) {
@@ -1718,21 +1716,8 @@ int orc_global_mincurv_xy(const double* t, int nt, const double* cx0, const doub
       mu /= (double)(2 * R);
       double rdmax = 0.0;
       for (int j = 0; j < nz; ++j) rdmax = fmax(rdmax, fabs(rd[j]));
-      {
-        /* Intermediate linearisations are solved inexactly, but TIGHTER than in orc_global_mincurv (complementarity 1e-7,
-         * residuals 1e-6 against 1e-5 / 1e-4): with both coordinates free the cost is nearly flat along the line and an
-         * under-converged iterate is a badly conditioned function of the data.  Measured here (Monza, N = 1998 / 2000 / 2300,
-         * widths changed by 1e-9 m, 3 and 6 linearisations): the result moves by up to 1e-2 m with 1e-5 / 1e-4, by at most
-         * 3e-7 m with 1e-7 / 1e-6 (same as with exact solves), for 101-104 instead of 86-88 iterations (exact: 110-112).
-         * Same constants as csrc/rl_global_xy.hpp kXYLooseMu / kXYLooseRes. */
-        /* converged -- or the complementarity is there and the residual has stopped falling within 100 x its tolerance
-         * (going on only drives mu down and the residual up with the normal matrix's conditioning: csrc/rl_global_xy.hpp) */
-        const int last_qp = outer + 1 >= n_outer;
-        const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : 1e-6;
-        const int done = mu < (last_qp ? 1e-10 : 1e-7) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));
-        res_prev = res;
-        if (done) break;
-      }
+      (void)rdmax; (void)rpmax; (void)qinf;
+      if (ipm_done(kIpmTolTwoCoords, outer + 1 >= n_outer, mu)) break;
       ++total_it;
       memcpy(Kq, P, (size_t)nz * nz * sizeof(double));
       for (int r = 0; r < R; ++r) {

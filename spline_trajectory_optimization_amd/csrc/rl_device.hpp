@@ -134,6 +134,27 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Exit rule of the interior-point iterations of the global QPs (k_global_qp, k_global_qp2, k_global_xy and their CPU twins,
+// oracle/mincurv_oracle.c: ipm_done), round 6: ONE test, on the complementarity mu alone -- below `tol_mid` for every
+// linearisation before the last, below 1e-10 for the last.
+//   * Round 5 left the intermediate linearisations at mu < 1e-5 (1e-7 with both coordinates free) plus residual and "the
+//     residual has stopped falling" clauses.  The iterate of an UNDER-CONVERGED interior-point method is an ill-conditioned
+//     function of the arithmetic (near the end of a QP the normal matrix has condition 1e12: the two implementations' steps
+//     differ in their fourth digit, and only further iterations correct that), so kernel and twin parted by up to 7e-4 m on
+//     2-3 % of a batch, and the residual clauses -- comparisons of two nearly equal numbers -- let them leave a QP up to five
+//     iterations apart.  Measured on the benchmarked batch (tools/global_full_batch_vs_twin.py, profiles/r06_*): a fixed
+//     iteration schedule instead of tolerances made it worse (60 of 1024 beyond 1e-6 m: the cause is the convergence level,
+//     not the exit flip); tol_mid = 1e-6 leaves 6 instances beyond 1e-6 m, 1e-7 none (largest 2.5e-7 m, 1024 of 1024 equal
+//     iteration counts) for the one-offset formulation; with both coordinates free -- the cost is nearly flat along the line --
+//     1e-7 / 1e-8 / 1e-9 leave 22 / 3 / 0 instances beyond 1e-6 m.
+//   * mu falls by one to two orders per iteration near the end, so a threshold on it is passed by a wide margin almost always
+//     (kernel and twin disagree on 0 resp. 4 of 1024 instances, by one iteration); going on PAST the complementarity drives
+//     the residual up with the conditioning and breaks down within two or three iterations (NaN seen), so nothing else is
+//     waited for.
+constexpr double kIpmTolOneOffset = 1e-7;   // one lateral offset per control point
+constexpr double kIpmTolTwoCoords = 1e-9;   // both coordinates free
+__device__ __forceinline__ bool ipm_done(double tol_mid, bool last_qp, double mu) { return mu < (last_qp ? 1e-10 : tol_mid); }
+
 // oracle/mincurv_oracle.c: closest_hit.  Returns the signed parameter s of the closest hit,
 // 0 when there is none (bound = the waypoint itself, trajectory.py:127).
 struct Hit {

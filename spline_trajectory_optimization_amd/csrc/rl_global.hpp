@@ -32,13 +32,7 @@
 
 namespace rl {
 
-// Interior-point tolerances of the linearisations BEFORE the last one (the last is solved to 1e-9 / 1e-10): complementarity
-// mu and, ten times looser, the scaled dual / primal residuals.  Measured in the CPU twin (Monza N = 2000, 24 instances):
-// 1e-5 takes 93 -> 73 interior-point iterations with the final sum kappa^2 unchanged to 1e-8 relative; looser still converges
-// (1e-4: 59 iterations, cost equal to 1e-7; 1e-3 stalls the Gauss-Newton iteration) but an under-converged iterate is a
-// badly conditioned function of the data: a 1e-9 m change of the widths then moves the result of single instances by up
-// to 1e-5 m (1e-4), against 2e-8 m (1e-5) and 5e-9 m (exact solves) -- and two implementations differ by that much.
-constexpr double kGLooseMu = 1e-5, kGLooseRes = 1e-4;
+// (the interior-point exit rule of all global-QP kernels: rl_device.hpp, ipm_done)
 
 constexpr int kGRows = 8;     // samples per chunk == per thread
 constexpr int kGRound = 11;   // span outputs staged per flush round
@@ -400,7 +394,6 @@ __global__ void __launch_bounds__(MAXB) k_global_qp(GlobalArgs a) {
         }
       }
     }
-    double res_prev = INFINITY;
     for (int it = 0; it < a.max_ipm; ++it) {
       // ---- residuals, complementarity, and the span sums of A'DA, A'e, A'(lu - ll)
       for (int j = tid; j < np; j += nt) {
@@ -471,13 +464,8 @@ __global__ void __launch_bounds__(MAXB) k_global_qp(GlobalArgs a) {
       }
       double d0 = 0.0, d1 = 0.0;
       reduce3(d0, rdmax, d1);
-      {   // inexact solves of all but the last linearisation (see k_global_qp2; twin: orc_global_mincurv)
-        const bool last_qp = outer + 1 >= a.n_outer;
-        const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : kGLooseRes;
-        const bool done = mu < (last_qp ? 1e-10 : kGLooseMu) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));   // (stagnation
-        res_prev = res;                                                                                      //  clause: k_global_qp2)
-        if (done) break;
-      }
+      (void)rdmax; (void)rpmax; (void)qinf;   // the residuals no longer decide anything (rl_device.hpp: ipm_done)
+      if (ipm_done(kIpmTolOneOffset, outer + 1 >= a.n_outer, mu)) break;
       ++total_it;
       // ---- factor, affine direction
       if (wave == 0) {

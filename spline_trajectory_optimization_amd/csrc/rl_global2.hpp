@@ -1081,7 +1081,6 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
       }
       __syncthreads();
       double *xc = xsA, *xn = xsB;
-      double res_prev = INFINITY;
       for (int it = 0; it < a.max_ipm; ++it) {
         // [I1]  rdP = P x + q
         for (int j = lane; j < np; j += kWave) {
@@ -1116,15 +1115,9 @@ __global__ void __launch_bounds__(kG2Block) k_global_qp2(GlobalArgs a) {
           for (int j = lane; j < np; j += kWave) rdmax = fmax(rdmax, fabs(rd[j]));
           rdmax = wave_max(rdmax);
           const double mu = mu_sum / (double)(2 * N);
-          // the linearisations before the last are solved INEXACTLY (complementarity 1e-5, residuals 1e-4): the next
-          // Gauss-Newton step moves the line by decimetres, so their last digits buy nothing (92.7 -> 73 interior-point
-          // iterations on the benchmarked batch, same final sum kappa^2; rl_global.hpp: kGLooseMu; twin: orc_global_mincurv)
-          const bool last_qp = outer + 1 >= a.n_outer;
-          // ... or the complementarity is there and the residual, within 100 x its tolerance, has stopped falling: going on only
-          // drives mu down and the residual up with the conditioning (found on k_global_xy, rl_global_xy.hpp; same rule in the twin)
-          const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : kGLooseRes;
-          conv = mu < (last_qp ? 1e-10 : kGLooseMu) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));
-          res_prev = res;
+          // the exit rule (rl_device.hpp: ipm_done): the complementarity alone, 1e-7 before the last linearisation, 1e-10 on it
+          (void)rdmax; (void)rpmax; (void)qinf;
+          conv = ipm_done(kIpmTolOneOffset, outer + 1 >= a.n_outer, mu);
           if (lane == 0) ctl[0] = conv ? 1.0 : 0.0;
         }
         double bx[G];

@@ -35,9 +35,8 @@ namespace rl {
 
 constexpr int kXYRows = 4;     // samples per thread
 constexpr int kXYMaxNz = 192;  // unknowns: three rows per lane in the solves
-// interior-point tolerances of the linearisations before the last: tighter than kGLooseMu / kGLooseRes -- with both coordinates free
-// an under-converged iterate is a badly conditioned function of the data (measurement in the comment of the CPU twin)
-constexpr double kXYLooseMu = 1e-7, kXYLooseRes = 1e-6;
+// (interior-point exit rule: rl_device.hpp, ipm_done with kIpmTolTwoCoords -- tighter than the one-offset kernels': with both
+// coordinates free the cost is nearly flat along the line and an under-converged iterate moves the result)
 
 struct GlobalXYArgs {
   TrackDev trk;
@@ -576,7 +575,6 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
     }
     }
     XY_STAMP(7)
-    double res_prev = INFINITY;
     for (int it = 0; it < a.max_ipm; ++it) {
       // ---- P x + q; the factorisation's storage cleared
       for (int u = tid; u < nz; u += NT) {
@@ -679,14 +677,10 @@ __global__ void __launch_bounds__(NT) k_global_xy(GlobalXYArgs a) {
         reduce4(d0, d1, rdmax, mn);
       }
       {
-        // converged -- or the complementarity is there and the residual has stopped falling within 100 x its tolerance: going on
-        // would only drive mu down (1e-156 was seen) and the residual UP with the normal matrix's conditioning.  Measured on
-        // instance 133 of the benchmarked batch: residual 1.009e-9 against 1e-9 at mu = 3e-12, then 78 more iterations to the
-        // cap and a line 1.6e-4 m from the twin's, which had stopped at 0.99e-9.  (Same rule in the twin.)
-        const bool last_qp = outer + 1 >= a.n_outer;
-        const double res = fmax(rdmax / (1.0 + qinf), rpmax), tol_res = last_qp ? 1e-9 : kXYLooseRes;
-        const bool done = mu < (last_qp ? 1e-10 : kXYLooseMu) && (res < tol_res || (res < 100.0 * tol_res && res >= res_prev));
-        res_prev = res;
+        // the exit rule (rl_device.hpp: ipm_done): the complementarity alone, 1e-9 before the last linearisation, 1e-10 on it (going
+        // on past it only drives mu down -- 1e-156 was seen -- and the residual UP with the normal matrix's conditioning)
+        (void)rdmax; (void)rpmax; (void)qinf;
+        const bool done = ipm_done(kIpmTolTwoCoords, outer + 1 >= a.n_outer, mu);
         if (done) break;
       }
       ++total_it;

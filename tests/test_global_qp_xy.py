@@ -211,8 +211,9 @@ def test_kernel_vs_twin_other_shapes(rl, shape):
     print(f"[global xy {shape}: k={k} n_p={n_p} N={N}] |dz| {dz:.2e} m |dxy| {dxy:.2e} m  ipm {int(st[0, 0])}/{int(ost[0])}  "
           f"k2 {st[0, 1]:.5f}->{st[0, 2]:.5f}  viol {st[0, 3]:.1e}  block {rs.block_threads} lds {rs.lds_bytes}  {rs.kernel_ms:.2f} ms")
     assert np.isfinite(xy).all() and st[0, 3] <= 1e-9
-    assert dxy <= 2e-3 and st[0, 2] == pytest.approx(ost[2], rel=1e-6) and abs(int(st[0, 0]) - int(ost[0])) <= 3
-    assert dxy <= TOL or abs(int(st[0, 0]) - int(ost[0])) >= 1      # beyond the tolerance only with an iteration count apart
+    # round 6: exit on the complementarity alone, tight before the last linearisation too (rl_device.hpp: ipm_done): hard bounds
+    # again -- the line within 2e-6 m, the iteration count at most one apart (the whole batch: 1020 of 1024 equal, none further)
+    assert dxy <= TOL and st[0, 2] == pytest.approx(ost[2], rel=1e-6) and abs(int(st[0, 0]) - int(ost[0])) <= 1
 
 
 @pytest.mark.gpu
@@ -248,13 +249,13 @@ def test_batch_properties_full_size(rl, fits):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dof", [1, 2])
-def test_batch_sample_against_the_twin_two_tier(rl, fits, dof):
-    """64 instances of the benchmarked batch (every 16th) against the twins, both formulations.  Kernel and twin are two
-    implementations of an iteration with tolerance-based exits from INEXACT intermediate QPs: on a few per cent of the instances one
-    of them leaves an intermediate QP one iteration earlier, the lines then differ by up to ~1e-3 m at equal cost (9 digits) and
-    come together again as the Gauss-Newton iteration converges (tools/global_outlier_trace.py; the whole batch:
-    profiles/r05_global_full_batch_vs_twin.json -- 992 / 1002 of 1024 within 1e-6 m, largest 6.8e-4 / 1.4e-4 m).  So: every
-    instance within 2e-3 m with the cost equal to 1e-7 and the iteration count within 5; at least 90 % within 2e-6 m."""
+def test_batch_sample_against_the_twin(rl, fits, dof):
+    """64 instances of the benchmarked batch (every 16th) against the twins, both formulations: EVERY instance within 1e-6 m at
+    the twin's cost, with the twin's interior-point iteration count (one offset per control point) or at most one iteration
+    from it (both coordinates free).  Round 5 accepted 2e-3 m here: its intermediate linearisations stopped at complementarity
+    1e-5 / 1e-7, where the iterate is an ill-conditioned function of the arithmetic.  Round 6 (csrc/rl_device.hpp: ipm_done):
+    1e-7 / 1e-9, on the complementarity alone; the whole batch: tools/global_full_batch_vs_twin.py,
+    profiles/r06_global_full_batch_vs_twin.json -- 0 of 1024 beyond 1e-6 m in either formulation."""
     t, cx, cy, k, u, wl, wr = monza_widths(fits, "c100", 2000)
     W = rl.batch.width_batch(wl, wr, 1024, seed=1234)[::16]
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, 2000)
@@ -268,9 +269,9 @@ def test_batch_sample_against_the_twin_two_tier(rl, fits, dof):
         dev.append(np.abs(xy[b] - r[2]).max()); dits.append(abs(int(st[b, 0]) - int(r[4][0])))
         assert st[b, 2] == pytest.approx(r[4][2], rel=1e-7)
     dev = np.array(dev)
-    print(f"[global dof={dof}, 64 instances vs twin] within 2e-6 m: {(dev <= TOL).sum()}, largest {dev.max():.2e} m, median {np.median(dev):.2e} m, "
+    print(f"[global dof={dof}, 64 instances vs twin] largest {dev.max():.2e} m, median {np.median(dev):.2e} m, "
           f"largest iteration-count difference {max(dits)}")
-    assert dev.max() <= 2e-3 and max(dits) <= 5 and (dev <= TOL).mean() >= 0.9
+    assert dev.max() <= 1e-6 and max(dits) <= (0 if dof == 1 else 1)
 
 
 @pytest.mark.gpu
