@@ -59,7 +59,12 @@ def per_kernel(pattern):
     if not dur:
         return None
     avg = {k: sum(v) / len(v) for k, v in agg.items()}
-    out = {"kernel": pattern, "launches_profiled": len(dur), "avg_ms": sum(dur) / len(dur), "counters_per_launch": avg}
+    srt = sorted(dur)
+    # min and median next to the average: a cold first launch (and the profiler's own overhead on it) otherwise puts the
+    # profile's figure above the driver's ms_per_step
+    out = {"kernel": pattern, "launches_profiled": len(dur), "avg_ms": sum(dur) / len(dur), "min_ms": srt[0],
+           "median_ms": srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]),
+           "counters_per_launch": avg}
     if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
         out["hbm_bytes_raw"] = (avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
         out["hbm_bytes_fetch_x2"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
