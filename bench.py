@@ -500,6 +500,16 @@ def qss_leg(B, with_cpu):
             if name == "batch":
                 out, its_batch = w.cpu().numpy(), its
         leg["timing"] = "median of three calls after a warm-up at the same size, HIP events on the launch stream (device resident)"
+        # passes per trajectory: the dataflow kernel's pass counter of this very workload (one Monza table, N = 2000: 3 790 passes, 3 829
+        # batches of <= 256 agents, 280 k examinations for 213 k steps -- RL_QSS_DEBUG counters of the diagnostic build, DESIGN.md 3c;
+        # the kernel has not changed since) against the dependency analysis's critical path (3 889 steps; 1 446 with shared passes)
+        if N == 2000 and "single" in leg:
+            leg["single"]["passes_per_trajectory"] = 3790
+            leg["single"]["us_per_pass"] = leg["single"]["ms"] * 1e3 / 3790
+            leg["single"]["passes_source"] = ("counter of the diagnostic build on this workload (DESIGN.md 3c), not read in this run; critical "
+                                              "path of the true dependencies: 3 889 passes (1 446 if a step shares a pass with the earlier "
+                                              "readers of the sample it writes): the pass COUNT is at the model's, the 7-8 us a pass costs "
+                                              "(about 2 000 instructions on the slowest lane of a 256-agent batch, four barriers) is what is off")
         cpath = os.path.join(ROOT, "profiles", "qss_counters_latest.json")
         if os.path.exists(cpath):       # counters of the committed rocprofv3 passes (tools/profile_qss.sh): not measured in this run
             try:

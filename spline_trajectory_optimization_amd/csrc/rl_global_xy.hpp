@@ -33,7 +33,10 @@
 
 namespace rl {
 
-constexpr int kXYRows = 4;     // samples per thread
+#ifndef RL_XY_ROWS
+#define RL_XY_ROWS 4
+#endif
+constexpr int kXYRows = RL_XY_ROWS;     // samples per thread
 constexpr int kXYMaxNz = 192;  // unknowns: three rows per lane in the solves
 // (interior-point exit rule: rl_device.hpp, ipm_done with kIpmTolTwoCoords -- tighter than the one-offset kernels': with both
 // coordinates free the cost is nearly flat along the line and an under-converged iterate moves the result)
