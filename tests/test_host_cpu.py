@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = built.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rl_version() == 102   # include/rl_mincurv.h: RL_VERSION
+    assert lib.rl_version() == 103   # include/rl_mincurv.h: RL_VERSION
 
 
 def test_no_cpu_fallback(built):
