@@ -90,7 +90,7 @@ def spawn_ranks(args):
 SWEEP_LIMITER = ("VALU instruction issue: across the arithmetic modes and builds of rounds 5-6 the kernel time is 2.9 ps per executed "
                  "VALU wave-instruction (1024 SIMDs, ~58 % of their cycles issuing, the rest the stalls of the steps' dependent chains "
                  "at 4 workgroups per CU); the solver state is on chip: the HBM roofline is the one north_star designates, the kernel "
-                 "is not HBM bound (DESIGN.md section 3)")
+                 "is not HBM bound (DESIGN.md section 5)")
 
 
 def profile_block(kernel):
@@ -240,7 +240,7 @@ def reference_order_leg(g, args, torch, search, fast_kernel_ms, fast_xy, po, ref
         whole["branch"]["kernel_ms"] = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evb]))
         whole["branch"]["what"] = ("RL_ARITH_BRANCH: positions, ring crossings, bound points and rows in the reference's order; normals from a "
                                    "reciprocal square root, cost sums from the fast tables in a tree")
-        whole["reading"] = ("the reference's formulation is chaotic in the last bits (DESIGN.md 5): every operation that rounds differently moves a few "
+        whole["reading"] = ("the reference's formulation is chaotic in the last bits (DESIGN_HISTORY.md 5): every operation that rounds differently moves a few "
                             "per cent of the instances to another branch; only the reference-order arithmetic stays on the oracle's")
         leg["whole_batch_vs_reference_order"] = whole
     except Exception as e:
@@ -306,7 +306,7 @@ def global_qp_leg(trk, d_widths, g, args, torch, with_cpu):
                         "traffic_source": prof.get("source") if prof else None, "traffic_measured_in_run": False,
                         "kernel": "k_global_qp2", "kernel_ms": ms,
                         "algorithmic_bytes_per_launch": BYTES_PER_SOLVE * B,
-                        "actual_limiter": "FP64 VALU issue of the factorising wave + barriers (DESIGN.md 3b)",
+                        "actual_limiter": "FP64 VALU issue of the factorising wave + barriers (DESIGN_HISTORY.md 3b)",
                         "valu": valu_block(prof, ms)}}
     if with_cpu:
         from oracle import oracle as orc
@@ -355,7 +355,7 @@ def global_qp_xy_block(trk, d_widths, g, args, torch, with_cpu):
            "block_threads": int(out["rl_stats"].block_threads), "lds_bytes_per_workgroup": int(out["rl_stats"].lds_bytes),
            "kernel": "k_global_xy",
            "actual_limiter": "register file: the interior-point state of 4 samples x 2 rows per thread (96 registers) plus the row "
-                             "passes exceed 256 VGPRs -- 139 spilled registers, 6 GB of scratch writes per launch (DESIGN.md 3b); then the one factorising wave"}
+                             "passes exceed 256 VGPRs -- 139 spilled registers, 6 GB of scratch writes per launch (DESIGN_HISTORY.md 3b); then the one factorising wave"}
     prof = profile_block("k_global_xy")
     if prof:   # committed rocprofv3 counters of the same kernel (profiles/counters_latest.json), not measured in this run
         c = prof["counters_per_launch"]
@@ -382,7 +382,7 @@ def global_qp_xy_block(trk, d_widths, g, args, torch, with_cpu):
     return blk
 
 
-MFMA_F64_PEAK_GFLOPS = 78600.0  # v_mfma_f64_16x16x4_f64 runs at the FP64 vector rate on gfx950 (64 cycles per 2048 flops per SIMD)
+MFMA_F64_PEAK_GFLOPS = 78600.0  # v_mfma_f64_16x16x4_f64 runs at the FP64 vector rate on gfx950 (DESIGN_HISTORY.md 3d: 64 cycles per 2048 flops per SIMD)
 
 
 def mintime_leg(B, with_cpu):
@@ -423,7 +423,7 @@ def mintime_leg(B, with_cpu):
                                       if chain_us else "")
                                    + f" -> >= {leg['iterations_mean']:.0f} x that per solve: the floor under wall_s for small batches",
                 "actual_limiter": "FP64 VALU issue of the derivative kernels (transcendental / division sequences of the tyre model) "
-                                  "and the latency of the node-by-node elimination (DESIGN.md 3d)"}
+                                  "and the latency of the node-by-node elimination (DESIGN_HISTORY.md 3d)"}
     except Exception as e:
         leg["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:
@@ -464,7 +464,7 @@ def qss_leg(B, with_cpu):
     """Fourth leg: Simulator.run_simulation on B Monza tables of N = 2000 whose turn radii are scaled
     by 0.9 ... 1.1 per instance (different profiles and iteration counts), device resident (rl_qss_sim_dev on torch's stream),
     timed with events around one call after a warm-up; and one table alone.  The kernel is latency bound (a dependent chain
-    of front steps), so the leg reports times and rates, not a roofline.  cpu_baseline / parity: the C oracle's
+    of front steps, DESIGN_HISTORY.md 3c), so the leg reports times and rates, not a roofline.  cpu_baseline / parity: the C oracle's
     list-order loop on the first instances, one core."""
     try:
         import torch
@@ -501,12 +501,12 @@ def qss_leg(B, with_cpu):
                 out, its_batch = w.cpu().numpy(), its
         leg["timing"] = "median of three calls after a warm-up at the same size, HIP events on the launch stream (device resident)"
         # passes per trajectory: the dataflow kernel's pass counter of this very workload (one Monza table, N = 2000: 3 790 passes, 3 829
-        # batches of <= 256 agents, 280 k examinations for 213 k steps -- RL_QSS_DEBUG counters of the diagnostic build, DESIGN.md 3c;
+        # batches of <= 256 agents, 280 k examinations for 213 k steps -- RL_QSS_DEBUG counters of the diagnostic build, DESIGN_HISTORY.md 3c;
         # the kernel has not changed since) against the dependency analysis's critical path (3 889 steps; 1 446 with shared passes)
         if N == 2000 and "single" in leg:
             leg["single"]["passes_per_trajectory"] = 3790
             leg["single"]["us_per_pass"] = leg["single"]["ms"] * 1e3 / 3790
-            leg["single"]["passes_source"] = ("counter of the diagnostic build on this workload (DESIGN.md 3c), not read in this run; critical "
+            leg["single"]["passes_source"] = ("counter of the diagnostic build on this workload (DESIGN_HISTORY.md 3c), not read in this run; critical "
                                               "path of the true dependencies: 3 889 passes (1 446 if a step shares a pass with the earlier "
                                               "readers of the sample it writes): the pass COUNT is at the model's, the 7-8 us a pass costs "
                                               "(about 2 000 instructions on the slowest lane of a 256-agent batch, four barriers) is what is off")
@@ -522,7 +522,7 @@ def qss_leg(B, with_cpu):
                     "valu_busy_share_of_wave_cycles": 4.0 * row["SQ_ACTIVE_INST_VALU"] / row["SQ_WAVE_CYCLES"],
                     "lds_bank_conflict_share_of_lds_cycles": row["SQ_LDS_BANK_CONFLICT"] / row["SQ_LDS_IDX_ACTIVE"],
                     "wave_instructions_per_trajectory": {k_: row["per_instance"][k_] for k_ in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")},
-                    "bound": "latency of a dependent chain of front steps (DESIGN.md 3c): no bandwidth or flop roofline applies; the "
+                    "bound": "latency of a dependent chain of front steps (DESIGN_HISTORY.md 3c): no bandwidth or flop roofline applies; the "
                              "counters say how much of a wave's time is waiting",
                     "source": cj.get("source_file", "profiles/qss_counters_latest.json"), "measured_in_run": False}
             except Exception as e:

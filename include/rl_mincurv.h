@@ -66,7 +66,7 @@ enum { RL_SEARCH_BRUTE = 0, RL_SEARCH_CULLED = 1, RL_SEARCH_WINDOWED = 2 };
  * (since round 6; until then the fast one); a chosen arithmetic is taken literally and fails with RL_ERR_UNSUPPORTED where it
  * does not exist.  rl_stats.reserved[0] names the arithmetic a call ran in.
  *   RL_ARITH_FAST       fma throughout, normal from a reciprocal square root, tree sums -- a legal rounding of the
- *                       reference's arithmetic, within the nearest-branch rule of DESIGN.md section 5;
+ *                       reference's arithmetic, within the nearest-branch rule of DESIGN_HISTORY.md section 5;
  *   RL_ARITH_REFERENCE  the reference's operations in the reference's order (numpy / scipy: unfused de Boor
  *                       recurrences and sums, splder derivative splines in the cost, sequential cost sums, unfused
  *                       cross products, yaw = atan2 and the normals cos / sin(yaw +- pi/2) CORRECTLY ROUNDED): returns

@@ -170,7 +170,7 @@ constexpr int kNoEdge = 0x7fffffff;
 // contraction of a*b - c*d differs between call sites.
 // ST (the reference-order mode, RL_ARITH_REFERENCE): two rounded products and a subtraction, like numpy and like
 // oracle/mincurv_oracle.c: closest_hit -- with one product exact (fma) a crossing through a sample that sits ON a ring
-// leaves another residual than the reference's.
+// leaves another residual than the reference's (DESIGN_HISTORY.md section 5).
 __device__ __forceinline__ double cross_unfused(double a, double b, double c, double d) {
 #pragma clang fp contract(off)
   return a * b - c * d;
@@ -336,7 +336,7 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
 // the hints.  Measured on the benchmarked batch (same box, interleaved, bit-identical results; tools/sweep_variant.py):
 // direct loads 9.66-9.88 ms, staged 9.48-9.75 ms (-1.5 %), vector-memory read instructions per launch 2.04e8 -> 0.96e8.
 // Requesting the stretches at the START of a step (before the cost pass, so that the refresh waits for no vertex at all)
-// was 2 % SLOWER than direct loads (9.88-10.02 ms): the step is not waiting for these loads.
+// was 2 % SLOWER than direct loads (9.88-10.02 ms): the step is not waiting for these loads (DESIGN_HISTORY.md section 3).
 constexpr int kStage = 96;
 constexpr int kStageBatch = 4;   // LDS reads in flight per lane (the latency of an LDS read is a sixth of an L2 round trip)
 static_assert(kStage >= kWinEdges + 1 + 64 && kStage <= 104, "a stretch holds the windows of 64 consecutive chunk starts; two DMA instructions fill it");

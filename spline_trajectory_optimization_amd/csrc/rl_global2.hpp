@@ -205,7 +205,7 @@ __device__ __forceinline__ int fold_inv(int p, int np) { return (p & 1) ? np - 1
 //              one FP64 VALU / LDS instruction per ~8 cycles whatever it depends on (timing builds without the Newton steps
 //              of 1/sqrt, or without any cross-lane traffic at all, are 6 % / 17 % faster only), so the linear algebra of an
 //              instance costs (instructions) x 8 cycles on 1/8 of the CU's issue slots while the row waves wait.  What would
-//              change that is a second INSTANCE in the workgroup whose row passes fill those slots.
+//              change that is a second INSTANCE in the workgroup whose row passes fill those slots (DESIGN_HISTORY.md section 9).
 //   ordering   P M P' = L D L' with P = (top columns, bottom columns, middle): an ordinary symmetric permutation, so
 //              the factorisation is as stable as the one-front one; rounding differs (another elimination order).
 //   storage    as FoldBand: below the pivot L[r][c]; above it the mirrored entry times 1/d_c for eliminated columns,

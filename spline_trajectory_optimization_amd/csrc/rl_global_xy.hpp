@@ -174,7 +174,7 @@ __device__ __forceinline__ void fband_factor(double* LT, double* dinv, int nz, i
 // CYCLIC order.  Per column: one readlane pair, and per row group one subtract, one unsigned minimum (rows outside the
 // band land on the column's zero), one LDS read, one fma.  The factor's entries of the NEXT column are read while the current
 // one is applied: the addresses do not depend on the solution, and a step that waits for its own LDS read costs 185 cycles
-// instead of ~60 (measured: 45 k -> see DESIGN.md 3b cycles per solve).
+// instead of ~60 (measured: 45 k -> see DESIGN_HISTORY.md 3b cycles per solve).
 template <int HB, int NG>
 __device__ __forceinline__ void fband_solve(const double* LT, const double* dinv, int nz, int lane, const double* rhs, double* out) {
   constexpr int CW = HB + 2;

@@ -48,11 +48,11 @@ __global__ void k_build_tables(const double* __restrict__ t, int nt, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// REFERENCE-ORDER ARITHMETIC (RL_ARITH_REFERENCE).  The fast kernels evaluate the curve with
+// REFERENCE-ORDER ARITHMETIC (RL_ARITH_REFERENCE; DESIGN_HISTORY.md section 5b).  The fast kernels evaluate the curve with
 // fma from tables that were themselves built with fma, take the normal from a reciprocal square root and add the cost
 // sums in a tree: every one of these is a legal rounding of the reference's arithmetic, but not the reference's.  On
 // ill-conditioned instances that is enough to end on another of the discrete lines the reference's own formulation
-// allows.  The reference-order mode restates, operation by operation and in numpy's order, what
+// allows (DESIGN_HISTORY.md section 5).  The reference-order mode restates, operation by operation and in numpy's order, what
 // the reference computes -- which is what oracle/mincurv_oracle.c restates too, so the two can be compared bit for bit:
 //   * basis values by scipy's de Boor recurrences, unfused (the strict table set below);
 //   * x, y, x', y' as sequential unfused sums  s += c[l-k+a] * B_a(u)  (BSpline.__call__);
@@ -672,7 +672,7 @@ constexpr int kSweepDumpHead = 16;
 // ring crossings, bound points and rows stay in the reference's order (unfused, from the strict tables, bound points stored);
 // the normal comes from the reciprocal square root again (its last bit moves a bound point only across a rounding boundary),
 // the cost from the fast tables with tree sums (the unclamped optimum -g/H then differs from the reference's in its last bits,
-// as numpy's own matrix products do from the oracle's loop).  Not the oracle's bits -- the oracle's BRANCH.
+// as numpy's own matrix products do from the oracle's loop).  Not the oracle's bits -- the oracle's BRANCH (DESIGN_HISTORY.md 5b).
 template <int K, int BLOCK, bool RINGS_LDS, bool JOINT = false, bool DUMP = false, bool SIGMA_LDS = RINGS_LDS, bool STRICT = false,
           bool RAISE = false, bool LITE = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS && !JOINT)) ? 4 : 1) void k_sweep(SweepArgs a) {

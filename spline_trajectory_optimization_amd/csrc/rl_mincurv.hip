@@ -301,7 +301,7 @@ SweepPlan plan_sweep(const rl_ctx* ctx, int n, int N, int nL, int nR, int B, boo
   //   all in LDS      : lowest latency per step, but ~120 KB at N = 2000 -> one workgroup per CU;
   //   all in global   : ~31 KB of LDS -> four workgroups per CU (VGPR-limited), state served by L1/L2;
   //   crossings in LDS, rings in global (RL_FORCE_RESIDENCY=2 only): ~63 KB -> two workgroups per CU, no
-  //                     global writes inside the sweep (measured slower than all-global).
+  //                     global writes inside the sweep (measured slower than all-global; DESIGN_HISTORY.md section 6).
   // The kernel is FP64-issue / latency bound, so once a batch offers more than ~2 workgroups per
   // CU the occupancy wins (measured: 12.5 ms vs 20.2 ms for 1024 instances, N = 2000).
   // RL_FORCE_GLOBAL_RINGS=0/1 and RL_FORCE_RESIDENCY=0/1/2 override (tests cover the variants).
@@ -1312,7 +1312,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
   // tables) is re-run by the list-order kernel right behind it, which returns at once for every other instance.
   // Which kernel: the dataflow kernel finishes an instance 2 - 4.5 times sooner but its tables fill the LDS (one instance per CU at
   // N = 2000, three at N = 500), the list-order kernel holds four and more per CU.  Compare the number of ROUNDS the batch
-  // takes on the chip (measured); RL_QSS_DF=1 / 0 forces one or the other (tests run both).
+  // takes on the chip (measured, DESIGN_HISTORY.md 3c); RL_QSS_DF=1 / 0 forces one or the other (tests run both).
   bool use_df = rl::df_supported(N, acc_m, dcc_m, (size_t)ctx->max_lds);
   if (use_df) {
     const long long per_cu_df = (long long)((size_t)ctx->max_lds / rl::df_layout(N, acc_m, dcc_m).bytes);
@@ -1321,7 +1321,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     const long long cus = ctx->num_cu > 0 ? ctx->num_cu : 1;
     const long long rounds_df = (B + per_cu_df * cus - 1) / (per_cu_df * cus), rounds_list = (B + per_cu_list * cus - 1) / (per_cu_list * cus);
     // a round of the dataflow kernel takes from 1/5 (N = 2000: 29 against 168 ms) to 1/2 (N = 500: 4.4 against 9.3 ms) of a
-    // list-order round: the ratio the comparison allows grows with N between those two measurements
+    // list-order round (DESIGN_HISTORY.md 3c): the ratio the comparison allows grows with N between those two measurements
     const double ratio = N <= 500 ? 2.0 : (N >= 2000 ? 5.0 : 2.0 + 3.0 * (double)(N - 500) / 1500.0);
     use_df = (double)rounds_df <= ratio * (double)rounds_list;
   }
@@ -1334,7 +1334,7 @@ int rl_qss_sim_dev(rl_ctx* ctx, double* points, int B, int N, const double* acc_
     if (const char* dbg = getenv("RL_QSS_DEBUG")) if (dbg[0] == '1') { RL_HIP(hipMalloc(&ddbg, (size_t)B * 12 * sizeof(int))); a.dbg = ddbg; }
 #endif
     // waves of the (one) workgroup an instance's tables leave room for: four is the fastest at every size measured
-    // (DESIGN.md 3c); one and two exist for the tests (rl_ctx_set_option "qss_df_waves")
+    // (DESIGN_HISTORY.md 3c); one and two exist for the tests (rl_ctx_set_option "qss_df_waves")
     if (ctx->qss_df_waves == 1) {
       RL_HIP(grant_dyn_lds(ctx, reinterpret_cast<const void*>(rl::k_qss_dfw<1>), lds_df));
       hipLaunchKernelGGL(rl::k_qss_dfw<1>, dim3(B), dim3(64), lds_df, ctx->stream, a);

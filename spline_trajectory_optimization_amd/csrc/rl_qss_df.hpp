@@ -379,7 +379,7 @@ __device__ __forceinline__ DfStep dfw_step(const DfStepCtx& C, int side, int li,
 // compare-and-swap after its link is written, so that a wake-up by another wave that empties the same list sees it complete
 // or not at all; every thread derives the iteration window from the same counters, so nothing is broadcast.
 // (The first version, one wave per instance with these counters in wave-uniform registers, took 44 ms per N = 2000
-// trajectory against 29 ms: git history)
+// trajectory against 29 ms: git history, DESIGN_HISTORY.md 3c.)
 enum { DFS_Q2N = 0, DFS_Q2NE, DFS_NWIN, DFS_ERR, DFS_BAIL, DFS_FREE, DFS_NSPQ, DFS_GMINE, DFS_GMINX, DFS_GMIN, DFS_CHG, DFS_NE, DFS_NX, DFS_MAXG,
        DFS_QN, DFS_QNE, DFS_NU, DFS_DEXAM, DFS_DSTEP, DFS_COUNT };
 static_assert(DFS_COUNT <= 32, "scalars");

@@ -23,7 +23,7 @@ reference has no counterpart for.
 
 Deviations from the reference, all in one place:
   * solver: IPOPT is not part of the reference tree nor of this image; the solve is the build's own interior-point
-    SQP-type method on the GPU.  Its `tol` is an ABSOLUTE bound on the KKT residuals in the reference's
+    SQP-type method on the GPU (DESIGN_HISTORY.md 3d).  Its `tol` is an ABSOLUTE bound on the KKT residuals in the reference's
     scaling, whereas IPOPT's `tol` (yaml :8, 0.1) bounds its SCALED NLP error (residuals divided by multiplier-dependent
     factors s_d, s_c >= 1, and only reached after the barrier parameter has come down with it) -- handing 0.1 straight
     through stopped seconds of lap time short of the optimum while reporting success (round-3 advisor finding).  The

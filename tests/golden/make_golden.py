@@ -621,7 +621,7 @@ def main():
                 return {"x": x.reshape(-1, 1)}
             return solve
     if want("G9"):
-        # The sliding-window driver is chaotic in the rounding (DESIGN.md "Conditioning"): of 40 (N, seed,
+        # The sliding-window driver is chaotic in the rounding (DESIGN_HISTORY.md "Conditioning"): of 40 (N, seed,
         # max_iter) combinations tried, the strict oracle reproduces the reference's run to <= 2.5e-8 m with
         # identical window counts on 23 and ends metres away on the rest.  The cases below are five of the
         # reproducible ones (they pin the driver logic: window order, wrap, skip semantics, the simulator call

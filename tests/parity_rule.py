@@ -5,7 +5,7 @@ on z it implies divides the ~1e-13 m rounding noise of O(1e3) m coordinates by b
 the first samples inside a basis function's support.  Whether such a row binds -- and whether a QP is
 feasible at all (optimizer.py:291-293) -- is decided by the last bits of the sampled positions and bound
 points, so the reference's OWN arithmetic does not define the result of an instance to 1e-4 m unless
-those bits happen not to matter (DESIGN.md "Conditioning").  What the reference's arithmetic does define
+those bits happen not to matter (DESIGN_HISTORY.md "Conditioning").  What the reference's arithmetic does define
 is a small set of BRANCHES: the lines reached by the legitimate roundings of the same operations.
 
 How the branches are enumerated: RE-ROUNDINGS of the oracle.  Besides the strict build, the same oracle

@@ -9,7 +9,7 @@ line must be within 1e-4 m of the strict oracle OR of one of the lines the oracl
 seeded +-1 ulp re-roundings / its FMA-contracted build.  No percentile, no multiple of a spread.  Why branches
 exist: the REFERENCE forms each constraint row as min(L,R) - (p - b*z_old) (optimizer.py:236-248) and the implied
 bound on z divides the ~1e-13 m rounding noise of the O(1e3) m coordinates by b, which is ~1e-10 for samples at the
-edge of a basis function's support ("Conditioning").  That is the FAST arithmetic (RL_ARITH_FAST); the
+edge of a basis function's support (DESIGN_HISTORY.md, "Conditioning").  That is the FAST arithmetic (RL_ARITH_FAST); the
 reference-order arithmetic (RL_ARITH_REFERENCE) is held to the oracle bit for bit in tests/test_reference_order.py.
 The fast kernel's per-step logic is pinned independently of that noise by
 tests/test_sweep_replay.py (teacher-forced replay of every step against the oracle)."""
@@ -249,7 +249,7 @@ def test_benchmarked_configuration_vs_reference_run(rl, fits, rings):
     the real Monza rings, instances 0 and 3 of bench.py's width-perturbed batch in bench.py's sweep order) against one
     launch of the HIP sweep kernel.  NEAREST-BRANCH rule, enumerated per case (G7B_EXPECTED): three cases must be within
     1e-4 m (north_star) of the REFERENCE's run; the two on which the reference's arithmetic branches under +-1 ulp
-    re-roundings must be within 1e-4 m of the strict oracle or of one of its <= 24 + 1 re-roundings --
+    re-roundings (DESIGN_HISTORY.md section 5) must be within 1e-4 m of the strict oracle or of one of its <= 24 + 1 re-roundings --
     no multiple of a spread is accepted."""
     g = golden("G7b_benchmarked_config.npz")
     t, cx, cy, k, length = spline(fits, "c100")
@@ -800,7 +800,7 @@ def test_mixed_batch_monza_and_oval(rl, fits, rings):
 JOINT_ROBUST_CASES = [(200, [29]), (200, [35]), (200, [10]), (200, [47]), (200, [41]), (300, [5]), (300, [56]), (400, [54]),
                       (400, [57]), (1000, [3, 30]), (2000, [2]), (2000, [57])]
 # CHAOTIC = the oracle itself moves by 10-60 m under the same re-roundings (a window's feasibility is decided by the last
-# bit of a bound point): no end-to-end statement exists for these -- not for the oracle against the
+# bit of a bound point, DESIGN_HISTORY.md section 5): no end-to-end statement exists for these -- not for the oracle against the
 # reference's run either -- and none is asserted; what pins the kernel on them is the teacher-forced replay of EVERY window
 # (test_joint_windows_teacher_forced) and the re-solved window QPs (test_joint_window_qps_replayed).
 JOINT_CHAOTIC_CASES = [(200, [28]), (400, [15]), (500, [25]), (1000, [17]), (2000, [24]), (300, [3]),

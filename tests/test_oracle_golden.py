@@ -237,7 +237,7 @@ def test_g7d_benchmarked_batch_sample(fits, rings):
     """Fixture G7d (round 5): the reference's own loop for instances 1, 2, 4, 5, 6, 7 of bench.py's batch -- with G7b's 0 and 3
     the whole sample bench.py lays beside the oracle.  The oracle reproduces all six lines to <= 1.8e-6 m with the reference's
     success counts in every pass but the last, where on two of the six one QP is decided the other way (numpy's matrix products
-    sum in another order than the oracle's loop: the control point then differs in its last bits)."""
+    sum in another order than the oracle's loop: the control point then differs in its last bits, DESIGN_HISTORY.md section 5)."""
     _check_reference_runs(golden("G7d_benchmarked_batch_sample.npz"), fits, rings, n_cases=6, n_bench=6)
 
 

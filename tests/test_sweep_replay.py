@@ -1,7 +1,7 @@
 """Step-level pin of the sweep kernel (k_sweep) on the benchmarked configuration.
 
 The end-to-end result of the reference's Gauss-Seidel driver is noise-sensitive on some instances
-(DESIGN.md "Conditioning"), so besides the per-instance end-to-end rule (tests/parity_rule.py) every
+(DESIGN_HISTORY.md "Conditioning"), so besides the per-instance end-to-end rule (tests/parity_rule.py) every
 single step the kernel takes is checked on its own, TEACHER-FORCED: the recording instantiation of the
 kernel (rl_debug_dump_enable) stores, for the first instances of the batch and for each of their
 2 * max_iter * (n - k) steps, the control points the step started from, what it assembled (H, g, the

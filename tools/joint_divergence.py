@@ -5,7 +5,7 @@ The kernel records the control points every window starts from (rl_debug_dump_en
 window through its teacher-forced instrument (orc_replay_joint_windows fed with ITS OWN state, which reproduces
 orc_run_joint_min_curvature_qp exactly -- checked).  Printed per case: the first windows at which the two states differ
 by more than 1e-13 / 1e-9 / 1e-4 m, what entered that window (state difference), what the window did with it (verdicts,
-smallest norm of an active row = the 1/b amplification of DESIGN.md section 5), and what came out.
+smallest norm of an active row = the 1/b amplification of DESIGN_HISTORY.md section 5), and what came out.
     python tools/joint_divergence.py [case substring]          (GPU box)"""
 import ctypes
 import os
