@@ -40,10 +40,11 @@ def widths_like_monza(rl, fits, rings, tag, N, B, seed):
 
 
 def test_cr_heading_on_the_device(rl):
-    """csrc/rl_crmath.hpp on the device against libquadmath (the oracle's CR build): identical bits for 400 000 tangents
-    of every direction and magnitude ratio, and for headings exactly on an axis."""
+    """csrc/rl_crmath.hpp on the device -- the two-stage evaluation the kernels call (heading_fast with v_rcp_f32 / v_rsq_f32
+    seeds, the full double-double heading where it cannot decide) -- against libquadmath (the oracle's CR build): identical bits
+    for 2 000 000 tangents of every direction and magnitude ratio, and for headings exactly on an axis."""
     rng = np.random.default_rng(5)
-    n = 200000
+    n = 1000000
     dx = np.concatenate([(rng.random(n) - 0.5) * 12000.0, np.ldexp(1.0 + rng.random(n), rng.integers(-20, 20, n))])
     dy = np.concatenate([(rng.random(n) - 0.5) * 12000.0,
                          dx[n:] * np.ldexp(1.0 + rng.random(n), -rng.integers(0, 20, n)) * rng.choice([-1.0, 1.0], n)])
@@ -474,6 +475,34 @@ def test_cost_and_constraint_entry_points_bitwise(rl, fits, rings):
     for (A, lba, uba), i in zip(rows, idx[::7]):
         oA, olba, ouba = orc.track_constraint(int(i), t, cx, cy, k, pts)
         np.testing.assert_array_equal(A, oA); np.testing.assert_array_equal(lba, olba); np.testing.assert_array_equal(uba, ouba)
+
+
+@pytest.mark.parametrize("scale,collapse", [(1.0, True), (1e-120, False), (1e+95, False)])
+def test_cost_quotients_outside_the_plain_range_bitwise(rl, fits, scale, collapse):
+    """The reference-order cost takes its three quotients by one denominator through the division's own instruction sequence with
+    the reciprocal chain shared -- valid for operands far from the ends of the exponent range; a wave with any lane outside takes
+    the plain divisions (csrc/rl_kernels.hpp: cost_quotients).  Both paths must return the oracle's bits: a spline with a run of
+    coincident control points (samples of exactly zero tangent: 0 / 0), and the Monza spline scaled so that (x'^2 + y'^2)^3
+    under- or overflows (1e-120: denominators down in the subnormals; 1e+95: up at 1e590 = inf)."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    cx, cy = cx * scale, cy * scale
+    if collapse:
+        cx, cy = cx.copy(), cy.copy()
+        cx[20:28] = cx[20]; cy[20:28] = cy[20]          # eight coincident control points: the curve stands still on two knot spans
+    N = 500
+    ctx = rl.lib.Context.get(0)
+    trk = rl.lib.Track(ctx, t, cx, cy, k, N)
+    idx = np.arange(2, len(cx) - 3)
+    with ctx.arith(REF):
+        H, g, M = rl.ops.mincurv_cost(trk, idx)
+    n_special = 0
+    for q, i in enumerate(idx):
+        oH, og, oM = orc.min_curvature_cost(np.array([cx[i], cy[i]]), int(i), t, cx, cy, k, N)
+        assert M[q] == oM
+        np.testing.assert_array_equal(H[q], oH, err_msg=f"H of control point {i}")   # NaN where the oracle has NaN, the same infinities
+        np.testing.assert_array_equal(g[q], og, err_msg=f"g of control point {i}")
+        n_special += int(not np.isfinite(oH).all() or not np.isfinite(og).all() or (oH == 0).all())
+    assert n_special > 0, "the case was meant to leave the plain range"
 
 
 def test_numpy_raise_semantics_g12_sliding_window(rl):
