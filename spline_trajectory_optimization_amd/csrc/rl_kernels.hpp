@@ -2225,6 +2225,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   }
 #endif
   // ---- epilogue
+  // (the reference-order loop ends its steps with a barrier that orders LDS only: the bound points the table below reads were
+  // written to global memory by other waves -- one full barrier here makes them visible)
+  if constexpr (STRICT && !RINGS_LDS) __syncthreads();
   if (tid == 0 && a.status) a.status[b] = n_skipped;
   for (int j = tid; j < n; j += BLOCK) {
     reinterpret_cast<double2*>(a.out_ctrl)[(size_t)b * n + j] = make_double2(cx[j], cy[j]);

@@ -82,14 +82,19 @@ def test_single_instance_on_the_monza_rings_bitwise(rl, fits, rings, tag, N, max
     assert ons.sum() > 0.8 * ons.size * (len(cx) - 5)
 
 
-def test_final_table_of_the_single_sweep_bitwise(rl, fits, rings):
-    """rl_mincurv_sweep's returned Trajectory table: X, Y, YAW, turn radius and the four bound columns."""
+@pytest.mark.parametrize("residency", ["1", "0"])
+def test_final_table_of_the_single_sweep_bitwise(rl, fits, rings, monkeypatch, residency):
+    """rl_mincurv_sweep's returned Trajectory table: X, Y, YAW, turn radius and the four bound columns -- with the per-instance
+    state in LDS and in global scratch (there the bound columns are read back from what OTHER waves wrote in the last step, behind
+    the loop's LDS-only barriers: the epilogue's own full barrier, round 6)."""
     t, cx, cy, k, length = spline(fits, "c100")
     N = 300
     i_start = rl.batch.default_i_start(len(cx), k, 2, seed=3)
     trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
     trk.set_rings(rings[0], rings[1])
+    monkeypatch.setenv("RL_FORCE_RESIDENCY", residency)
     hcx, hcy, pts, ns, st = rl.ops.mincurv_sweep(trk, cx, cy, i_start, arith=REF)
+    assert st.rings_in_lds == int(residency)
     with orc.cr_variant():
         ocx, ocy, opts, ons = orc.run_min_curvature_qp(t, cx, cy, k, length, N, rings[0], rings[1], i_start)
     np.testing.assert_array_equal(ns, ons)
