@@ -1623,6 +1623,8 @@ int rl_mintime_solve_batch_dev(rl_ctx* ctx, const double* model, int B, int N, c
       hipLaunchKernelGGL(rl::k_mt_dir, dim3(rl::kMtDirBlocks(N), G.nb), bn64, 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_trial, gn, bn64, 0, G.q, G.P, G.st);
       hipLaunchKernelGGL(rl::k_mt_step, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
+      hipLaunchKernelGGL(rl::k_mt_trial_b, gn, bn64, 0, G.q, G.P, G.st);        // halvings of the instances whose first trial point was rejected
+      hipLaunchKernelGGL(rl::k_mt_step_b, dim3(G.nb), dim3(256), 0, G.q, G.P, G.st);
     }
     if (ctx->mt_poll && (it & 7) == 7) {   // host entry point only: stop once every instance has finished
       const int chunk = it >> 3, slot = chunk & 1;

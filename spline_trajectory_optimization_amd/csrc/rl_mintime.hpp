@@ -2152,13 +2152,23 @@ __global__ void __launch_bounds__(64) k_mt_trial(MtProblem P, MtState st) {
   }
 }
 
+// The step decision in two stages (round 6).  72 % of the steps of the benchmark batch take the first trial point (a = ap); the others
+// used to evaluate ap / 2, ap / 4, ... INSIDE k_mt_step -- one workgroup per instance, four nodes per thread one after the other,
+// while the workgroups of the instances that were done sat idle: the kernel lasted as long as its slowest instance (865 us per
+// iteration against 115 us for k_mt_trial's whole grid).  Now k_mt_step decides on the first point and, where it is rejected, only
+// marks the instance (scal[15]) and leaves (ap, ad, theta0, phi0) in the free slots of node 0's trial record; k_mt_trial_b --
+// k_mt_trial's grid, returning at once for unmarked instances -- evaluates ap / 2 and ap / 4 per node, and k_mt_step_b decides on
+// those (and, for the 3 % that need more, goes on halving in the kernel as before).  The per-node shares are formed and added
+// exactly as before (mt_trial_node, thread-strided sums, mt_block_reduce_n): the decisions and the iterates are the same bits.
+static_assert(kMtTrials == 1, "the deferred halvings are written for one precomputed trial point");
+constexpr int kMtStash = 8;   // vec[b][0][8 .. 11]: ap, ad, theta0, phi0 of an instance whose first trial point was rejected
+
 __global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
   __shared__ double red[(4 + 2 * kMtTrials) * 4];
   const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
   const MtStepPtrs q = mt_step_ptrs(st, b, N);
   if (q.scal[5] != 0.0) return;
   mt_instance(P, b);
-  const double mu = q.scal[0];
   // ---- the step lengths and (theta0, phi0) of the current point from the shares of k_mt_dir
   double ap = 1.0, ad = 1.0, theta0 = 0.0, phi0 = 0.0;
   {
@@ -2179,38 +2189,78 @@ __global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
       phi0 += c;
     }
   }
-  // ---- the trial points of k_mt_trial: the first acceptable one
-  const double* tp = st.vec + (size_t)b * N * 16;
-  double th[kMtTrials], ph[kMtTrials];
-#pragma unroll
-  for (int k = 0; k < kMtTrials; ++k) { th[k] = 0.0; ph[k] = 0.0; }
-  for (int j = tid; j < N; j += 256) {
-#pragma unroll
-    for (int k = 0; k < kMtTrials; ++k) { th[k] += tp[(size_t)j * 16 + 2 * k]; ph[k] += tp[(size_t)j * 16 + 2 * k + 1]; }
-  }
+  // ---- the trial point of k_mt_trial
+  double* tp = st.vec + (size_t)b * N * 16;
+  double th0 = 0.0, ph0 = 0.0;
+  for (int j = tid; j < N; j += 256) { th0 += tp[(size_t)j * 16]; ph0 += tp[(size_t)j * 16 + 1]; }
   {
-    double v[4 + 2 * kMtTrials];
-    int op[4 + 2 * kMtTrials];
-    v[0] = ap; v[1] = ad; v[2] = theta0; v[3] = phi0; op[0] = 1; op[1] = 1; op[2] = 0; op[3] = 0;
-#pragma unroll
-    for (int k = 0; k < kMtTrials; ++k) { v[4 + 2 * k] = th[k]; v[5 + 2 * k] = ph[k]; op[4 + 2 * k] = 0; op[5 + 2 * k] = 0; }
-    mt_block_reduce_n<256, 4 + 2 * kMtTrials>(v, op, red);
-    ap = v[0]; ad = v[1]; theta0 = v[2]; phi0 = v[3];
-#pragma unroll
-    for (int k = 0; k < kMtTrials; ++k) { th[k] = v[4 + 2 * k]; ph[k] = v[5 + 2 * k]; }
+    double v[6] = {ap, ad, theta0, phi0, th0, ph0};
+    const int op[6] = {1, 1, 0, 0, 0, 0};
+    mt_block_reduce_n<256, 6>(v, op, red);
+    ap = v[0]; ad = v[1]; theta0 = v[2]; phi0 = v[3]; th0 = v[4]; ph0 = v[5];
   }
   const int nfilt_total = (int)q.scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
-  double a = ap;
+  if (mt_accept(st, q.filt, nfilt, N, th0, ph0, theta0, phi0)) {
+    RL_MT_COUNT(0);
+    mt_take_step(st, q, N, tid, ap, 0, ap, ad, theta0, phi0);
+    return;
+  }
+  // rejected: the halvings are evaluated by k_mt_trial_b / k_mt_step_b
+  __syncthreads();   // everybody has read scal and the trial record
+  if (tid == 0) { tp[kMtStash] = ap; tp[kMtStash + 1] = ad; tp[kMtStash + 2] = theta0; tp[kMtStash + 3] = phi0; q.scal[15] = 1.0; }
+}
+
+// grid as k_mt_trial: for the instances k_mt_step has marked, the trial points ap / 2 and ap / 4 per node -> vec[b][j][2 .. 5]
+__global__ void __launch_bounds__(64) k_mt_trial_b(MtProblem P, MtState st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, N = P.N;
+  const MtStepPtrs q = mt_step_ptrs(st, b, N);
+  if (q.scal[5] != 0.0 || q.scal[15] == 0.0) return;
+  if (j >= N) return;
+  mt_instance(P, b);
+  const double ap = st.vec[(size_t)b * N * 16 + kMtStash];
+  const double mu = q.scal[0];
+  double* o = st.vec + ((size_t)b * N + j) * 16;
+  double a = 0.5 * ap;
+  for (int k = 1; k <= 2; ++k) {
+    double theta = 0.0, phi = 0.0;
+    mt_trial_node(P, q, N, j, a, mu, theta, phi);
+    o[2 * k] = theta; o[2 * k + 1] = phi;   // (node 0's record also holds the stash, in slots 8 .. 11)
+    a *= 0.5;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_mt_step_b(MtProblem P, MtState st) {
+  __shared__ double red[4 * 4];
+  const int b = blockIdx.x, tid = threadIdx.x, N = P.N;
+  const MtStepPtrs q = mt_step_ptrs(st, b, N);
+  if (q.scal[5] != 0.0 || q.scal[15] == 0.0) return;
+  mt_instance(P, b);
+  const double mu = q.scal[0];
+  const double* tp = st.vec + (size_t)b * N * 16;
+  const double ap = tp[kMtStash], ad = tp[kMtStash + 1], theta0 = tp[kMtStash + 2], phi0 = tp[kMtStash + 3];
+  double th[2] = {0.0, 0.0}, ph[2] = {0.0, 0.0};
+  for (int j = tid; j < N; j += 256) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { th[k] += tp[(size_t)j * 16 + 2 + 2 * k]; ph[k] += tp[(size_t)j * 16 + 3 + 2 * k]; }
+  }
+  {
+    double v[4] = {th[0], ph[0], th[1], ph[1]};
+    const int op[4] = {0, 0, 0, 0};
+    mt_block_reduce_n<256, 4>(v, op, red);
+    th[0] = v[0]; ph[0] = v[1]; th[1] = v[2]; ph[1] = v[3];
+  }
+  const int nfilt_total = (int)q.scal[14], nfilt = nfilt_total < kMtFilter ? nfilt_total : kMtFilter;
+  double a = 0.5 * ap;
   int taken = -1;
 #pragma unroll
-  for (int k = 0; k < kMtTrials; ++k) {
+  for (int k = 0; k < 2; ++k) {
     if (taken < 0) {
-      if (mt_accept(st, q.filt, nfilt, N, th[k], ph[k], theta0, phi0)) taken = k;
+      if (mt_accept(st, q.filt, nfilt, N, th[k], ph[k], theta0, phi0)) taken = 1 + k;
       else a *= 0.5;
     }
   }
-  // ---- the precomputed trial point(s) rejected: further halvings, evaluated here
-  for (int trial = kMtTrials; trial < 12 && taken < 0; ++trial) {
+  // ---- further halvings, evaluated here (3 % of the steps)
+  for (int trial = 3; trial < 12 && taken < 0; ++trial) {
     double theta = 0.0, phi = 0.0;
     for (int j = tid; j < N; j += 256) {   // per-node shares from zero, then added: the association of k_mt_trial's path
       double tj = 0.0, pj = 0.0;
@@ -2226,6 +2276,8 @@ __global__ void __launch_bounds__(256, 2) k_mt_step(MtProblem P, MtState st) {
     if (mt_accept(st, q.filt, nfilt, N, theta, phi, theta0, phi0)) taken = trial;
     else a *= 0.5;
   }
+  __syncthreads();
+  if (tid == 0) q.scal[15] = 0.0;
   if (taken < 0) {
     // no acceptable step: more damping, same point (the next iteration re-solves with the larger delta)
     const double delta = fmax(10.0 * q.scal[1], 1e-4);
