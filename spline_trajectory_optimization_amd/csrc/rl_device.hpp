@@ -527,7 +527,11 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
   if (windowed && found && nchunk > 2 * kNear + 1) {
     const int ce = h.edge / kChunk;
     bool ok = sep[ce] > 2.0 * di;
-    if (ok) {
+    // The usual case: the crossing is still in the middle chunk of a window that does not run over the ring's seam -- then
+    // ce - 1, ce, ce + 1 ARE the window (three whole chunks) and there is no neighbour left to test.  (A crossing moves out of
+    // its chunk only when the line moves by more than a chunk's length in one step; the window is re-centred on it next time.)
+    const bool centred = ce * kChunk == lo + kChunk && lo + kWinEdges <= nr;
+    if (ok && !centred) {
 #pragma unroll
       for (int u = -kNear; u <= kNear; ++u) {
         int c = ce + u;
