@@ -181,6 +181,18 @@ __device__ __forceinline__ double edge_side(double vx, double vy, double dx, dou
   else return fma(vx, dy, -(vy * dx));
 }
 
+// the crossing of the line with an edge whose end points are known NOT to lie strictly on one side of it
+template <bool ST = false>
+__device__ __forceinline__ void edge_cross(double ax, double ay, double bx, double by, double dx, double dy, int edge, Hit& h) {
+  const double sx = bx - ax, sy = by - ay;
+  const double den = ST ? cross_unfused(dx, sy, dy, sx) : fma(dx, sy, -(dy * sx));
+  if (den == 0.0) return;  // parallel / collinear: not a Point intersection
+  const double s = (ST ? cross_unfused(ax, sy, ay, sx) : fma(ax, sy, -(ay * sx))) / den;
+  const double as = fabs(s);
+  if (as > 1.0) return;  // beyond +-max_dist
+  if (as < h.best || (as == h.best && edge < h.edge)) { h.best = as; h.best_s = s; h.edge = edge; }
+}
+
 template <bool ST = false>
 __device__ __forceinline__ void edge_hit(double ax, double ay, double ea, double bx, double by,
                                          double eb, double dx, double dy, int edge, Hit& h) {
@@ -311,17 +323,23 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
     // sign change across edge q <-> bits 24 - q and 23 - q of `signs` differ <-> bit 23 - q of signs ^ (signs >> 1); reversed: bit q
     cand = __builtin_bitreverse32((signs ^ (signs >> 1)) & 0xFFFFFFu) >> 8;
     if (emin == 0.0) cand = 0xFFFFFFu;
-  }
-  static_assert(kWinEdges == 24 && kWinEdges % BATCH == 0, "window scan is unrolled in whole batches; the candidate word holds 24 edges");
-  while (__any(cand != 0u)) {
-    if (cand != 0u) {
-      const int q = __ffs((int)cand) - 1;
-      cand &= cand - 1u;
-      const int j = lo + q, je = lo_edge + q;
-      const double2 va = ring[j], vb = ring[j + 1];
-      const double ax = va.x - px, ay = va.y - py, bx = vb.x - px, by = vb.y - py;
-      edge_hit<ST>(ax, ay, edge_side<ST>(ax, ay, dx, dy), bx, by, edge_side<ST>(bx, by, dx, dy), dx, dy,
-               je >= nr ? je - nr : je, h);
+    // An edge flagged for a CHANGE OF SIGN has its end points on different sides (or one of them is a zero of the other
+    // sign bit): edge_hit's two early exits -- product positive; product zero with both factors non-zero and of one sign -- can
+    // not fire, so pass 2 goes straight to the crossing, without forming the two side values again.  Only a wave that holds a
+    // lane with a vertex exactly on its line (every edge of that lane flagged) runs the full test.
+    const bool sides_known = !__any(emin == 0.0);
+    static_assert(kWinEdges == 24 && kWinEdges % BATCH == 0, "window scan is unrolled in whole batches; the candidate word holds 24 edges");
+    while (__any(cand != 0u)) {
+      if (cand != 0u) {
+        const int q = __ffs((int)cand) - 1;
+        cand &= cand - 1u;
+        const int j = lo + q, je = lo_edge + q;
+        const double2 va = ring[j], vb = ring[j + 1];
+        const double ax = va.x - px, ay = va.y - py, bx = vb.x - px, by = vb.y - py;
+        if (sides_known) edge_cross<ST>(ax, ay, bx, by, dx, dy, je >= nr ? je - nr : je, h);
+        else edge_hit<ST>(ax, ay, edge_side<ST>(ax, ay, dx, dy), bx, by, edge_side<ST>(bx, by, dx, dy), dx, dy,
+                          je >= nr ? je - nr : je, h);
+      }
     }
   }
 }

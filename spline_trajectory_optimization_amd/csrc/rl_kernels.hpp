@@ -79,9 +79,11 @@ template <int K> struct StrictRows {
 template <int CNT, typename CPtr>
 __device__ __forceinline__ double seq_dot(CPtr c, const double* __restrict__ tab, int N, int i) {
 #pragma clang fp contract(off)
-  double s = 0.0;
+  // s = 0; s += c[0] t[0] as ONE instruction: fma(c, t, +0) rounds the product once and adds an exact zero -- the same double,
+  // sign of a zero product included (-0 + +0 = +0), as the multiplication followed by the addition.
+  double s = fma(c[0], tab[i], 0.0);
 #pragma unroll
-  for (int a = 0; a < CNT; ++a) s += c[a] * tab[(size_t)a * N + i];
+  for (int a = 1; a < CNT; ++a) s += c[a] * tab[(size_t)a * N + i];
   return s;
 }
 __device__ __forceinline__ double uf_madd(double p, double w, double c) {   // p + w * c, two roundings
