@@ -256,13 +256,7 @@ static double g_seed_perturb = 1.0;   // host tests only: multiplies both seeds 
 #endif
 // The three parts of heading_fast (direction, angle, roundings) are independent until the end; left alone, the scheduler
 // interleaves them and the kernel that inlines it runs out of its 128 registers.  Device only: keep them in source order.
-#ifndef RL_X_HSEQ
-#define RL_X_HSEQ 1
-#endif
-#ifndef RL_X_POLY
-#define RL_X_POLY 1
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && RL_X_HSEQ
+#if defined(__HIP_DEVICE_COMPILE__)
 #define RL_CR_SEQ() __builtin_amdgcn_sched_barrier(0)
 #else
 #define RL_CR_SEQ() do { } while (0)
@@ -326,17 +320,14 @@ RL_CR_FN bool heading_fast(double x, double y, Heading& o, const double (*tab)[2
   const double wl0 = fma(-wh0, dl, rr + nn.lo) * R;
   const dd w = fast_two_sum(wh0, wl0);
   const double u2 = w.hi * w.hi;
-#if RL_X_POLY
-  // atan w - w = -(w^3 / 3) (1 - 3/5 w^2 (1 - 5/7 w^2 (1 - 7/9 w^2 (1 - 9/11 w^2)))): every addend is the inline constant 1.0
+  // atan w - w = -(w^3 / 3) (1 - 3/5 w^2 (1 - 5/7 w^2 (1 - 7/9 w^2 (1 - 9/11 w^2)))): every addend is the inline constant 1.0.
+  // (In Horner form with the constants 1/9, -1/7, 1/5, -1/3 as addends the kernel that inlines this kept four of them in
+  // registers across its loop, spilled them, and reloaded each from scratch in the middle of the chain: 1.2 ms of 14.)
   const double q4 = fma(u2 * (-9.0 / 11.0), 1.0, 1.0);
   const double q3 = fma(u2 * (-7.0 / 9.0), q4, 1.0);
   const double q2 = fma(u2 * (-5.0 / 7.0), q3, 1.0);
   const double q1 = fma(u2 * (-3.0 / 5.0), q2, 1.0);
   const double corr = ((w.hi * u2) * (-1.0 / 3.0)) * q1;
-#else
-  const double P = fma(u2, fma(u2, fma(u2, fma(u2, -1.0 / 11.0, 1.0 / 9.0), -1.0 / 7.0), 0.2), -1.0 / 3.0);
-  const double corr = (w.hi * u2) * P;
-#endif
   const dd a0 = fast_two_sum(tab[j][0], w.hi);              // T_j >= |w| for j >= 1, T_0 = 0
   const dd a1 = fast_two_sum(a0.hi, corr);
   dd th = fast_two_sum(a1.hi, a1.lo + (a0.lo + (tab[j][1] + w.lo)));

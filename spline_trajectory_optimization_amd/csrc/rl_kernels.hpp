@@ -546,9 +546,6 @@ __global__ void k_constraint_strict(TrackDev tr, const double* __restrict__ cx, 
 
 // ------------------------------------------------------------------------------------------------
 // a12: the sweep.
-#ifndef RL_X_PRIO
-#define RL_X_PRIO 0
-#endif
 constexpr int kJointRowsPerThread = 3;  // sliding-window variant: union of 5 supports <= 3 * 256 samples
 
 struct SweepArgs {
