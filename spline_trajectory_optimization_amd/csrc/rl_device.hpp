@@ -458,6 +458,28 @@ __device__ __forceinline__ double wave_reduce(double v) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
+// The same reduction as a butterfly through the LDS crossbar (ds_swizzle xor 1, 2, 4, 8, 16, then ds_bpermute across the two halves):
+// ONE vector instruction per stage -- the operation -- where the DPP path spends five (a 64-bit DPP move is two moves, each with its
+// `old` operand initialised first); the exchanges are LDS-pipe instructions, of which the sweep kernels, bound by VALU issue, have
+// plenty to spare.  Every lane ends with the result.  For order-independent operations only (max, min): a butterfly adds in another
+// order than the scan above, so the SUMS of the fast arithmetic stay on the DPP path (their order is their result).
+template <typename Op>
+__device__ __forceinline__ double wave_reduce_bfly(double v) {
+#define RL_BFLY(pattern)                                                                                        \
+  {                                                                                                             \
+    const int lo_ = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);                                    \
+    const int hi_ = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);                                    \
+    v = Op::f(v, __hiloint2double(hi_, lo_));                                                                   \
+  }
+  RL_BFLY(0x041F) RL_BFLY(0x081F) RL_BFLY(0x101F) RL_BFLY(0x201F) RL_BFLY(0x401F)   // and 0x1f, or 0, xor 1 / 2 / 4 / 8 / 16
+#undef RL_BFLY
+  const int other = (((int)threadIdx.x ^ 32) & 63) << 2;
+  const int lo_ = __builtin_amdgcn_ds_bpermute(other, __double2loint(v));
+  const int hi_ = __builtin_amdgcn_ds_bpermute(other, __double2hiint(v));
+  return Op::f(v, __hiloint2double(hi_, lo_));
+}
+__device__ __forceinline__ double wave_max_bfly(double v) { return wave_reduce_bfly<OpMax>(v); }
+__device__ __forceinline__ double wave_min_bfly(double v) { return wave_reduce_bfly<OpMin>(v); }
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMax>(v); }
 __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }

@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           }
         }
         const double v0 = wave_sum(hxx), v1 = wave_sum(hyy), v2 = wave_sum(gx), v3 = wave_sum(gy);
-        const double v4 = wave_max(lox), v5 = wave_min(hix), v6 = wave_max(loy), v7 = wave_min(hiy);
+        const double v4 = wave_max_bfly(lox), v5 = wave_min_bfly(hix), v6 = wave_max_bfly(loy), v7 = wave_min_bfly(hiy);   // (LDS crossbar: rl_device.hpp)
         const bool wbad = __any(bad);
         if (lane == 0) {
           double* r = red + wave * 12;
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         if (ch + 1 < nchunks) __syncthreads();   // the terms of this chunk are summed: their rows of LDS are free again
       }
       if (wave != 0) {
-        const double v4 = wave_max(lox), v5 = wave_min(hix), v6 = wave_max(loy), v7 = wave_min(hiy);
+        const double v4 = wave_max_bfly(lox), v5 = wave_min_bfly(hix), v6 = wave_max_bfly(loy), v7 = wave_min_bfly(hiy);   // (LDS crossbar: rl_device.hpp)
         const bool wbad = __any(bad);
         if (lane == 0) { double* r = red + wave * 12; r[4] = v4; r[5] = v5; r[6] = v6; r[7] = v7; r[8] = wbad ? 1.0 : 0.0; }
       }
@@ -2116,7 +2116,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         }
         if (s0 + wave * kWave < s1) {  // this wave held samples (wave-uniform)
           const double v0 = wave_sum(hxx), v1 = wave_sum(hyy), v2 = wave_sum(gx), v3 = wave_sum(gy);
-          const double v4 = wave_max(lox), v5 = wave_min(hix), v6 = wave_max(loy), v7 = wave_min(hiy);
+          const double v4 = wave_max_bfly(lox), v5 = wave_min_bfly(hix), v6 = wave_max_bfly(loy), v7 = wave_min_bfly(hiy);   // (LDS crossbar: rl_device.hpp)
           const bool wbad = __any(bad);
           if (lane == 0) {
             double* r = red + wave * 12;
