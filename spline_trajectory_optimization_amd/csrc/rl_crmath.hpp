@@ -258,8 +258,10 @@ static double g_seed_perturb = 1.0;   // host tests only: multiplies both seeds 
 // interleaves them and the kernel that inlines it runs out of its 128 registers.  Device only: keep them in source order.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RL_CR_SEQ() __builtin_amdgcn_sched_barrier(0)
+#define RL_CR_PIN6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
 #else
 #define RL_CR_SEQ() do { } while (0)
+#define RL_CR_PIN6(a, b, c, d, e, f) do { } while (0)
 #endif
 RL_CR_FN double seed_rcp(double d) {      // 1 / d within 2^-22, d in the float range
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -277,7 +279,12 @@ RL_CR_FN double seed_rsqrt(double d) {    // 1 / sqrt(d) within 2^-22, d in the 
 }
 
 // diag (host tests): [0,1] th.hi, th.lo  [2] e_th  [3 + 3 q .. ] vh, vl, E of output q = cl, sl, cr, sr (before the sign)
-RL_CR_FN bool heading_fast(double x, double y, Heading& o, const double (*tab)[2] = kAtanTab, double* diag = nullptr) {
+struct NoHook { RL_CR_FN void operator()() const {} };
+// after_table(): called once the look-up of atan(j / 64) has ARRIVED (it travels during the direction part) -- the sweep kernel
+// requests its ring stretches there, and they travel during the angle and the roundings
+template <typename Hook = NoHook>
+RL_CR_FN bool heading_fast(double x, double y, Heading& o, const double (*tab)[2] = kAtanTab, double* diag = nullptr,
+                           Hook&& after_table = Hook()) {
   RL_CR_STRICT
   const double kPio2Hi = 0x1.921fb54442d18p+0, kPio2Lo = 0x1.1a62633145c07p-54;
   const double kPiHi = 0x1.921fb54442d18p+1, kPiLo = 0x1.1a62633145c07p-53;
@@ -287,6 +294,12 @@ RL_CR_FN bool heading_fast(double x, double y, Heading& o, const double (*tab)[2
   // ordinary tangents only: finite, not on an axis, |min / max| >= 2^-40, max component within 2^+-60
   // (no early return: anything else flows through as garbage or NaN and is rejected at the end, without a divergent branch)
   const bool ordinary = den >= 0x1p-60 && den <= 0x1p+60 && num >= den * 0x1p-40;
+  // ---- the table entry of theta, requested first
+  const float qf = (float)num * (float)seed_rcp(den);
+  int j = (int)rintf(qf * 64.0f);
+  j = j < 0 ? 0 : (j > 64 ? 64 : j);
+  double Tj = tab[j][0], Tjl = tab[j][1];
+  RL_CR_SEQ();
   // ---- (cos, sin) theta
   const dd dd2 = two_prod(den, den), nn2 = two_prod(num, num);
   const dd s2 = fast_two_sum(dd2.hi, nn2.hi);
@@ -299,13 +312,16 @@ RL_CR_FN bool heading_fast(double x, double y, Heading& o, const double (*tab)[2
   const double ml = fma(s2.hi, yy.hi, -mh) + fma(s2l, yy.hi, s2.hi * yy.lo);
   const double e = (1.0 - mh) - ml;                          // 1 - s2 y1^2
   const double rl = y1 * (0.5 * e);
-  const double cth = y1 * x, ctl = fma(rl, x, fma(y1, x, -cth));
-  const double sth = y1 * y, stl = fma(rl, y, fma(y1, y, -sth));
+  double cth = y1 * x, ctl = fma(rl, x, fma(y1, x, -cth));
+  double sth = y1 * y, stl = fma(rl, y, fma(y1, y, -sth));
+  RL_CR_SEQ();
+  // the table entry has to be IN its registers before the hook runs: the compiler waits for every outstanding vector-memory
+  // operation in front of a value that was requested before an LDS-DMA, so a look-up still in flight would wait for the stretches
+  // (the direction part is named too: left free, it sinks below the hook and the look-up's flight time is spent waiting)
+  RL_CR_PIN6(Tj, Tjl, cth, ctl, sth, stl);
+  after_table();
   RL_CR_SEQ();
   // ---- theta
-  const float qf = (float)num * (float)seed_rcp(den);
-  int j = (int)rintf(qf * 64.0f);
-  j = j < 0 ? 0 : (j > 64 ? 64 : j);
   const double c = (double)j * 0.015625;
   const dd p = two_prod(c, den);
   const dd h = two_sum(num, -p.hi);
@@ -328,9 +344,9 @@ RL_CR_FN bool heading_fast(double x, double y, Heading& o, const double (*tab)[2
   const double q2 = fma(u2 * (-5.0 / 7.0), q3, 1.0);
   const double q1 = fma(u2 * (-3.0 / 5.0), q2, 1.0);
   const double corr = ((w.hi * u2) * (-1.0 / 3.0)) * q1;
-  const dd a0 = fast_two_sum(tab[j][0], w.hi);              // T_j >= |w| for j >= 1, T_0 = 0
+  const dd a0 = fast_two_sum(Tj, w.hi);                     // T_j >= |w| for j >= 1, T_0 = 0
   const dd a1 = fast_two_sum(a0.hi, corr);
-  dd th = fast_two_sum(a1.hi, a1.lo + (a0.lo + (tab[j][1] + w.lo)));
+  dd th = fast_two_sum(a1.hi, a1.lo + (a0.lo + (Tjl + w.lo)));
   // theta = sign(y) (K + sigma th):  (0, +) | x < 0: (pi, -) | swapped: (pi/2, -) | swapped and x < 0: (pi/2, +)
   const bool xneg = x < 0.0;
   const double Kh = swap ? kPio2Hi : (xneg ? kPiHi : 0.0), Kl = swap ? kPio2Lo : (xneg ? kPiLo : 0.0);

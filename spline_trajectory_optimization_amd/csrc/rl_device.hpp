@@ -294,40 +294,79 @@ constexpr int kWinBatch = 8;
 // of the window inside the stretch.
 template <int BATCH = kWinBatch, bool ST = false, typename RingPtr>
 __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo_edge, double px, double py,
-                                            double dx, double dy, Hit& h) {
+                                            double dx, double dy, Hit& h, const double* cmax_p) {
   // Pass 1 per vertex: its side value e, then TWO bookkeeping instructions -- the sign bit of e shifted into a 25-bit word
   // (v_alignbit) and a running minimum of |e|.  Edge q is a candidate when the signs of its two vertices differ; a vertex
   // exactly ON the line (e == +-0, seen as a zero minimum) makes every edge of the window a candidate.  That is a superset of
   // the edges on which edge_hit() records a crossing (it needs e_a e_b <= 0 with a sign change or a zero: same-sign pairs whose
   // product merely underflows, and NaNs, never give one), and pass 2 runs the exact test on the candidates.  (Until round 6:
   // `!(e_a * e_b > 0)` per edge -- a multiplication, a comparison, a select and an or.)
+  // Round 6, QUICK pass 1: all pass 1 has to deliver is the SIGN of every vertex's side value as the exact arithmetic rounds
+  // it.  e' = v_x d_y - v_y d_x - (p_x d_y - p_y d_x), two fma per vertex on the untranslated coordinates (instead of two
+  // subtractions and the cross product: 4 instead of 7 vector instructions per vertex with the bookkeeping), differs from the
+  // real-number value by at most 4u Mp D + u |e'| (u = 2^-53, Mp >= every coordinate involved, D = |d_x| + |d_y|), and so
+  // does the difference of the two products whose sign the exact arithmetic returns (fused or not: the final subtraction
+  // cannot change a sign or make a zero).  |e'| > tol = 2^-46 Mp D = 128 u Mp D for every vertex of the window therefore
+  // proves: same signs, no exact zero.  tol outside [2^-900, 2^900], a non-finite operand (cmax is +inf for a ring with a
+  // non-finite vertex) or a vertex closer to the line than that sends the WAVE through the exact pass -- the untouched far
+  // end of a support in the first sweep (a width-form ring's vertex i sits on sample i's first normal), hardly ever later.
+  // A NaN vertex inside a finite ring gives no crossing on its edges whichever way its sign bit is read.
   unsigned cand;
   {
-    double2 v = ring[lo];
-    const double e0 = edge_side<ST>(v.x - px, v.y - py, dx, dy);
-    unsigned signs = (unsigned)__double2hiint(e0) >> 31;   // vertex k of the window ends up in bit 24 - k
-    double emin = fabs(e0);
+    unsigned signs;
+    double emin;
+    bool sure;
+    {
+      const double c0 = fma(px, dy, -(py * dx));
+      double2 v = ring[lo];
+      const double e0 = fma(v.x, dy, fma(-v.y, dx, -c0));
+      signs = (unsigned)__double2hiint(e0) >> 31;   // vertex k of the window ends up in bit 24 - k
+      emin = fabs(e0);
 #pragma unroll
-    for (int q0 = 0; q0 < kWinEdges; q0 += BATCH) {
-      double2 w[BATCH];
+      for (int q0 = 0; q0 < kWinEdges; q0 += BATCH) {
+        double2 w[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) w[u] = ring[lo + q0 + u + 1];
+        for (int u = 0; u < BATCH; ++u) w[u] = ring[lo + q0 + u + 1];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        const double eb = edge_side<ST>(w[u].x - px, w[u].y - py, dx, dy);
-        signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(eb), 31);   // (signs << 1) | sign(eb)
-        emin = fmin(emin, fabs(eb));
+        for (int u = 0; u < BATCH; ++u) {
+          const double eb = fma(w[u].x, dy, fma(-w[u].y, dx, -c0));
+          signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(eb), 31);   // (signs << 1) | sign(eb)
+          emin = fmin(emin, fabs(eb));
+        }
+        if constexpr (BATCH != kWinBatch) __builtin_amdgcn_sched_barrier(0);   // staged scan: keep the next batch's LDS reads behind this batch's arithmetic (registers)
       }
-      if constexpr (BATCH != kWinBatch) __builtin_amdgcn_sched_barrier(0);   // staged scan: keep the next batch's LDS reads behind this batch's arithmetic (registers)
+      asm volatile("" : "+v"(signs));   // the word is made HERE: left alone, the compiler sinks the 24 shifts below the branch and keeps 25 side values alive for them
+      const double tol = 0x1p-46 * ((cmax_p[opaque_zero()] + fabs(px)) + fabs(py)) * (fabs(dx) + fabs(dy));   // read here: a register held across the scan would be spilled
+      sure = emin > tol && tol > 0x1p-900 && tol < 0x1p+900;
+    }
+    if (__any(!sure)) {   // the exact pass, for the whole wave (a lane that was sure gets the same word again)
+      double2 v = ring[lo];
+      const double e0 = edge_side<ST>(v.x - px, v.y - py, dx, dy);
+      signs = (unsigned)__double2hiint(e0) >> 31;
+      emin = fabs(e0);
+#pragma unroll
+      for (int q0 = 0; q0 < kWinEdges; q0 += BATCH) {
+        double2 w[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) w[u] = ring[lo + q0 + u + 1];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+          const double eb = edge_side<ST>(w[u].x - px, w[u].y - py, dx, dy);
+          signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(eb), 31);
+          emin = fmin(emin, fabs(eb));
+        }
+        if constexpr (BATCH != kWinBatch) __builtin_amdgcn_sched_barrier(0);
+      }
+      sure = emin != 0.0;   // NaN: "sure" -- its edges give no crossing
     }
     // sign change across edge q <-> bits 24 - q and 23 - q of `signs` differ <-> bit 23 - q of signs ^ (signs >> 1); reversed: bit q
     cand = __builtin_bitreverse32((signs ^ (signs >> 1)) & 0xFFFFFFu) >> 8;
-    if (emin == 0.0) cand = 0xFFFFFFu;
+    if (!sure) cand = 0xFFFFFFu;
     // An edge flagged for a CHANGE OF SIGN has its end points on different sides (or one of them is a zero of the other
     // sign bit): edge_hit's two early exits -- product positive; product zero with both factors non-zero and of one sign -- can
     // not fire, so pass 2 goes straight to the crossing, without forming the two side values again.  Only a wave that holds a
     // lane with a vertex exactly on its line (every edge of that lane flagged) runs the full test.
-    const bool sides_known = !__any(emin == 0.0);
+    const bool sides_known = !__any(!sure);
     static_assert(kWinEdges == 24 && kWinEdges % BATCH == 0, "window scan is unrolled in whole batches; the candidate word holds 24 edges");
     while (__any(cand != 0u)) {
       if (cand != 0u) {
@@ -367,16 +406,18 @@ constexpr int kStageSlots = kStage + kStage / kChunk;   // 108
 __device__ __forceinline__ int stage_slot(int v) { return v + (v >> 3); }
 
 __device__ __forceinline__ void stage_issue(const double2* ring, int nr, int base, double2* stg, int lane) {
+  // two DMA instructions, neither predicated: slots 0..63 and slots kStageSlots-64..kStageSlots-1 (the twenty slots both cover
+  // receive the same vertex twice).  Exactly two vector-memory operations whatever the lanes do: the wait counts of loads
+  // issued BEFORE a stretch request stay exact (a conditional request makes the compiler wait for everything).
+  static_assert(kStageSlots > kWave && kStageSlots <= 2 * kWave, "two instructions cover the stretch");
 #pragma unroll
-  for (int t0 = 0; t0 < kStageSlots; t0 += kWave) {
+  for (int t0 = 0; t0 <= kStageSlots - kWave; t0 += kStageSlots - kWave) {
     const int t = t0 + lane;                 // slot
-    if (t < kStageSlots) {
-      const int v = t - t / 9;               // the vertex of slot t (slots 8, 17, 26, ... are the pads: they fetch a neighbour)
-      int idx = base + (v < kStage ? v : kStage - 1);
-      if (idx >= nr) idx -= nr;              // (base + v) mod nr: base < nr and v < kStage <= nr (the caller checks)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ring + idx),
-                                       (__attribute__((address_space(3))) void*)(stg + t0), 16, 0, 0);
-    }
+    const int v = t - t / 9;                 // the vertex of slot t (slots 8, 17, 26, ... are the pads: they fetch a neighbour)
+    int idx = base + (v < kStage ? v : kStage - 1);
+    if (idx >= nr) idx -= nr;                // (base + v) mod nr: base < nr and v < kStage <= nr (the caller checks)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ring + idx),
+                                     (__attribute__((address_space(3))) void*)(stg + t0), 16, 0, 0);
   }
 }
 // a window inside a staged stretch: vertex k of the window (its start is chunk aligned) -> its padded slot
@@ -394,6 +435,20 @@ __device__ __forceinline__ int window_start(int hint, int nchunk) {
   int cs = hint / kChunk - 1;
   if (cs < 0) cs += nchunk;
   return cs * kChunk;
+}
+
+// Request the stretch a wave's next window scan will read, ahead of time (the hints are known before the curve point is):
+// returns the base to hand to search_ring_windowed as `staged_base` (-1: no lane has a usable hint, nothing requested).
+// The search waits for the copy (stage_wait) before its first read.
+__device__ __forceinline__ int stage_prefetch(const double2* ring, int nr, int nchunk, bool active, int hint, double2* stg, int lane) {
+  const unsigned long long m = __ballot(active && hint >= 0 && hint < nr);
+  // no branch: with no usable hint in the wave the stretch at 0 is fetched for nothing (see stage_issue on the wait counts)
+  const int first = m ? __ffsll((long long)m) - 1 : 0;
+  const int lo = __builtin_amdgcn_readlane(window_start(hint, nchunk), first);
+  const int base = m ? lo : 0;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nobody still reads the stretch it replaces
+  stage_issue(ring, nr, base, stg, lane);
+  return m ? base : -1;
 }
 
 // brute force over all edges; ring vertices as double2 (x,y), any address space
@@ -511,7 +566,7 @@ template <bool STAGED = false, bool ST = false, typename RingPtr, typename Circl
 __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, CirclePtr circ,
                                                     CirclePtr sep, int nchunk, bool active, int hint,
                                                     double px, double py, double dx, double dy,
-                                                    double dlen, bool skip_guard = false,
+                                                    double dlen, const double* cmax, bool skip_guard = false,
                                                     unsigned long long* stamps = nullptr,
                                                     double2* stg = nullptr, int staged_base = -1) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -523,10 +578,11 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0) :: "memory");
 #endif
   if constexpr (!STAGED) {
-    if (windowed) scan_window<kWinBatch, ST>(ring, nr, lo, lo, px, py, dx, dy, h);
+    if (windowed) scan_window<kWinBatch, ST>(ring, nr, lo, lo, px, py, dx, dy, h, cmax);
   } else {
     bool todo = windowed;
     int base = staged_base;
+    if (base >= 0) stage_wait();   // requested by the caller (stage_prefetch)
     for (;;) {
       if (base >= 0) {
         int off = lo - base;
@@ -536,7 +592,7 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
         // bases are multiples of kChunk, so this only fails behind the seam of a ring whose length is not a multiple of
         // kChunk (off = lo - base + nr); such a lane is re-staged from its own window start (off = 0) below.
         if (todo && (off & (kChunk - 1)) == 0 && off + kWinEdges + 1 <= kStage) {
-          scan_window<kStageBatch, ST>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h);
+          scan_window<kStageBatch, ST>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h, cmax);
           todo = false;
         }
       }

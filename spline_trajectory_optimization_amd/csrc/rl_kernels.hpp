@@ -86,6 +86,21 @@ __device__ __forceinline__ double seq_dot(CPtr c, const double* __restrict__ tab
   for (int a = 1; a < CNT; ++a) s += c[a] * tab[(size_t)a * N + i];
   return s;
 }
+// the same sum from table values that are in registers already (load_rows): every table load of a sample is issued before the
+// first dependent operation, one memory round trip instead of one per group the scheduler happens to form
+template <int CNT, typename CPtr>
+__device__ __forceinline__ double seq_dot_v(CPtr c, const double (&tv)[CNT]) {
+#pragma clang fp contract(off)
+  double s = fma(c[0], tv[0], 0.0);
+#pragma unroll
+  for (int a = 1; a < CNT; ++a) s += c[a] * tv[a];
+  return s;
+}
+template <int CNT>
+__device__ __forceinline__ void load_rows(double (&tv)[CNT], const double* __restrict__ tab, int N, int i) {
+#pragma unroll
+  for (int a = 0; a < CNT; ++a) tv[a] = tab[(size_t)a * N + i];
+}
 __device__ __forceinline__ double uf_madd(double p, double w, double c) {   // p + w * c, two roundings
 #pragma clang fp contract(off)
   return p + w * c;
@@ -611,6 +626,7 @@ constexpr int kSweepWaves = 4;   // waves of the 256-thread sweep workgroup (the
 constexpr int kTermChunk = 256;
 constexpr int kTermStride = kTermChunk + 2;   // 6 lanes read 6 rows at the same index: 2064 B apart = 4 banks apart, no conflict (stride 256: six-fold)
 constexpr int kC12Doubles = 4 * (2 * kMaxK) + 8;
+constexpr int kRedCoordMax = 194;   // slot of the reduction scratch (8 x 24 + 4 doubles) that keeps the rings' coordinate bound
 
 // joint: the sliding-window instantiation (its QP scratch and per-sample flags are carved only then).  With the rings in
 // global memory every wave gets two staged stretches (left / right ring, rl_device.hpp: kStage vertices each): at N = 2000
@@ -801,6 +817,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         }
         (left ? sepL : sepR)[cc] = gap * (1.0 - 1e-9) - 1e-9;
       }
+      if (wave == 0) {   // a bound on every ring coordinate, for the quick sign pass of the window scan (+inf: no quick pass)
+        double m = 0.0;
+        for (int c = lane; c < L.ncL + L.ncR; c += kWave) {
+          const double* o = c < L.ncL ? circL + 3 * c : circR + 3 * (c - L.ncL);
+          const double v = fmax(fabs(o[0]), fabs(o[1])) + o[2];
+          m = v <= 0x1p+1000 ? fmax(m, v) : INFINITY;
+        }
+        m = wave_max_bfly(m);
+        if (lane == 0) red[kRedCoordMax] = m;
+      }
       __syncthreads();
     }
   }
@@ -846,17 +872,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   bool saw_degenerate = false;   // plain reference-order kernel: a flagged sample was seen while numpy is in raise mode
   auto refresh = [&](int i0, int i1, int j0, int j1, int mode, int l_first = -1) {
     const int m0 = i1 - i0, m1 = j1 - j0, m = m0 + m1;
+    const double* cmax = red + kRedCoordMax;
     if constexpr (STRICT) {
       // reference-order mode: sample_along (trajectory.py:278-280) + fill_bounds (:83-141) of the samples that moved,
       // operation by operation (oracle: sample_geometry, closest_hit)
       int delta = 0;
-      auto point = [&](int i, double& px, double& py, cr::Heading& hd, bool flags) {
+      auto point = [&](int i, double& px, double& py, cr::Heading& hd, bool flags, auto&& in_heading) {
 #pragma clang fp contract(off)
+        // every table value of the sample is requested before the first sum: one round trip
         const int l = tr.ell[i];
-        px = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, i);
-        py = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, i);
-        const double tx = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D1 * N, N, i);
-        const double ty = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D1 * N, N, i);
+        double t0[K + 1], t1[K + 1];
+        load_rows<K + 1>(t0, Ds + (size_t)SR::D0 * N, N, i);
+        load_rows<K + 1>(t1, Ds + (size_t)SR::D1 * N, N, i);
+        __builtin_amdgcn_sched_barrier(0);
+        px = seq_dot_v<K + 1>(cx + (l - K), t0);
+        py = seq_dot_v<K + 1>(cy + (l - K), t0);
+        const double tx = seq_dot_v<K + 1>(cx + (l - K), t1);
+        const double ty = seq_dot_v<K + 1>(cy + (l - K), t1);
+
         if constexpr (LITE && RL_LITE_NORMAL) {   // unit left normal from the reciprocal square root; the right one is its negative
           double nx, ny, inv_s2;
           scaled_normal(tx, ty, 1.0, nx, ny, inv_s2);
@@ -887,7 +920,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         unsigned long long sh0, sh1;
         RL_STAMP(sh0);
 #endif
-        const bool sure = cr::heading_fast(tx, ty, hd);
+        const bool sure = cr::heading_fast(tx, ty, hd, cr::kAtanTab, nullptr, in_heading);   // in_heading: the ring stretches are requested behind the heading's table look-up
         if (__any(!sure)) { if (!sure) hd = cr::heading(tx, ty); }
 #ifdef RL_STAMPS
         RL_STAMP(sh1); st_fine[5] += sh1 - sh0; if (__any(!sure)) st_fine[6] += 1;
@@ -903,15 +936,22 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
 #ifdef RL_STAMPS
           RL_STAMP(sf0);
 #endif
-          point(i, px, py, hd, flag_mode && active);
+          // both stretches travel while the heading is computed
+          int baseL = -1, baseR = -1;
+          point(i, px, py, hd, flag_mode && active, [&]() {
+            if constexpr (STAGED) {
+              baseL = stage_prefetch(reinterpret_cast<const double2*>(rL), nL, L.ncL, active, (int)hints[i], stgL, lane);
+              baseR = stage_prefetch(reinterpret_cast<const double2*>(rR), nR, L.ncR, active, (int)hints[Npad + i], stgR, lane);
+            }
+          });
           RL_FSTAMP(0);
           const double dLx = a.max_dist * hd.cl, dLy = a.max_dist * hd.sl;   // trajectory.py:87-88, norm = +pi/2
           const double dRx = a.max_dist * hd.cr, dRy = a.max_dist * hd.sr;   //                      norm = -pi/2
           const Hit hl = search_ring_windowed<STAGED, true>(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], px, py,
-                                                            dLx, dLy, a.max_dist, false, nullptr, stgL);
+                                                            dLx, dLy, a.max_dist, cmax, false, nullptr, stgL, baseL);
           RL_FSTAMP(1);
           const Hit hr = search_ring_windowed<STAGED, true>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], px, py,
-                                                            dRx, dRy, a.max_dist, false, nullptr, stgR);
+                                                            dRx, dRy, a.max_dist, cmax, false, nullptr, stgR, baseR);
           RL_FSTAMP(2);
           if (active) {   // no crossing: best_s = 0, the waypoint itself (trajectory.py:127)
             const double2 Lp = make_double2(uf_madd(px, hl.best_s, dLx), uf_madd(py, hl.best_s, dLy));
@@ -930,7 +970,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         const int r = side ? task - m : task;
         const int i = r < m0 ? i0 + r : j0 + (r - m0);
         double px, py; cr::Heading hd;
-        point(i, px, py, hd, flag_mode && side == 0);
+        point(i, px, py, hd, flag_mode && side == 0, []() {});
         const double dx = a.max_dist * (side ? hd.cr : hd.cl), dy = a.max_dist * (side ? hd.sr : hd.sl);
         Hit h;
         if (mode == 1) {
@@ -975,10 +1015,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           double dx, dy, inv_s2;
           scaled_normal(c.dx, c.dy, a.max_dist, dx, dy, inv_s2);
           if (!right) {
-            const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y, dx, dy, a.max_dist, false);
+            const Hit hl = search_ring_windowed(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y, dx, dy, a.max_dist, cmax, false);
             if (active) { sL[i] = hl.best_s; hints[i] = (unsigned short)(hl.edge == kNoEdge ? 0xFFFF : hl.edge); }
           } else {
-            const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x, c.y, -dx, -dy, a.max_dist, false);
+            const Hit hr = search_ring_windowed(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x, c.y, -dx, -dy, a.max_dist, cmax, false);
             if (active) { sR[i] = hr.best_s; hints[Npad + i] = (unsigned short)(hr.edge == kNoEdge ? 0xFFFF : hr.edge); }
           }
         }
@@ -994,6 +1034,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
 #ifdef RL_STAMPS
         RL_STAMP(sf0);
 #endif
+        int baseL = -1, baseR = -1;
+        if constexpr (STAGED) {   // both stretches are on their way while the point is evaluated
+          baseL = stage_prefetch(reinterpret_cast<const double2*>(rL), nL, L.ncL, active, (int)hints[i], stgL, lane);
+          baseR = stage_prefetch(reinterpret_cast<const double2*>(rR), nR, L.ncR, active, (int)hints[Npad + i], stgR, lane);
+        }
         CurvePoint<K, 1> c;
         eval_sample<K, 1>(tr, cx, cy, i, l, c);
         double dx, dy, inv_s2;
@@ -1003,17 +1048,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
 #ifdef RL_STAMPS
         unsigned long long ws[2] = {0, 0};
         const Hit hl = search_ring_windowed<STAGED>(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
-                                                    dx, dy, a.max_dist, skip, ws, stgL);
+                                                    dx, dy, a.max_dist, cmax, skip, ws, stgL, baseL);
         RL_FSTAMP(1);
         const Hit hr = search_ring_windowed<STAGED>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
-                                                    c.y, -dx, -dy, a.max_dist, skip, ws, stgR);  // yaw - pi/2
+                                                    c.y, -dx, -dy, a.max_dist, cmax, skip, ws, stgR, baseR);  // yaw - pi/2
         RL_FSTAMP(2);
         st_fine[4] += ws[0];
 #else
         const Hit hl = search_ring_windowed<STAGED>(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], c.x, c.y,
-                                                    dx, dy, a.max_dist, skip, nullptr, stgL);
+                                                    dx, dy, a.max_dist, cmax, skip, nullptr, stgL, baseL);
         const Hit hr = search_ring_windowed<STAGED>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], c.x,
-                                                    c.y, -dx, -dy, a.max_dist, skip, nullptr, stgR);  // yaw - pi/2
+                                                    c.y, -dx, -dy, a.max_dist, cmax, skip, nullptr, stgR, baseR);  // yaw - pi/2
 #endif
         if (active) {
           sL[i] = hl.best_s;
@@ -1312,15 +1357,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           for (int r = tz - kWave; r < cnt; r += BLOCK - kWave) {
 #pragma clang fp contract(off)
             const int ir = s0 + ch * kTermChunk + r;
+            // everything that does not depend on the knot interval is requested at once, in front of the arithmetic
             const int l = tr.ell[ir];
+            double t0[K + 1];
+            load_rows<K + 1>(t0, Ds + (size_t)SR::D0 * N, N, ir);
+            const double2 Lp = bL[ir], Rp = bR[ir];
+            __builtin_amdgcn_sched_barrier(0);
             double x, y;                    // the table's X, Y: of the current spline unless the table is stale
             if (RAISE && stale) { const double2 ps = ptab[ir]; x = ps.x; y = ps.y; }
             else {
-              x = seq_dot<K + 1>(cx + (l - K), Ds + (size_t)SR::D0 * N, N, ir);
-              y = seq_dot<K + 1>(cy + (l - K), Ds + (size_t)SR::D0 * N, N, ir);
+              x = seq_dot_v<K + 1>(cx + (l - K), t0);
+              y = seq_dot_v<K + 1>(cy + (l - K), t0);
             }
             const double B0 = Ds[(size_t)(SR::D0 + idx - l + K) * N + ir];
-            const double2 Lp = bL[ir], Rp = bR[ir];
             const double nzx = x - B0 * zx, nzy = y - B0 * zy;
             const double lbx = fmin(Lp.x, Rp.x) - nzx, ubx = fmax(Lp.x, Rp.x) - nzx;
             const double lby = fmin(Lp.y, Rp.y) - nzy, uby = fmax(Lp.y, Rp.y) - nzy;
