@@ -1369,7 +1369,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
               x = seq_dot_v<K + 1>(cx + (l - K), t0);
               y = seq_dot_v<K + 1>(cy + (l - K), t0);
             }
-            const double B0 = Ds[(size_t)(SR::D0 + idx - l + K) * N + ir];
+            // the basis value of idx at the sample is one of the K+1 table values in registers (a look-up would be a second,
+            // dependent memory round trip): a support sample has idx - l + K in 0..K
+            const int aa = idx - l + K;
+            double B0 = t0[0];
+#pragma unroll
+            for (int a2 = 1; a2 <= K; ++a2) B0 = aa == a2 ? t0[a2] : B0;
             const double nzx = x - B0 * zx, nzy = y - B0 * zy;
             const double lbx = fmin(Lp.x, Rp.x) - nzx, ubx = fmax(Lp.x, Rp.x) - nzx;
             const double lby = fmin(Lp.y, Rp.y) - nzy, uby = fmax(Lp.y, Rp.y) - nzy;
