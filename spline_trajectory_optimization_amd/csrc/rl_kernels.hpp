@@ -1398,10 +1398,30 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
       __syncthreads();                            // the clamp interval of waves 1..3 is in `red`
       RL_STAMP(st_t0); RL_STAMP_ADD(3, st_t0, st_t1);
     };
+    // the control point of the NEXT step and its support are fetched one step ahead: the look-up of the support would
+    // otherwise be a memory round trip at the head of every step, in front of everything else
+    // (through a per-lane index the compiler cannot see through: a value it knows to be uniform is moved to scalar registers
+    // where it is loaded, i.e. waited for at once)
+    auto lane_zero = []() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; };
+    int idx_n = total_steps > 0 ? step_index(0) : 0;
+    int s0_n = tr.sup[2 * idx_n + lane_zero()], s1_n = tr.sup[2 * idx_n + 1 + lane_zero()];
+    // (outer iteration, pass, step) of the next step, advanced by counting: step_index() divides three times
+    int it_n = 0, pass_n = 0, stp_n = 0, ist_n = total_steps > 0 ? a.i_start[0] : 0;
     for (int q = 0; q < total_steps; ++q) {
-      const int it = q / (2 * steps), pass = (q / steps) & 1;
-      const int idx = step_index(q);
-      const int s0 = tr.sup[2 * idx], s1 = tr.sup[2 * idx + 1];
+      const int it = it_n, pass = pass_n;
+      const int idx = idx_n;
+      const int s0 = __builtin_amdgcn_readfirstlane(s0_n), s1 = __builtin_amdgcn_readfirstlane(s1_n);
+      if (q + 1 < total_steps) {
+        if (++stp_n == steps) {
+          stp_n = 0;
+          pass_n ^= 1;
+          if (pass_n == 0) { ++it_n; ist_n = a.i_start[it_n]; }
+        }
+        idx_n = (pass_n == 0 ? stp_n : steps - stp_n) + ist_n;
+        if (idx_n >= i_max) idx_n = idx_n - i_max + i_min;
+        const int z = lane_zero();
+        s0_n = tr.sup[2 * idx_n + z]; s1_n = tr.sup[2 * idx_n + 1 + z];
+      }
       const double zx = cx[idx], zy = cy[idx];
       if (!np_raise && a.raise_flag && (a.np_raise_at_start || it >= 1)) {   // raise mode begins: flags of the whole line, once
         np_raise = true;
@@ -1419,7 +1439,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
       bool bad = false;
       double sacc = 0.0;   // lanes 0..5 of wave 0: the running sums, in sample order
       RL_STAMP(st_t0);
-      phase1(idx, q + 1 < total_steps ? step_index(q + 1) : -1, s0, s1, zx, zy, sacc, lox, hix, loy, hiy, bad);
+      phase1(idx, q + 1 < total_steps ? idx_n : -1, s0, s1, zx, zy, sacc, lox, hix, loy, hiy, bad);
       // ---- phase 2 (wave 0): the 2-variable QP in closed form (oracle: orc_qp_solve_separable), control point + wrap,
       // then the derivative-spline window of the next step
       if (wave == 0) {
@@ -1468,7 +1488,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if constexpr (!(LITE && RL_LITE_COST)) { if (q + 1 < total_steps) deriv_window(step_index(q + 1), kd1, kd2, kr1, kr2); }
+        if constexpr (!(LITE && RL_LITE_COST)) { if (q + 1 < total_steps) deriv_window(idx_n, kd1, kd2, kr1, kr2); }
       }
       RL_STAMP(st_t1); RL_STAMP_ADD(2, st_t1, st_t0);
       if (wave == 0) __builtin_amdgcn_s_setprio(0);
@@ -1547,7 +1567,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
       } else {
         ++n_skipped;
       }
-      if ((q + 1) % steps == 0) {
+      if (q + 1 == total_steps || stp_n == 0) {   // the last step of a pass (the counters already describe the next step)
         if (tid == 0 && a.n_success) a.n_success[(size_t)b * 2 * a.max_iter + 2 * it + pass] = ok_count;
         ok_count = 0;
       }
