@@ -87,10 +87,11 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------------
-SWEEP_LIMITER = ("VALU instruction issue: across the arithmetic modes and builds of rounds 5-6 the kernel time is 2.9 ps per executed "
-                 "VALU wave-instruction (1024 SIMDs, ~58 % of their cycles issuing, the rest the stalls of the steps' dependent chains "
-                 "at 4 workgroups per CU); the solver state is on chip: the HBM roofline is the one north_star designates, the kernel "
-                 "is not HBM bound (DESIGN.md section 5)")
+SWEEP_LIMITER = ("one instance's 610 dependent steps: the batch's 1024 workgroups all run at once (4 per CU), so the kernel time is the "
+                 "latency of one instance under that sharing.  Across every arithmetic mode and build of rounds 5-6 it is 2.9-3.0 ps per "
+                 "executed VALU wave-instruction (1024 SIMDs issuing ~56 % of their cycles); removing instructions or memory round "
+                 "trips from a step pays, moving work to idle waves does not (measured: DESIGN.md section 5).  The solver state is on "
+                 "chip: the HBM roofline is the one north_star designates, the kernel is not HBM bound")
 
 
 def profile_block(kernel):
