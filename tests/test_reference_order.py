@@ -541,3 +541,35 @@ def test_numpy_raise_semantics_g12_sliding_window(rl):
         pcx, pcy, _, pns = orc.run_joint_min_curvature_qp(t, cx, cy, k, length, N, g["ringL"], g["ringR"], i_start)
     np.testing.assert_array_equal(ns2, pns)
     np.testing.assert_array_equal(hcx2, pcx); np.testing.assert_array_equal(hcy2, pcy)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("offset", [(0.0, 0.0), (3.0e5, -7.0e5), (1.0e9, 1.0e9)])
+def test_window_scan_quick_sign_pass_far_from_the_origin(rl, fits, rings, monkeypatch, offset):
+    """The window scan's first pass takes the SIGN of every vertex's side value from a cheaper evaluation on untranslated
+    coordinates and trusts it only above a threshold that grows with the coordinates (rl_device.hpp: scan_window); below it the
+    wave runs the exact pass.  A track moved 1e6 / 1e9 m from the origin makes that threshold 1e3 / 1e6 times what it is on
+    Monza -- many waves fall back, many vertices sit near it: the windowed search still returns the brute-force search's bits,
+    in both arithmetics and both residencies, and in the reference-order arithmetic the oracle's."""
+    t, cx, cy, k, length = spline(fits, "c100")
+    N, B = 400, 5
+    widths = widths_like_monza(rl, fits, rings, "c100", N, B, seed=77)
+    cx = cx + offset[0]; cy = cy + offset[1]
+    i_start = rl.batch.default_i_start(len(cx), k, 2, seed=4)
+    trk = rl.lib.Track(rl.lib.Context.get(0), t, cx, cy, k, N)
+    for arith in (REF, rl.lib.ARITH_FAST):
+        res = {}
+        for residency in ("0", "1"):
+            monkeypatch.setenv("RL_FORCE_RESIDENCY", residency)
+            for search in (0, 2):
+                res[(residency, search)] = rl.ops.solve_batch_host(trk, rl.lib.BOUNDS_WIDTHS, widths, i_start, search=search, arith=arith)
+        base = res[("0", 0)]
+        print(f"offset {offset} arith {arith}: successful steps per pass {base[2][0].ravel().tolist()}")
+        if offset[0] < 1e8: assert int(base[2].sum()) > 0   # (at 1e9 m a coordinate's ulp is 1e-7 m: whatever happens, the modes agree)
+        for key, r in res.items():
+            np.testing.assert_array_equal(base[0], r[0], err_msg=f"arith {arith} {key}")
+            np.testing.assert_array_equal(base[2], r[2], err_msg=f"arith {arith} {key}")
+        if arith == REF:
+            with orc.cr_variant():
+                octrl, oxy, ons = orc.solve_width_batch(t, cx, cy, k, length, N, widths, i_start, nthreads=8)
+            np.testing.assert_array_equal(base[0], octrl); np.testing.assert_array_equal(base[2], ons)
