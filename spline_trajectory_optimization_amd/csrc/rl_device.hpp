@@ -294,7 +294,8 @@ constexpr int kWinBatch = 8;
 // of the window inside the stretch.
 template <int BATCH = kWinBatch, bool ST = false, typename RingPtr>
 __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo_edge, double px, double py,
-                                            double dx, double dy, Hit& h, const double* cmax_p) {
+                                            double dx, double dy, Hit& h, const double* cmax_p,
+                                            unsigned long long* counts = nullptr) {   // counts (diagnostic build): [1] exact passes, [2] pass-2 rounds, [3] scans
   // Pass 1 per vertex: its side value e, then TWO bookkeeping instructions -- the sign bit of e shifted into a 25-bit word
   // (v_alignbit) and a running minimum of |e|.  Edge q is a candidate when the signs of its two vertices differ; a vertex
   // exactly ON the line (e == +-0, seen as a zero minimum) makes every edge of the window a candidate.  That is a superset of
@@ -339,6 +340,9 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
       const double tol = 0x1p-46 * ((cmax_p[opaque_zero()] + fabs(px)) + fabs(py)) * (fabs(dx) + fabs(dy));   // read here: a register held across the scan would be spilled
       sure = emin > tol && tol > 0x1p-900 && tol < 0x1p+900;
     }
+#ifdef RL_STAMPS
+    if (counts) { counts[3] += 1; if (__any(!sure)) counts[1] += 1; }
+#endif
     if (__any(!sure)) {   // the exact pass, for the whole wave (a lane that was sure gets the same word again)
       double2 v = ring[lo];
       const double e0 = edge_side<ST>(v.x - px, v.y - py, dx, dy);
@@ -369,6 +373,9 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
     const bool sides_known = !__any(!sure);
     static_assert(kWinEdges == 24 && kWinEdges % BATCH == 0, "window scan is unrolled in whole batches; the candidate word holds 24 edges");
     while (__any(cand != 0u)) {
+#ifdef RL_STAMPS
+      if (counts) counts[2] += 1;
+#endif
       if (cand != 0u) {
         const int q = __ffs((int)cand) - 1;
         cand &= cand - 1u;
@@ -592,7 +599,7 @@ __device__ __forceinline__ Hit search_ring_windowed(RingPtr ring, int nr, Circle
         // bases are multiples of kChunk, so this only fails behind the seam of a ring whose length is not a multiple of
         // kChunk (off = lo - base + nr); such a lane is re-staged from its own window start (off = 0) below.
         if (todo && (off & (kChunk - 1)) == 0 && off + kWinEdges + 1 <= kStage) {
-          scan_window<kStageBatch, ST>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h, cmax);
+          scan_window<kStageBatch, ST>(StagedWindow{stg + stage_slot(off)}, nr, 0, lo, px, py, dx, dy, h, cmax, stamps);
           todo = false;
         }
       }

@@ -857,9 +857,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
   }
 
 #ifdef RL_STAMPS
+  unsigned long long st_cnt[4] = {0, 0, 0, 0};   // reference-order refresh: [0] window-scan cycles, [1] exact sign passes, [2] pass-2 rounds, [3] scans
+#define RL_STRICT_COUNTS st_cnt
   unsigned long long st_fine[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sf0 = 0, sf1 = 0;   // inside the refresh: evaluation, left ring, right ring, stores
 #define RL_FSTAMP(slot) do { RL_STAMP(sf1); st_fine[slot] += sf1 - sf0; sf0 = sf1; } while (0)
 #else
+#define RL_STRICT_COUNTS nullptr
 #define RL_FSTAMP(slot) do { } while (0)
 #endif
   // refresh(i0,i1,j0,j1): new p, normal and closest ring crossings for the samples of two ranges
@@ -948,10 +951,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           const double dLx = a.max_dist * hd.cl, dLy = a.max_dist * hd.sl;   // trajectory.py:87-88, norm = +pi/2
           const double dRx = a.max_dist * hd.cr, dRy = a.max_dist * hd.sr;   //                      norm = -pi/2
           const Hit hl = search_ring_windowed<STAGED, true>(rL, nL, circL, sepL, L.ncL, active, (int)hints[i], px, py,
-                                                            dLx, dLy, a.max_dist, cmax, false, nullptr, stgL, baseL);
+                                                            dLx, dLy, a.max_dist, cmax, false, RL_STRICT_COUNTS, stgL, baseL);
           RL_FSTAMP(1);
           const Hit hr = search_ring_windowed<STAGED, true>(rR, nR, circR, sepR, L.ncR, active, (int)hints[Npad + i], px, py,
-                                                            dRx, dRy, a.max_dist, cmax, false, nullptr, stgR, baseR);
+                                                            dRx, dRy, a.max_dist, cmax, false, RL_STRICT_COUNTS, stgR, baseR);
           RL_FSTAMP(2);
           if (active) {   // no crossing: best_s = 0, the waypoint itself (trajectory.py:127)
             const double2 Lp = make_double2(uf_madd(px, hl.best_s, dLx), uf_madd(py, hl.best_s, dLy));
@@ -2287,6 +2290,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
     double* o = a.dbg + ((size_t)b * NW + wave) * 16;
     for (int q = 0; q < 6; ++q) o[q] = (double)st_acc[q];
     for (int q = 0; q < 8; ++q) o[8 + q] = (double)st_fine[q];
+    if constexpr (STRICT) { o[11] = (double)st_cnt[3]; o[12] = (double)st_cnt[2]; o[14] = (double)st_cnt[1]; }   // scans, pass-2 rounds, exact sign passes (slot 14 otherwise: tiles that took the full heading)
     o[6] = (double)(st_t1 - st_begin);
     {   // where the wave ran: HW_ID (wave slot, SIMD, CU, shader array, shader engine) and the XCC
       unsigned hw, xcc;

@@ -23,3 +23,6 @@ print("kernel ms", out[4].kernel_ms)
 print("per wave, cycles per step, slots 0..5 (phase1, barA, phase2, barB, refresh(+ahead), barC), total:")
 for w in range(4):
     print(w, (s[:, w, :6].mean(axis=0) / 610).round(0).tolist(), round(s[:, w, 6].mean() / 610))
+if ARITH == 1:
+    sc, p2, ex = s[:, :, 11].sum(), s[:, :, 12].sum(), s[:, :, 14].sum()
+    print("window scans per instance %.0f, pass-2 rounds per scan %.3f, exact sign passes per scan %.4f" % (sc / B, p2 / sc, ex / sc))
