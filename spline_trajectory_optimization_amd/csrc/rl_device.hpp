@@ -445,8 +445,9 @@ __device__ __forceinline__ int window_start(int hint, int nchunk) {
 }
 
 // Request the stretch a wave's next window scan will read, ahead of time (the hints are known before the curve point is):
-// returns the base to hand to search_ring_windowed as `staged_base` (-1: no lane has a usable hint, nothing requested).
-// The search waits for the copy (stage_wait) before its first read.
+// returns the base to hand to search_ring_windowed as `staged_base`.  The search waits for the copy (stage_wait) before its
+// first read -- also when no lane had a usable hint and the stretch at 0 was fetched for nothing: the stretches share their
+// LDS with the cost terms of the next step, no copy may still be on its way when the refresh ends.
 __device__ __forceinline__ int stage_prefetch(const double2* ring, int nr, int nchunk, bool active, int hint, double2* stg, int lane) {
   const unsigned long long m = __ballot(active && hint >= 0 && hint < nr);
   // no branch: with no usable hint in the wave the stretch at 0 is fetched for nothing (see stage_issue on the wait counts)
@@ -455,7 +456,7 @@ __device__ __forceinline__ int stage_prefetch(const double2* ring, int nr, int n
   const int base = m ? lo : 0;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nobody still reads the stretch it replaces
   stage_issue(ring, nr, base, stg, lane);
-  return m ? base : -1;
+  return base;
 }
 
 // brute force over all edges; ring vertices as double2 (x,y), any address space
