@@ -1425,6 +1425,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
         const int z = lane_zero();
         s0_n = tr.sup[2 * idx_n + z]; s1_n = tr.sup[2 * idx_n + 1 + z];
       }
+#ifdef RL_EXTRA_BARRIER
+      __syncthreads();   // timing probe: what one more barrier per step costs
+#endif
       const double zx = cx[idx], zy = cy[idx];
       if (!np_raise && a.raise_flag && (a.np_raise_at_start || it >= 1)) {   // raise mode begins: flags of the whole line, once
         np_raise = true;
