@@ -402,7 +402,7 @@ __device__ __forceinline__ void scan_window(RingPtr ring, int nr, int lo, int lo
 // Requesting the stretches at the START of a step (before the cost pass, so that the refresh waits for no vertex at all)
 // was 2 % SLOWER than direct loads (9.88-10.02 ms): the step is not waiting for these loads (DESIGN_HISTORY.md section 3).
 constexpr int kStage = 96;
-constexpr int kStageBatch = 4;   // LDS reads in flight per lane (the latency of an LDS read is a sixth of an L2 round trip)
+constexpr int kStageBatch = 8;   // LDS reads in flight per lane (round 6: 4 -> 8 with the quick sign pass's shorter batches, -0.7 %; 12 spills)
 static_assert(kStage >= kWinEdges + 1 + 64 && kStage <= 104, "a stretch holds the windows of 64 consecutive chunk starts; two DMA instructions fill it");
 // LDS image of a stretch: vertex v of the stretch sits in slot v + (v >> 3) -- one empty 16-byte slot behind every chunk of 8.
 // The lanes of a wave scan windows that start 0, 8, 16, ... vertices into the stretch; unpadded, those starts are 128 bytes
