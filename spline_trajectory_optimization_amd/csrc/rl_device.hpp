@@ -101,6 +101,28 @@ __device__ __forceinline__ void eval_sample(const TrackDev& tr, CPtr cx, CPtr cy
   o.x = x; o.y = y; o.dx = dx; o.dy = dy; o.d2x = d2x; o.d2y = d2y;
 }
 
+// The same evaluation (same operations in the same order) that also hands back the basis values and second derivatives it
+// loaded: the basis value of a given control point at the sample is then a select among registers, not another look-up.
+template <int K, typename CPtr>
+__device__ __forceinline__ void eval_sample_keep(const TrackDev& tr, CPtr cx, CPtr cy, int i, int l, CurvePoint<K, 2>& o,
+                                                 double (&b0v)[K + 1], double (&b2v)[K + 1]) {
+  const int N = tr.N;
+  const double* __restrict__ D0 = tr.D;
+  const double* __restrict__ D1 = tr.D + (size_t)(K + 1) * N;
+  const double* __restrict__ D2 = tr.D + (size_t)2 * (K + 1) * N;
+  double x = 0, y = 0, dx = 0, dy = 0, d2x = 0, d2y = 0;
+#pragma unroll
+  for (int a = 0; a <= K; ++a) {
+    const double c_x = cx[l - K + a], c_y = cy[l - K + a];
+    const double b0 = D0[(size_t)a * N + i], b1 = D1[(size_t)a * N + i], b2 = D2[(size_t)a * N + i];
+    b0v[a] = b0; b2v[a] = b2;
+    x = fma(c_x, b0, x); y = fma(c_y, b0, y);
+    dx = fma(c_x, b1, dx); dy = fma(c_y, b1, dy);
+    d2x = fma(c_x, b2, d2x); d2y = fma(c_y, b2, d2y);
+  }
+  o.x = x; o.y = y; o.dx = dx; o.dy = dy; o.d2x = d2x; o.d2y = d2y;
+}
+
 // Left normal of the curve scaled to max_dist: max_dist * (cos, sin)(yaw + pi/2) without the trip
 // through atan2/cos/sin (the oracle takes that trip; the two agree to rounding).  One place, so
 // that the re-intersection and the constraint assembly see bit-identical direction vectors.

@@ -2160,10 +2160,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 512 || (!RINGS_LDS && !SIGMA_LDS &
           const int l = tr.ell[i];
           if (i == s0 + tid) l_keep = l;
           CurvePoint<K, 2> c;
-          eval_sample<K, 2>(tr, cx, cy, i, l, c);
+          double b0v[K + 1], b2v[K + 1];
+          eval_sample_keep<K>(tr, cx, cy, i, l, c, b0v, b2v);
+          // the basis function of idx at the sample and its second derivative: among the values just loaded (a support sample
+          // has idx - l + K in 0..K) -- a look-up by that index would be a second, dependent memory round trip
           const int aa = idx - l + K;
-          const double B2 = D2[(size_t)aa * N + i];
-          const double B0 = D0[(size_t)aa * N + i];
+          double B2 = b2v[0], B0 = b0v[0];
+#pragma unroll
+          for (int a2 = 1; a2 <= K; ++a2) { const bool hit = aa == a2; B2 = hit ? b2v[a2] : B2; B0 = hit ? b0v[a2] : B0; }
           double ndx, ndy, inv_s2;
           scaled_normal(c.dx, c.dy, a.max_dist, ndx, ndy, inv_s2);
           {
